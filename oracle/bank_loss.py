@@ -1,0 +1,51 @@
+"""Oracle: combiner + L2-normalise + scaled-negative bank InfoNCE (CPU fp32).
+
+Restates clip4cir/models_negplus.py:48-50 (element_wise_sum), :130-142 (bank_large_step)
+and :150-154 (infonce_loss with nn.CrossEntropyLoss, mean reduction); the zero-shot variant
+zscir/models_bank.py:90-101 differs only in which index selects the reference row and in an
+optional label_smoothing (zscir/models_bank.py:35).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def combine(ref_feats, text_feats):
+    # clip4cir/models_negplus.py:48-50
+    return ref_feats + text_feats
+
+
+def l2_normalize(x, eps=1e-12):
+    # F.normalize(p=2, dim=1): x / max(||x||, eps)  (clip4cir/models_negplus.py:137)
+    return x / x.norm(dim=1, keepdim=True).clamp_min(eps)
+
+
+def infonce(q, bank, labels, tau, label_smoothing=0.0):
+    """clip4cir/models_negplus.py:150-154: mean_i( logsumexp_j(l_ij) - l_i,y_i ), l = q bank^T / tau."""
+    logits = (q @ bank.t()) / tau
+    return F.cross_entropy(logits, labels.long(), label_smoothing=label_smoothing)
+
+
+def bank_large_step(refer_bank, refer_idx, text_feats, target_bank, labels, tau, label_smoothing=0.0):
+    """clip4cir/models_negplus.py:130-142.  ``refer_idx`` is reference_index_all when --plus,
+    else the triplet index; ``labels`` are unique-image ids (rows of target_bank)."""
+    r = refer_bank[refer_idx.long()].detach()
+    q = l2_normalize(combine(r, text_feats))
+    return infonce(q, target_bank.detach(), labels, tau, label_smoothing)
+
+
+def infonce_stats(q, bank, labels, tau):
+    """Per-row pieces used by the kernel tests: (row_lse, label_logit, row_loss)."""
+    logits = (q.double() @ bank.double().t()) / tau
+    lse = torch.logsumexp(logits, dim=1)
+    lab = logits[torch.arange(q.shape[0]), labels.long()]
+    return lse, lab, lse - lab
+
+
+def infonce_grad_q(q, bank, labels, tau, grad_scale=None):
+    """d(mean CE)/dq = ((softmax - onehot) / B) @ bank / tau, in fp64 for the kernel tests."""
+    B = q.shape[0]
+    logits = (q.double() @ bank.double().t()) / tau
+    g = torch.softmax(logits, dim=1)
+    g[torch.arange(B), labels.long()] -= 1.0
+    scale = (1.0 / B) if grad_scale is None else grad_scale
+    return (g @ bank.double()) * (scale / tau)
