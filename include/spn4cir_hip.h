@@ -1,0 +1,163 @@
+/* spn4cir_hip.h — C-ABI of libspn4cir_hip.so (MI355X / gfx950).
+ *
+ * The reference (BUAADreamer/SPN4CIR) is pure Python on stock PyTorch ops and has no FFI of
+ * its own; the seam this library sits under is the Python `CIRPlus` protocol
+ * (clip4cir/models_negplus.py:16-154, zscir/models_bank.py:18-134) and the torch ops it
+ * calls.  Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, < 0 = argument/shape/workspace error
+ *     (SPN_ERR_*), > 0 = hipError_t of a failed launch.  Nothing throws.
+ *   - all data pointers are DEVICE pointers owned by the caller; `bf16` buffers are raw
+ *     2-byte bfloat16 (void* in the signatures), `float` is fp32.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Calls only enqueue
+ *     work; no function synchronises the device or allocates memory.
+ *   - no mutable global state: one caller thread per stream, as under one-process-per-GPU DDP.
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef SPN4CIR_HIP_H
+#define SPN4CIR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPN_ABI_VERSION 1
+
+#define SPN_ERR_ARG (-1)
+#define SPN_ERR_SHAPE (-2)
+#define SPN_ERR_WORKSPACE (-3)
+
+#define SPN_ACT_NONE 0
+#define SPN_ACT_QUICKGELU 1 /* x*sigmoid(1.702x), clip/model.py:166-168 */
+#define SPN_ACT_GELU_ERF 2  /* exact GELU, blip4cir/med.py BertIntermediate */
+
+int spn_abi_version(void);
+const char* spn_error_string(int code);
+
+/* ---------------------------------------------------------------- GEMM (torch.nn.Linear, `@`)
+ * C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]); bf16 inputs, fp32 MFMA accumulation.
+ * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0.  Replaces F.linear inside
+ * nn.MultiheadAttention / mlp.c_fc / mlp.c_proj (clip/model.py:175-181,187). */
+int spn_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, int act,
+                void* out_bf16, float* out_f32, void* pre_act_out_bf16, int ldc, void* stream);
+/* out_f32 = resid + A.B^T + bias (residual add fused: `x = x + ...`, clip/model.py:190-191) */
+int spn_gemm_nt_resid(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias,
+                      const float* resid, int ldr, float* out_f32, void* out_bf16, int ldc, void* stream);
+/* out_bf16 = (A.B^T) * act'(pre_act)  (backward of the fused activation) */
+int spn_gemm_nt_dact(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const void* pre_act_bf16,
+                     int act, void* out_bf16, int ldc, void* stream);
+/* C[N1,N2] (fp32) = alpha * A[Kr,N1]^T . B[Kr,N2] (+ C): weight gradients dW = dY^T X (autograd of
+ * F.linear).  N1, N2 % 8 == 0.  ws: spn_gemm_tn_workspace_bytes() bytes of scratch. */
+int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
+                float alpha, int accumulate, void* ws, size_t ws_bytes, void* stream);
+size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2);
+
+/* ---------------------------------------------------------------- elementwise / reductions */
+int spn_cast_f32_bf16(const float* x, void* y_bf16, size_t n, void* stream);
+/* y = bf16(x) and yt = bf16(x)^T for x [rows, cols]; either output may be NULL */
+int spn_cast_transpose_f32_bf16(const float* x, void* y_bf16, void* yt_bf16, int rows, int cols, void* stream);
+/* out[c] (+)= sum_r x[r][c]  (bias gradients) */
+int spn_colsum_bf16(const void* x_bf16, int rows, int cols, int ld, float* out, int accumulate, void* ws,
+                    size_t ws_bytes, void* stream);
+size_t spn_colsum_workspace_bytes(int rows, int cols);
+
+/* ---------------------------------------------------------------- LayerNorm (clip/model.py:157-163)
+ * fp32 statistics over fp32 input; outputs bf16 and/or fp32. W % 4 == 0, W <= 2048. */
+int spn_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
+                      float* rstd, int rows, int W, float eps, void* stream);
+int spn_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, int accumulate_dx, void* dx_bf16, float* dgamma, float* dbeta,
+                      int accumulate_dparam, int rows, int W, void* ws, size_t ws_bytes, void* stream);
+size_t spn_layernorm_bwd_workspace_bytes(int rows, int W);
+
+/* ---------------------------------------------------------------- attention core, head_dim 64
+ * softmax(scale * q k^T + causal mask + key_bias) v per (batch, head); q rows b*Lq+i, k/v rows
+ * b*Lk+j, head h at column h*64.  Replaces the core of nn.MultiheadAttention
+ * (clip/model.py:186-187 with the -inf causal mask of :330-336) and BertSelfAttention
+ * (blip4cir/med.py:196-234; key_bias = the (1-mask)*-10000 extended mask). */
+int spn_attention_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
+                      float* lse, const float* key_bias, int B, int H, int Lq, int Lk, int causal, float scale,
+                      void* stream);
+int spn_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* o, int ldo,
+                      const float* lse, const float* key_bias, const void* d_o, int lddo, void* dq, void* dk, void* dv,
+                      int lddq, int lddk, int lddv, float* delta_ws, int B, int H, int Lq, int Lk, int causal,
+                      float scale, void* stream);
+
+/* ---------------------------------------------------------------- embedding (clip/model.py:346-348) */
+int spn_embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W,
+                  int vocab, void* stream);
+int spn_embed_bwd(const int32_t* ids, const int32_t* eot_or_null, const float* dx, float* dtok_zeroed, float* dpos,
+                  int B, int L, int W, int vocab, void* stream);
+
+/* ---------------------------------------------------------------- combiner + normalise
+ * q = F.normalize(refer_bank[ref_idx] + text)   (models_negplus.py:48-50,133-137).
+ * refer_bank may be NULL (q = normalize(text)).  q_bf16 has leading dim ldq >= D (pad is zeroed). */
+int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
+                           void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream);
+int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const float* dq, float* dtext, int B, int D,
+                           void* stream);
+
+/* ---------------------------------------------------------------- bank InfoNCE
+ * models_negplus.py:150-154: logits = (q @ bank.T)/tau ; CrossEntropyLoss(logits, labels).
+ * The bank (or this rank's shard of it: rows [m_begin, m_begin+M) of the global bank) is a
+ * device-resident bf16 [M, D] matrix of L2-normalised rows; D in {128,256,512,640,768,1024}.
+ *   stats[b] = {max_j l_bj, sum_j exp(l_bj - max), sum_j l_bj, l_b,label (or -inf)} over the shard. */
+int spn_bank_stats_fwd(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int M, int D,
+                       int m_begin, float inv_tau, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* combine nshards stats blocks [nshards][B][4] -> row_lse[B], row_loss[B], loss_mean[1] */
+int spn_bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
+                           float* row_lse, float* row_loss, float* loss_mean, void* stream);
+/* dq[b,:] = grad_scale * inv_tau * sum_j (softmax_bj - target_bj) bank[j,:] over the shard
+ * (grad_scale = GradScaler scale / B_global for the mean loss) */
+int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int M, int D,
+                    int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
+                    float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
+size_t spn_bank_workspace_bytes(int B, int M, int D);
+
+/* ---------------------------------------------------------------- AdamW (train_negplus.py:77-83)
+ * torch.optim.AdamW semantics; g is multiplied by inv_scale (GradScaler.unscale_), the step is
+ * skipped when *found_inf != 0 (GradScaler.step).  step is 1-based. */
+int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float inv_scale, const float* found_inf, void* stream);
+int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream);
+
+/* ---------------------------------------------------------------- Recall@K (validate.py:28-33)
+ * scores[i][j] = <q_i, g_j> accumulated in fp64; top-K by (score desc, index asc), skipping
+ * exclude[i] (the reference image, validate.py:39,130-134) when exclude != NULL. */
+int spn_cosine_scores_f64(const float* q, const float* gallery, int Nq, int Ng, int D, double* scores, void* stream);
+int spn_topk_from_scores(const double* scores, int Nq, int Ng, int K, const int32_t* exclude, int32_t* idx,
+                         double* val, void* stream);
+
+/* ---------------------------------------------------------------- CLIP text tower
+ * CLIP.encode_text (clip/model.py:345-358) forward and its backward, 12 x
+ * ResidualAttentionBlock (:171-192).  Parameters live in ONE flat fp32 buffer laid out by
+ * spn_text_layout(); the GEMM weights are mirrored (plus transposes) in a flat bf16 buffer
+ * that spn_text_refresh_bf16() rewrites after every optimizer step. */
+typedef struct {
+    int B, L, L_ctx, W, H, layers, D, vocab;
+} spn_text_cfg;
+
+typedef struct {
+    int64_t tok, pos, blocks, block_size, lnf_g, lnf_b, text_proj, n_params;
+    /* inside a block: ln1_g ln1_b w_qkv b_qkv w_o b_o ln2_g ln2_b w_fc b_fc w_proj b_proj, [12] = size */
+    int64_t block_off[13];
+    int64_t bf16_block_size, bf16_text_proj, bf16_text_proj_t, n_bf16;
+} spn_text_layout_t;
+
+int spn_text_layout(const spn_text_cfg* cfg, spn_text_layout_t* out);
+size_t spn_text_act_bytes(const spn_text_cfg* cfg);
+size_t spn_text_ws_bytes(const spn_text_cfg* cfg);
+int spn_text_refresh_bf16(const spn_text_cfg* cfg, const float* params, void* weights_bf16, void* stream);
+int spn_text_fwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                 void* acts, float* feats, void* stream);
+int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                 void* acts, const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPN4CIR_HIP_H */

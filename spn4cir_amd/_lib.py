@@ -1,0 +1,97 @@
+"""ctypes binding of libspn4cir_hip.so (the C-ABI declared in include/spn4cir_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a symbol is
+absent, loading raises and every op fails loudly.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspn4cir_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "spn4cir_hip.h")
+
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class TextCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "L_ctx", "W", "H", "layers", "D", "vocab")]
+
+
+class TextLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("tok", "pos", "blocks", "block_size", "lnf_g", "lnf_b", "text_proj",
+                                         "n_params")] + [("block_off", C.c_int64 * 13)] + \
+               [(n, C.c_int64) for n in ("bf16_block_size", "bf16_text_proj", "bf16_text_proj_t", "n_bf16")]
+
+
+_SIGS = {
+    "spn_abi_version": (i32, []),
+    "spn_error_string": (C.c_char_p, [i32]),
+    "spn_gemm_nt": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]),
+    "spn_gemm_nt_resid": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
+    "spn_gemm_nt_dact": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
+    "spn_gemm_tn": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, i32, vp, sz, vp]),
+    "spn_gemm_tn_workspace_bytes": (sz, [i32, i32, i32]),
+    "spn_cast_f32_bf16": (i32, [vp, vp, sz, vp]),
+    "spn_cast_transpose_f32_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
+    "spn_colsum_bf16": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "spn_colsum_workspace_bytes": (sz, [i32, i32]),
+    "spn_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "spn_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
+    "spn_layernorm_bwd_workspace_bytes": (sz, [i32, i32]),
+    "spn_attention_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "spn_attention_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, vp,
+                                i32, i32, i32, i32, i32, f32, vp]),
+    "spn_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spn_embed_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spn_combine_l2norm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "spn_combine_l2norm_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "spn_bank_stats_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
+    "spn_bank_loss_finalize": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),
+    "spn_bank_grad_q": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),
+    "spn_bank_workspace_bytes": (sz, [i32, i32, i32]),
+    "spn_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
+    "spn_grad_check_finite": (i32, [vp, sz, vp, vp]),
+    "spn_cosine_scores_f64": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "spn_topk_from_scores": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "spn_text_layout": (i32, [C.POINTER(TextCfg), C.POINTER(TextLayout)]),
+    "spn_text_act_bytes": (sz, [C.POINTER(TextCfg)]),
+    "spn_text_ws_bytes": (sz, [C.POINTER(TextCfg)]),
+    "spn_text_refresh_bf16": (i32, [C.POINTER(TextCfg), vp, vp, vp]),
+    "spn_text_fwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp]),
+    "spn_text_bwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/spn4cir_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(spn_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the library; raises if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C spn4cir_amd/csrc`). spn4cir_amd has no CPU fallback.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(handle, name)          # AttributeError if the symbol is absent
+        fn.restype, fn.argtypes = res, args
+    if handle.spn_abi_version() != 1:
+        raise RuntimeError("libspn4cir_hip.so ABI version mismatch")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().spn_error_string(rc).decode()
+        raise RuntimeError(f"spn4cir_hip {what} failed: {msg} (code {rc})")

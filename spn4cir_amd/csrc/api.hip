@@ -1,0 +1,221 @@
+// extern "C" surface of libspn4cir_hip.so: thin argument marshalling over the C++ kernels.
+#include "../../include/spn4cir_hip.h"
+#include "tower.h"
+
+using namespace spn;
+
+static_assert(sizeof(spn_text_cfg) == sizeof(TextCfg), "spn_text_cfg layout");
+static_assert(sizeof(spn_text_layout_t) == sizeof(TextLayout), "spn_text_layout_t layout");
+
+#define ST(s) ((hipStream_t)(s))
+#define BF(p) ((bf16_t*)(p))
+#define CBF(p) ((const bf16_t*)(p))
+
+extern "C" {
+
+int spn_abi_version(void) { return SPN_ABI_VERSION; }
+
+const char* spn_error_string(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case SPN_ERR_ARG: return "invalid argument";
+        case SPN_ERR_SHAPE: return "unsupported shape / alignment";
+        case SPN_ERR_WORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int spn_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, int act,
+                void* out_bf16, float* out_f32, void* pre_act_out_bf16, int ldc, void* stream) {
+    GemmEpilogue e;
+    e.bias = bias; e.act = act; e.out_bf16 = BF(out_bf16); e.out_f32 = out_f32; e.aux_out = BF(pre_act_out_bf16);
+    e.ldc = ldc;
+    return gemm_nt(CBF(A), CBF(B), M, N, K, lda, ldb, GEMM_STORE, e, ST(stream));
+}
+
+int spn_gemm_nt_resid(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias,
+                      const float* resid, int ldr, float* out_f32, void* out_bf16, int ldc, void* stream) {
+    GemmEpilogue e;
+    e.bias = bias; e.resid = resid; e.ldr = ldr; e.out_f32 = out_f32; e.out_bf16 = BF(out_bf16); e.ldc = ldc;
+    return gemm_nt(CBF(A), CBF(B), M, N, K, lda, ldb, GEMM_RESID, e, ST(stream));
+}
+
+int spn_gemm_nt_dact(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const void* pre_act_bf16,
+                     int act, void* out_bf16, int ldc, void* stream) {
+    GemmEpilogue e;
+    e.aux_in = CBF(pre_act_bf16); e.act = act; e.out_bf16 = BF(out_bf16); e.ldc = ldc;
+    return gemm_nt(CBF(A), CBF(B), M, N, K, lda, ldb, GEMM_DACT, e, ST(stream));
+}
+
+int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
+                float alpha, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_tn(CBF(A), CBF(B), Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2) { return gemm_tn_workspace_bytes(Kr, N1, N2); }
+
+int spn_cast_f32_bf16(const float* x, void* y, size_t n, void* stream) { return cast_f32_bf16(x, BF(y), n, ST(stream)); }
+
+int spn_cast_transpose_f32_bf16(const float* x, void* y, void* yt, int rows, int cols, void* stream) {
+    return cast_transpose_f32_bf16(x, BF(y), BF(yt), rows, cols, ST(stream));
+}
+
+int spn_colsum_bf16(const void* x, int rows, int cols, int ld, float* out, int accumulate, void* ws, size_t ws_bytes,
+                    void* stream) {
+    return colsum_bf16(CBF(x), rows, cols, ld, out, accumulate, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_colsum_workspace_bytes(int rows, int cols) { return colsum_workspace_bytes(rows, cols); }
+
+int spn_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
+                      float* rstd, int rows, int W, float eps, void* stream) {
+    return layernorm_fwd(x, gamma, beta, BF(y_bf16), y_f32, mean, rstd, rows, W, eps, ST(stream));
+}
+
+int spn_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, int accumulate_dx, void* dx_bf16, float* dgamma, float* dbeta,
+                      int accumulate_dparam, int rows, int W, void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_bwd(CBF(dy_bf16), dy_f32, x, gamma, mean, rstd, dx, accumulate_dx, BF(dx_bf16), dgamma, dbeta,
+                         accumulate_dparam, rows, W, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_layernorm_bwd_workspace_bytes(int rows, int W) { return layernorm_bwd_workspace_bytes(rows, W); }
+
+static AttnArgs make_attn(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
+                          float* lse, const float* key_bias, int B, int H, int Lq, int Lk, int causal, float scale) {
+    AttnArgs a;
+    a.q = CBF(q); a.k = CBF(k); a.v = CBF(v); a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.o = BF(o); a.ldo = ldo; a.lse = lse; a.key_bias = key_bias;
+    a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.causal = causal; a.scale = scale;
+    return a;
+}
+
+int spn_attention_fwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
+                      float* lse, const float* key_bias, int B, int H, int Lq, int Lk, int causal, float scale,
+                      void* stream) {
+    if (!q || !k || !v || !o) return SPN_ERR_ARG;
+    return attention_fwd(make_attn(q, k, v, ldq, ldk, ldv, o, ldo, lse, key_bias, B, H, Lq, Lk, causal, scale),
+                         ST(stream));
+}
+
+int spn_attention_bwd(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* o, int ldo,
+                      const float* lse, const float* key_bias, const void* d_o, int lddo, void* dq, void* dk, void* dv,
+                      int lddq, int lddk, int lddv, float* delta_ws, int B, int H, int Lq, int Lk, int causal,
+                      float scale, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv) return SPN_ERR_ARG;
+    AttnBwdArgs g;
+    g.f = make_attn(q, k, v, ldq, ldk, ldv, const_cast<void*>(o), ldo, const_cast<float*>(lse), key_bias, B, H, Lq, Lk,
+                    causal, scale);
+    g.d_o = CBF(d_o); g.lddo = lddo;
+    g.dq = BF(dq); g.dk = BF(dk); g.dv = BF(dv); g.lddq = lddq; g.lddk = lddk; g.lddv = lddv;
+    g.delta = delta_ws;
+    return attention_bwd(g, ST(stream));
+}
+
+int spn_embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W,
+                  int vocab, void* stream) {
+    return embed_fwd(ids, tok_emb, pos_emb, x, B, L, W, vocab, ST(stream));
+}
+
+int spn_embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,
+                  int vocab, void* stream) {
+    return embed_bwd(ids, eot, dx, dtok, dpos, B, L, W, vocab, ST(stream));
+}
+
+int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
+                           void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream) {
+    return combine_l2norm_fwd(refer_bank, ref_idx, text, q_f32, BF(q_bf16), inv_norm, B, D, ldq, ST(stream));
+}
+
+int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const float* dq, float* dtext, int B, int D,
+                           void* stream) {
+    return combine_l2norm_bwd(q_f32, inv_norm, dq, dtext, B, D, ST(stream));
+}
+
+static BankArgs make_bank(const void* q, int ldq, const void* bank, const int64_t* labels, int B, int M, int D,
+                          int m_begin, float inv_tau) {
+    BankArgs a;
+    a.q = CBF(q); a.ldq = ldq; a.bank = CBF(bank); a.labels = labels;
+    a.B = B; a.M = M; a.D = D; a.m_begin = m_begin; a.inv_tau = inv_tau;
+    return a;
+}
+
+int spn_bank_stats_fwd(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int M, int D,
+                       int m_begin, float inv_tau, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!stats) return SPN_ERR_ARG;
+    return bank_stats_fwd(make_bank(q_bf16, ldq, bank_bf16, labels, B, M, D, m_begin, inv_tau), stats, (float*)ws,
+                          ws_bytes, ST(stream));
+}
+
+int spn_bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
+                           float* row_lse, float* row_loss, float* loss_mean, void* stream) {
+    if (!stats) return SPN_ERR_ARG;
+    return bank_loss_finalize(stats, nshards, B, M_total, label_smoothing, row_lse, row_loss, loss_mean, ST(stream));
+}
+
+int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int M, int D,
+                    int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
+                    float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream) {
+    return bank_grad_q(make_bank(q_bf16, ldq, bank_bf16, labels, B, M, D, m_begin, inv_tau), row_lse, label_smoothing,
+                       M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_bank_workspace_bytes(int B, int M, int D) { return bank_workspace_bytes(B, M, D); }
+
+int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float inv_scale, const float* found_inf, void* stream) {
+    if (!p || !g || !m || !v) return SPN_ERR_ARG;
+    return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, inv_scale, found_inf, ST(stream));
+}
+
+int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream) {
+    if (!g || !found_inf) return SPN_ERR_ARG;
+    return grad_unscale_check(const_cast<float*>(g), n, 1.0f, found_inf, ST(stream));
+}
+
+int spn_cosine_scores_f64(const float* q, const float* gallery, int Nq, int Ng, int D, double* scores, void* stream) {
+    if (!q || !gallery || !scores) return SPN_ERR_ARG;
+    return cosine_scores_f64(q, gallery, Nq, Ng, D, scores, ST(stream));
+}
+
+int spn_topk_from_scores(const double* scores, int Nq, int Ng, int K, const int32_t* exclude, int32_t* idx,
+                         double* val, void* stream) {
+    if (!scores || !idx) return SPN_ERR_ARG;
+    return topk_from_scores(scores, Nq, Ng, K, exclude, idx, val, ST(stream));
+}
+
+static TextCfg tc(const spn_text_cfg* c) {
+    TextCfg t;
+    t.B = c->B; t.L = c->L; t.L_ctx = c->L_ctx; t.W = c->W; t.H = c->H; t.layers = c->layers; t.D = c->D;
+    t.vocab = c->vocab;
+    return t;
+}
+
+int spn_text_layout(const spn_text_cfg* cfg, spn_text_layout_t* out) {
+    if (!cfg || !out) return SPN_ERR_ARG;
+    text_layout(tc(cfg), reinterpret_cast<TextLayout*>(out));
+    return SPN_OK;
+}
+
+size_t spn_text_act_bytes(const spn_text_cfg* cfg) { return cfg ? text_act_bytes(tc(cfg)) : 0; }
+size_t spn_text_ws_bytes(const spn_text_cfg* cfg) { return cfg ? text_ws_bytes(tc(cfg)) : 0; }
+
+int spn_text_refresh_bf16(const spn_text_cfg* cfg, const float* params, void* weights_bf16, void* stream) {
+    if (!cfg || !params || !weights_bf16) return SPN_ERR_ARG;
+    return text_refresh_bf16(tc(cfg), params, BF(weights_bf16), ST(stream));
+}
+
+int spn_text_fwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                 void* acts, float* feats, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !feats) return SPN_ERR_ARG;
+    return text_fwd(tc(cfg), params, CBF(weights_bf16), ids, (char*)acts, feats, ST(stream));
+}
+
+int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                 void* acts, const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !dfeats || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd(tc(cfg), params, CBF(weights_bf16), ids, (char*)acts, dfeats, grads, (char*)ws, ws_bytes,
+                    ST(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,469 @@
+// Scaled-negative bank InfoNCE: combiner + L2-normalise, streaming similarity + online
+// softmax statistics over the static negative bank, and the gradient w.r.t. the queries.
+// Restates models_negplus.py:130-154 (bank_large_step / infonce_loss) without ever writing
+// the B x M logits.
+//
+// Structure ("attention with K = V = bank"): a block owns a 32-query tile and one contiguous
+// chunk of bank rows; bank tiles of 32 rows x D (bf16) are DMA'd into LDS (buffer_load...lds,
+// double buffered) and each tile is used twice from LDS:
+//   logits   S[q][m]  = sum_d q[q][d] bank[m][d]      bank rows read d-contiguous (ds_read_b128)
+//   gradient dq[q][d] += sum_m G[q][m] bank[m][d]     bank rows read m-contiguous (ds_read_b64_tr_b16)
+// Work split inside the block: wave w owns the d-slice [w*D/4, (w+1)*D/4): its q fragments stay
+// in registers for the whole kernel, it produces a partial S over its slice (summed through LDS)
+// and accumulates dq for its slice.  With B_local = 32 (8-way data parallel at B = 256) the bank
+// is read from HBM exactly once per pass; with several query tiles the blocks that share a bank
+// chunk are co-scheduled on one XCD so the chunk is served from that XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace spn {
+
+static constexpr int BQ = 32;   // queries per block
+static constexpr int TR = 32;   // bank rows per LDS tile
+
+__device__ __forceinline__ f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ combiner + normalise
+// q = normalize(refer_bank[ref_idx] + text)   (models_negplus.py:133-137; F.normalize eps 1e-12)
+__global__ void combine_l2norm_fwd_kernel(const float* __restrict__ refer, const int64_t* __restrict__ ref_idx,
+                                          const float* __restrict__ text, float* __restrict__ qf,
+                                          bf16_t* __restrict__ qb, float* __restrict__ inv_norm, int B, int D, int ldq) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* r = refer ? refer + (size_t)ref_idx[b] * D : nullptr;
+    const float* t = text + (size_t)b * D;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 x = *(const f32x4*)(t + c);
+        if (r) x += *(const f32x4*)(r + c);
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    if (lane == 0 && inv_norm) inv_norm[b] = inv;
+    for (int c = lane * 4; c < ldq; c += 256) {
+        f32x4 x = {0, 0, 0, 0};
+        if (c < D) {
+            x = *(const f32x4*)(t + c);
+            if (r) x += *(const f32x4*)(r + c);
+            x *= inv;
+            if (qf) *(f32x4*)(qf + (size_t)b * D + c) = x;
+        }
+        if (qb) {
+            bf16x4 o = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+            *(bf16x4*)(qb + (size_t)b * ldq + c) = o;
+        }
+    }
+}
+
+int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
+                       bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st) {
+    if (B <= 0 || D <= 0) return SPN_ERR_ARG;
+    if (D % 4 || ldq % 4 || ldq < D || (refer_bank && !ref_idx)) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(combine_l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, refer_bank, ref_idx, text, q_f32,
+                       q_bf16, inv_norm, B, D, ldq);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// x = r + t, q = x * inv  =>  dx = inv * (dq - q * <q, dq>)  (valid while ||x|| > eps); dtext = dx
+__global__ void combine_l2norm_bwd_kernel(const float* __restrict__ q, const float* __restrict__ inv_norm,
+                                          const float* __restrict__ dq, float* __restrict__ dtext, int B, int D) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float dot = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 a = *(const f32x4*)(q + (size_t)b * D + c), g = *(const f32x4*)(dq + (size_t)b * D + c);
+        dot += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+    dot = wave_sum(dot);
+    const float inv = inv_norm[b];
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 a = *(const f32x4*)(q + (size_t)b * D + c), g = *(const f32x4*)(dq + (size_t)b * D + c);
+        *(f32x4*)(dtext + (size_t)b * D + c) = (g - a * dot) * inv;
+    }
+}
+
+int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, float* dtext, int B, int D,
+                       hipStream_t st) {
+    if (B <= 0 || D <= 0) return SPN_ERR_ARG;
+    if (D % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(combine_l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, q, inv_norm, dq, dtext, B, D);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ------------------------------------------------------------------------ bank streaming
+// LDS image of a bank tile [TR rows][D] bf16: row r at byte r*2D; the 16-byte chunk holding
+// logical columns 8c..8c+7 sits at chunk position c ^ swz(r&15).  swz is a bit permutation
+// chosen so that (a) 16 consecutive rows at one logical chunk (ds_read_b128 logit fragments)
+// and (b) rows {r..r+3, r+8..r+11} at one logical 32-byte pair (ds_read_b64_tr_b16 gradient
+// fragments) both spread over all 64 banks.
+__device__ __forceinline__ int bank_swz(int r) {
+    return (((r & 3) | (((r >> 3) & 1) << 2)) << 1) | ((r >> 2) & 1);
+}
+
+struct BankChunking {
+    int nq;         // query tiles
+    int nchunks;    // bank chunks
+    int rows;       // rows per chunk (multiple of TR)
+};
+
+static BankChunking bank_chunking(int B, int M) {
+    BankChunking c;
+    c.nq = (B + BQ - 1) / BQ;
+    int n = 256 / c.nq;
+    if (n < 1) n = 1;
+    const int tiles = (M + TR - 1) / TR;
+    if (n > tiles) n = tiles;
+    const int tiles_per = (tiles + n - 1) / n;
+    c.rows = tiles_per * TR;
+    c.nchunks = (M + c.rows - 1) / c.rows;
+    return c;
+}
+
+template <int D, bool BWD>
+__global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChunking ck, const float* __restrict__ row_lse,
+                                                            float label_smoothing, float inv_m_total,
+                                                            float* __restrict__ ws) {
+    constexpr int DW = D / 4;            // columns per wave
+    constexpr int KSW = DW / 32;         // 32-deep k-steps per wave in the logit GEMM
+    constexpr int NDT = DW / 16;         // 16-wide d tiles per wave in the gradient GEMM
+    constexpr int ROWB = D * 2;          // bytes per bank row
+    constexpr int TILE_B = TR * ROWB;
+    constexpr int GLDS_PER_WAVE = D / 64;
+    constexpr int LDG = TR + 8;          // G row stride (elements): 80 B rows, 16-B aligned
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tiles = smem;                                  // 2 x TILE_B
+    float* Sp = (float*)(smem + 2 * TILE_B);             // [4 waves][2 mt][2 nt][64 lanes][4]
+    bf16_t* Gs = (bf16_t*)(smem + 2 * TILE_B + 4 * 4096);   // [BQ][LDG]
+    float* Fin = (float*)(smem + 2 * TILE_B);            // reuse of Sp at the end (forward stats)
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
+    const int q0 = qi * BQ;
+    const int m_lo = mi * ck.rows;
+    const int m_hi = min(a.M, m_lo + ck.rows);
+    const int ntiles = m_hi > m_lo ? (m_hi - m_lo + TR - 1) / TR : 0;
+
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)ROWB);
+
+    // query fragments of this wave's d-slice (B operand: j = query, k = d)
+    bf16x8 qf[2][KSW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int qr = q0 + mt * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+            if (qr < a.B) {
+                qf[mt][ks] = *(const bf16x8*)(a.q + (size_t)qr * a.ldq + w * DW + ks * 32 + (lane >> 4) * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[mt][ks][e] = (bf16_t)0.0f;
+            }
+        }
+    }
+
+    // softmax-phase ownership: wave w owns query sub-tile mt_o and key sub-tile nt_o of each tile;
+    // lane owns query q_o and keys nt_o*16 + (lane>>4)*4 + 0..3
+    const int mt_o = w >> 1, nt_o = w & 1;
+    const int q_o = q0 + mt_o * 16 + (lane & 15);
+    const bool q_ok = q_o < a.B;
+    const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;
+    float lse = 0.f;
+    if constexpr (BWD) lse = q_ok ? row_lse[q_o] : 0.f;
+    float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
+
+    f32x4 dq[2][NDT];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[mt][dt] = f32x4{0, 0, 0, 0};
+    }
+
+    auto stage = [&](int t, int buf) {
+        char* dst = tiles + buf * TILE_B;
+        const int mrow0 = m_lo + t * TR;
+#pragma unroll
+        for (int i = 0; i < GLDS_PER_WAVE; ++i) {
+            const int ii = w * GLDS_PER_WAVE + i;
+            const int p = ii * 1024 + lane * 16;
+            const int r = p / ROWB, cp = (p % ROWB) >> 4;
+            const int c = cp ^ bank_swz(r & 15);
+            glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)c * 16u);
+        }
+    };
+
+    if (ntiles > 0) stage(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        wait_vm0();
+        __syncthreads();
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        const char* T = tiles + buf * TILE_B;
+
+        // ---- logits over this wave's d-slice: D[i = key][j = query]
+        f32x4 s[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int r = nt * 16 + (lane & 15);
+                const int c = (w * DW + ks * 32) / 8 + (lane >> 4);
+                const bf16x8 bfrag = *(const bf16x8*)(T + r * ROWB + ((c ^ bank_swz(r & 15)) << 4));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) s[mt][nt] = mfma16b(bfrag, qf[mt][ks], s[mt][nt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = s[mt][nt];
+        __syncthreads();
+        f32x4 sv = {0, 0, 0, 0};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
+
+        const int key0 = m_lo + t * TR + nt_o * 16 + (lane >> 4) * 4;   // shard-local row of sv[0]
+        if constexpr (!BWD) {
+            float tm = -INFINITY;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = (key0 + r < a.M) ? sv[r] * a.inv_tau : -INFINITY;
+                tm = fmaxf(tm, v[r]);
+            }
+            if (tm > -INFINITY) {
+                const float mn = fmaxf(st_m, tm);
+                float add = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (key0 + r < a.M) {
+                        add += __expf(v[r] - mn);
+                        st_sl += v[r];
+                        if ((int64_t)(key0 + r) == label) st_lab = v[r];
+                    }
+                }
+                st_l = st_l * __expf(st_m - mn) + add;
+                st_m = mn;
+            }
+        } else {
+            bf16x4 gb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gv = 0.f;
+                if (q_ok && key0 + r < a.M) {
+                    gv = __expf(sv[r] * a.inv_tau - lse) - label_smoothing * inv_m_total;
+                    if ((int64_t)(key0 + r) == label) gv -= 1.0f - label_smoothing;
+                }
+                gb[r] = f2bf(gv);
+            }
+            *(bf16x4*)(Gs + (mt_o * 16 + (lane & 15)) * LDG + nt_o * 16 + (lane >> 4) * 4) = gb;
+            __syncthreads();
+            // ---- dq[q][d] += sum_key G[q][key] bank[key][d]:  D[i = d][j = query], k = key (one 32-step)
+            bf16x8 gf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                gf[mt] = *(const bf16x8*)(Gs + (mt * 16 + (lane & 15)) * LDG + (lane >> 4) * 8);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                union { s16x4 h[2]; bf16x8 v; } u;
+                const int cb = w * DW + dt * 16;   // first column of this d tile
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+                    const int col = cb + (lane & 3) * 4;
+                    u.h[h] = lds_tr16_b64(T + r * ROWB + (((col >> 3) ^ bank_swz(r & 15)) << 4) + (col & 7) * 2);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) dq[mt][dt] = mfma16b(u.v, gf[mt], dq[mt][dt]);
+            }
+        }
+    }
+
+    if constexpr (!BWD) {
+        // combine the 4 lane groups (lane>>4) and the 2 key-half waves of each query row
+        __syncthreads();
+        float* f = Fin + ((w * 64 + lane) * 4);
+        f[0] = st_m; f[1] = st_l; f[2] = st_sl; f[3] = st_lab;
+        __syncthreads();
+        if (tid < BQ) {
+            const int mt = tid >> 4, ql = tid & 15;
+            float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+            for (int nt = 0; nt < 2; ++nt)
+                for (int g = 0; g < 4; ++g) {
+                    const float* p = Fin + (((mt * 2 + nt) * 64 + g * 16 + ql) * 4);
+                    const float mn = fmaxf(m, p[0]);
+                    if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+                    m = mn;
+                    sl += p[2];
+                    lab = fmaxf(lab, p[3]);
+                }
+            const int q = q0 + tid;
+            if (q < a.B) {
+                float* o = ws + ((size_t)mi * a.B + q) * 4;
+                o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = q0 + mt * 16 + (lane & 15);
+            if (q >= a.B) continue;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
+        }
+    }
+}
+
+// fold per-chunk statistics [n][B][4] -> [B][4]
+__global__ void bank_stats_fold_kernel(const float* __restrict__ ws, int n, int B, float* __restrict__ stats) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= B) return;
+    float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        const float* p = ws + ((size_t)i * B + q) * 4;
+        const float mn = fmaxf(m, p[0]);
+        if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+        m = mn;
+        sl += p[2];
+        lab = fmaxf(lab, p[3]);
+    }
+    float* o = stats + (size_t)q * 4;
+    o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+}
+
+// loss_row = lse - (1-eps)*label_logit - eps*mean_j logit_j   (CrossEntropyLoss w/ label smoothing)
+__global__ void bank_loss_finalize_kernel(const float* __restrict__ stats, int nshards, int B, float inv_m_total,
+                                          float label_smoothing, float* __restrict__ row_lse,
+                                          float* __restrict__ row_loss, float* __restrict__ loss_mean) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int q = threadIdx.x; q < B; q += blockDim.x) {
+        float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+        for (int i = 0; i < nshards; ++i) {
+            const float* p = stats + ((size_t)i * B + q) * 4;
+            const float mn = fmaxf(m, p[0]);
+            if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+            m = mn;
+            sl += p[2];
+            lab = fmaxf(lab, p[3]);
+        }
+        const float lse = m + logf(l);
+        const float loss = lse - (1.0f - label_smoothing) * lab - label_smoothing * sl * inv_m_total;
+        if (row_lse) row_lse[q] = lse;
+        if (row_loss) row_loss[q] = loss;
+        acc += loss;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss_mean) *loss_mean = red[0] / (float)B;
+}
+
+size_t bank_workspace_bytes(int B, int M, int D) {
+    const BankChunking c = bank_chunking(B, M);
+    const size_t a = (size_t)c.nchunks * B * 4 * sizeof(float);
+    const size_t b = (size_t)c.nchunks * B * D * sizeof(float);
+    return a > b ? a : b;
+}
+
+template <int D, bool BWD>
+static int launch_bank(const BankArgs& a, const BankChunking& c, const float* row_lse, float ls, float inv_m,
+                       float* ws, hipStream_t st) {
+    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2;
+    auto kern = bank_stream_kernel<D, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+#define SPN_BANK_DISPATCH(BWD_, ...)                                   \
+    switch (a.D) {                                                     \
+        case 128: rc = launch_bank<128, BWD_>(__VA_ARGS__); break;     \
+        case 256: rc = launch_bank<256, BWD_>(__VA_ARGS__); break;     \
+        case 512: rc = launch_bank<512, BWD_>(__VA_ARGS__); break;     \
+        case 640: rc = launch_bank<640, BWD_>(__VA_ARGS__); break;     \
+        case 768: rc = launch_bank<768, BWD_>(__VA_ARGS__); break;     \
+        case 1024: rc = launch_bank<1024, BWD_>(__VA_ARGS__); break;   \
+        default: return SPN_ERR_SHAPE;                                 \
+    }
+
+static int bank_check(const BankArgs& a) {
+    if (a.B <= 0 || a.M <= 0 || !a.q || !a.bank || !a.labels) return SPN_ERR_ARG;
+    if (a.ldq % 8 || a.ldq < a.D) return SPN_ERR_SHAPE;
+    if ((uint64_t)a.M * a.D * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    return SPN_OK;
+}
+
+int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st) {
+    int rc = bank_check(a);
+    if (rc) return rc;
+    const BankChunking c = bank_chunking(a.B, a.M);
+    if (ws_bytes < (size_t)c.nchunks * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
+    SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)
+    if (rc) return rc;
+    hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, ws, c.nchunks, a.B, stats);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
+                       float* row_lse, float* row_loss, float* loss_mean, hipStream_t st) {
+    if (nshards <= 0 || B <= 0 || M_total <= 0) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(bank_loss_finalize_kernel, dim3(1), dim3(256), 0, st, stats, nshards, B, 1.0f / (float)M_total,
+                       label_smoothing, row_lse, row_loss, loss_mean);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void bank_dq_fold_kernel(const float* __restrict__ ws, int n, int B, int D, float alpha,
+                                    float* __restrict__ dq, int accumulate) {
+    const int d4 = D >> 2;
+    const size_t total = (size_t)B * d4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0, 0, 0, 0};
+        for (int z = 0; z < n; ++z) s += *(const f32x4*)(ws + (size_t)z * B * D + i * 4);
+        s *= alpha;
+        if (accumulate) s += *(const f32x4*)(dq + i * 4);
+        *(f32x4*)(dq + i * 4) = s;
+    }
+}
+
+int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
+                float* dq, float* ws, size_t ws_bytes, hipStream_t st) {
+    int rc = bank_check(a);
+    if (rc) return rc;
+    if (!row_lse || !dq || M_total <= 0) return SPN_ERR_ARG;
+    const BankChunking c = bank_chunking(a.B, a.M);
+    if (ws_bytes < (size_t)c.nchunks * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
+    SPN_BANK_DISPATCH(true, a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
+    if (rc) return rc;
+    const size_t total = (size_t)a.B * (a.D / 4);
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(bank_dq_fold_kernel, dim3(blocks), dim3(256), 0, st, ws, c.nchunks, a.B, a.D,
+                       grad_scale * a.inv_tau, dq, 0);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+}  // namespace spn

@@ -1,0 +1,95 @@
+// Shared device helpers for the spn4cir_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPN_OK 0
+#define SPN_ERR_ARG (-1)
+#define SPN_ERR_SHAPE (-2)
+#define SPN_ERR_WORKSPACE (-3)
+
+#define SPN_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return (int)e__;              \
+    } while (0)
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+static constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over the 16 lanes that share (lane >> 4): xor 1,2,4,8
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+
+// Buffer resource over [base, base+bytes): raw buffer, out-of-range reads return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// 16-byte async global->LDS copy: LDS destination = lds_base (wave-uniform) + lane*16.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, uint32_t voffset_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset_bytes, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LDS transpose read: within each 16-lane group the 16 lanes address a 4x16 block of 16-bit
+// elements (lane i -> row i>>2, columns (i&3)*4..+3, 8 bytes each); lane i receives column i
+// (rows 0..3).  See cdna_hip_programming.md T10.
+__device__ __forceinline__ s16x4 lds_tr16_b64(const void* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+}
+
+// Bijective XCD-aware remap of a 1-D block id (cdna_hip_programming.md T1): blocks that the
+// dispatcher places on one XCD (id % 8) get a contiguous range of logical ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x * fast_sigmoid(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+    const float s = fast_sigmoid(1.702f * x);
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,328 @@
+// HBM-bound helper kernels: casts, transposes, column sums, embedding gather/scatter,
+// EOT pooling, fused AdamW.  All are streaming kernels: 16-byte accesses per lane,
+// grid-stride loops, grids capped at 2048 blocks (cdna guide G11/G13).
+#include "common.h"
+#include "kernels.h"
+
+namespace spn {
+
+static inline int grid_for(size_t work_items, int block = 256, int cap = 2048) {
+    size_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    return (int)(b > (size_t)cap ? cap : b);
+}
+
+// ------------------------------------------------------------------------------- casts
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    const size_t n8 = n >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(x + i * 8), b = *(const f32x4*)(x + i * 8 + 4);
+        bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+        *(bf16x8*)(y + i * 8) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(n8 << 3) + threadIdx.x] = f2bf(x[(n8 << 3) + threadIdx.x]);
+}
+
+int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
+    if (n == 0) return SPN_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, x, y, n);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// y (optional, bf16 copy) and yt (optional, bf16 transpose) of x [rows, cols]; 32x32 tiles via LDS.
+template <typename TIN>
+__global__ void cast_transpose_kernel(const TIN* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ yt,
+                                      int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tiles_c = (cols + 31) / 32;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = tr * 32 + ty + i * 8, c = tc * 32 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = (float)x[(size_t)r * cols + c];
+            if (y) y[(size_t)r * cols + c] = f2bf(v);
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+    if (yt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tc * 32 + ty + i * 8, r = tr * 32 + tx;
+            if (r < rows && c < cols) yt[(size_t)c * rows + r] = f2bf(tile[tx][ty + i * 8]);
+        }
+    }
+}
+
+int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return SPN_ERR_ARG;
+    const int tiles = ((rows + 31) / 32) * ((cols + 31) / 32);
+    hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3(tiles), dim3(256), 0, st, x, y, yt, rows, cols);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return SPN_ERR_ARG;
+    const int tiles = ((rows + 31) / 32) * ((cols + 31) / 32);
+    hipLaunchKernelGGL(cast_transpose_kernel<bf16_t>, dim3(tiles), dim3(256), 0, st, x, (bf16_t*)nullptr, y, rows, cols);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ----------------------------------------------------------------------------- column sums
+// out[c] (+)= sum_r x[r][c]; two stages: CS_ROWS row-slabs x column groups -> ws, then fold.
+static constexpr int CS_SLABS = 64;
+
+__global__ void colsum_partial_kernel(const bf16_t* __restrict__ x, int rows, int cols, int ld,
+                                      float* __restrict__ ws) {
+    // block: 256 threads = 32 column-octets x 8 row lanes; covers 256 columns
+    const int cg = blockIdx.x, slab = blockIdx.y;
+    const int co = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = cg * 256 + co * 8;
+    const int rows_per = (rows + CS_SLABS - 1) / CS_SLABS;
+    const int r0 = slab * rows_per, r1 = min(rows, r0 + rows_per);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < cols) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const bf16x8 v = *(const bf16x8*)(x + (size_t)r * ld + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+    }
+    __shared__ float red[8][256 + 8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][co * 8 + e] = acc[e];
+    __syncthreads();
+    const int t = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][t];
+    if (cg * 256 + t < cols) ws[(size_t)slab * cols + cg * 256 + t] = s;
+}
+
+__global__ void colsum_fold_kernel(const float* __restrict__ ws, int cols, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < CS_SLABS; ++k) s += ws[(size_t)k * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+size_t colsum_workspace_bytes(int rows, int cols) { return (size_t)CS_SLABS * cols * sizeof(float); }
+
+int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
+                hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return SPN_ERR_ARG;
+    if (cols % 8 || ld % 8) return SPN_ERR_SHAPE;
+    if (ws_bytes < colsum_workspace_bytes(rows, cols)) return SPN_ERR_WORKSPACE;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, CS_SLABS), dim3(256), 0, st, x, rows, cols, ld, ws);
+    SPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, ws, cols, out, accumulate);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ------------------------------------------------------------------------------- embedding
+// x[b,l,:] = tok_emb[ids[b,l],:] + pos_emb[l,:]      (clip/model.py:346-348)
+__global__ void embed_fwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
+                                 const float* __restrict__ pos, float* __restrict__ x, int BL, int L, int W, int vocab) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)BL * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 t = *(const f32x4*)(tok + (size_t)id * W + c);
+        const f32x4 p = *(const f32x4*)(pos + (size_t)(row % L) * W + c);
+        *(f32x4*)(x + (size_t)row * W + c) = t + p;
+    }
+}
+
+int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W, int vocab,
+              hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, tok_emb,
+                       pos_emb, x, B * L, L, W, vocab);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// dtok[ids[b,l],:] += dx[b,l,:] for l <= eot[b] (rows after the EOT token have zero gradient under
+// the causal mask and are skipped); dtok must be zero on entry.  dpos[l,:] = sum_b dx[b,l,:].
+__global__ void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ eot,
+                                     const float* __restrict__ dx, float* __restrict__ dtok, int BL, int L, int W,
+                                     int vocab) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)BL * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        const int b = row / L, l = row % L;
+        if (eot && l > eot[b]) continue;
+        int id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 g = *(const f32x4*)(dx + (size_t)row * W + c);
+        float* d = dtok + (size_t)id * W + c;
+        atomicAdd(d + 0, g[0]);
+        atomicAdd(d + 1, g[1]);
+        atomicAdd(d + 2, g[2]);
+        atomicAdd(d + 3, g[3]);
+    }
+}
+
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B, int L, int W) {
+    const int l = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
+        f32x4 s = {0, 0, 0, 0};
+        for (int b = 0; b < B; ++b) s += *(const f32x4*)(dx + ((size_t)b * L + l) * W + c);
+        *(f32x4*)(dpos + (size_t)l * W + c) = s;
+    }
+}
+
+int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,
+              int vocab, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    if (dtok) {
+        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, eot, dx,
+                           dtok, B * L, L, W, vocab);
+        SPN_CHECK_LAUNCH();
+    }
+    if (dpos) {
+        hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(L), dim3(256), 0, st, dx, dpos, B, L, W);
+        SPN_CHECK_LAUNCH();
+    }
+    return SPN_OK;
+}
+
+// eot[b] = argmax_l ids[b,l] (first maximum), clip/model.py:356
+__global__ void eot_argmax_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ eot, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int best = ids[(size_t)b * L], bi = 0;
+    for (int l = 1; l < L; ++l) {
+        const int v = ids[(size_t)b * L + l];
+        if (v > best) { best = v; bi = l; }
+    }
+    eot[b] = bi;
+}
+
+int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st) {
+    hipLaunchKernelGGL(eot_argmax_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ids, eot, B, L);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ eot, float* __restrict__ out,
+                                   int L, int W) {
+    const int b = blockIdx.x;
+    const float* src = x + ((size_t)b * L + eot[b]) * W;
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) *(f32x4*)(out + (size_t)b * W + c) = *(const f32x4*)(src + c);
+}
+
+int gather_rows_f32(const float* x, const int32_t* eot, float* out, int B, int L, int W, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, st, x, eot, out, L, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// dx[b,l,:] = (l == eot[b]) ? src[b,:] : 0 ; also the bf16 copy
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ eot, float* __restrict__ dx,
+                                    bf16_t* __restrict__ dxb, int BL, int L, int W) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)BL * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        const int b = row / L, l = row % L;
+        f32x4 v = {0, 0, 0, 0};
+        if (l == eot[b]) v = *(const f32x4*)(src + (size_t)b * W + c);
+        *(f32x4*)(dx + (size_t)row * W + c) = v;
+        if (dxb) {
+            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(dxb + (size_t)row * W + c) = o;
+        }
+    }
+}
+
+int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx_bf16, int B, int L, int W,
+                     hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, src, eot, dx,
+                       dx_bf16, B * L, L, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ---------------------------------------------------------------------------------- AdamW
+// torch.optim.AdamW semantics (decoupled weight decay), train_negplus.py:77-83.  g is
+// multiplied by inv_scale first (GradScaler unscale); the whole step is skipped when
+// *found_inf != 0 (GradScaler.step semantics).
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float rsqrt_bc2, float inv_scale, const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.f) return;
+    const size_t n4 = n >> 2;
+    const float step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 P = *(const f32x4*)(p + i * 4), G = *(const f32x4*)(g + i * 4);
+        f32x4 Mv = *(const f32x4*)(m + i * 4), V = *(const f32x4*)(v + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = G[e] * inv_scale;
+            float pe = P[e] * (1.0f - lr * wd);
+            const float me = b1 * Mv[e] + (1.0f - b1) * gr;
+            const float ve = b2 * V[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(ve) * rsqrt_bc2 + eps;
+            pe -= step_size * (me / denom);
+            P[e] = pe; Mv[e] = me; V[e] = ve;
+        }
+        *(f32x4*)(p + i * 4) = P;
+        *(f32x4*)(m + i * 4) = Mv;
+        *(f32x4*)(v + i * 4) = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float gr = g[i] * inv_scale;
+        float pe = p[i] * (1.0f - lr * wd);
+        const float me = b1 * m[i] + (1.0f - b1) * gr;
+        const float ve = b2 * v[i] + (1.0f - b2) * gr * gr;
+        pe -= step_size * (me / (sqrtf(ve) * rsqrt_bc2 + eps));
+        p[i] = pe; m[i] = me; v[i] = ve;
+    }
+}
+
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st) {
+    if (n == 0) return SPN_OK;
+    if (step < 1) return SPN_ERR_ARG;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
+                       (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// GradScaler inf check: *found_inf = 1 if any g is non-finite (g is not modified; the
+// unscale is folded into adamw_step through inv_scale).
+__global__ void grad_check_kernel(const float* __restrict__ g, size_t n, float* __restrict__ found_inf) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = g[i];
+        bad |= !(fabsf(x) <= 3.402823466e38f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
+}
+
+int grad_unscale_check(float* g, size_t n, float inv_scale, float* found_inf, hipStream_t st) {
+    (void)inv_scale;
+    hipLaunchKernelGGL(grad_check_kernel, dim3(grid_for(n)), dim3(256), 0, st, g, n, found_inf);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+}  // namespace spn

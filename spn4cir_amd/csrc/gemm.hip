@@ -1,0 +1,330 @@
+// bf16 MFMA GEMMs for the text / vision / fusion towers (gfx950).
+//
+//   gemm_nt : C[M,N]  = epilogue( A[M,K] . B[N,K]^T )      both operands K-contiguous
+//   gemm_tn : C[N1,N2] = A[Kr,N1]^T . B[Kr,N2]              both operands reduction-major
+//                                                           (weight gradients: dW = dY^T X)
+//
+// 128x128 output tile, 64-deep K step, 256 threads = 4 waves (2x2), each wave 64x64 =
+// 4x4 v_mfma_f32_16x16x32_bf16 tiles, fp32 accumulation.  Operand tiles are DMA'd straight
+// into LDS with buffer_load ... lds (16 B / lane, out-of-range rows read as zero) into an
+// XOR-swizzled image (swizzle applied to the per-lane SOURCE address, cdna guide rule 21)
+// so that the ds_read_b128 / ds_read_b64_tr_b16 fragment reads are bank-conflict free.
+// Two LDS stages: tile t+1 streams in while tile t is multiplied.
+#include "common.h"
+#include "kernels.h"
+
+namespace spn {
+
+static constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+static constexpr int TILE_BYTES = 128 * 64 * 2;   // one operand tile = 16 KiB
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// NT mainloop pieces (shared with the bank kernels through kernels.h is not needed; local)
+// ---------------------------------------------------------------------------------------
+// LDS image of a [128 rows][64 k] bf16 tile: row r at byte r*128; the 16-byte chunk holding
+// logical k-chunk c (8 elements) sits at position c ^ ((r>>1)&7).
+__device__ __forceinline__ int nt_swz(int r, int c) { return c ^ ((r >> 1) & 7); }
+
+__device__ __forceinline__ void nt_stage(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0,
+                                         int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R0 = (wid * 4 + i) * 8;
+        const int r = R0 + (lane >> 3);
+        const int c = nt_swz(r, lane & 7);
+        const uint32_t off = ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u;
+        glds16(rs, sT + R0 * 128, off);
+    }
+}
+
+__device__ __forceinline__ bf16x8 nt_frag(const char* sT, int r, int c) {
+    return *(const bf16x8*)(sT + r * 128 + (nt_swz(r, c) << 4));
+}
+
+template <int MODE, int ACT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A,
+                                                              const bf16_t* __restrict__ B, int M, int N, int K,
+                                                              int lda, int ldb, GemmEpilogue ep) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    nt_stage(rsA, smem, m0, lda, 0, wid, lane);
+    nt_stage(rsB, smem + TILE_BYTES, n0, ldb, 0, wid, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        wait_vm0();
+        __syncthreads();   // tile kt landed for every wave; everyone finished reading buf^1
+        if (kt + 1 < nk) {
+            char* nxt = smem + (buf ^ 1) * 2 * TILE_BYTES;
+            nt_stage(rsA, nxt, m0, lda, (kt + 1) * BK, wid, lane);
+            nt_stage(rsB, nxt + TILE_BYTES, n0, ldb, (kt + 1) * BK, wid, lane);
+        }
+        const char* sA = smem + buf * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+            const int c = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = nt_frag(sA, wr * 64 + i * 16 + (lane & 15), c);
+                b[i] = nt_frag(sB, wc * 64 + i * 16 + (lane & 15), c);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+        }
+    }
+
+    // Epilogue.  With the (B-fragment, A-fragment) operand order each lane owns, per 16x16
+    // tile, row m = lane&15 and the 4 consecutive columns n = (lane>>4)*4 .. +3.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[i][j] * ep.alpha;
+            if (ep.bias) v += *(const f32x4*)(ep.bias + n);
+            const size_t o = (size_t)m * ep.ldc + n;
+            if constexpr (MODE == GEMM_STORE) {
+                if constexpr (ACT != ACT_NONE) {
+                    if (ep.aux_out) {
+                        bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        *(bf16x4*)(ep.aux_out + o) = p;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                }
+            } else if constexpr (MODE == GEMM_RESID) {
+                v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
+            } else if constexpr (MODE == GEMM_DACT) {
+                const bf16x4 p = *(const bf16x4*)(ep.aux_in + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = bf2f(p[e]);
+                    v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                }
+            }
+            if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
+            if (ep.out_bf16) {
+                bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *(bf16x4*)(ep.out_bf16 + o) = p;
+            }
+        }
+    }
+}
+
+int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
+            const GemmEpilogue& ep, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return SPN_ERR_ARG;
+    if (K % BK || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
+    if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+#define SPN_LAUNCH_NT(MODE_, ACT_)                                                                              \
+    hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K, lda, ldb, ep)
+    if (mode == GEMM_STORE) {
+        if (ep.act == ACT_NONE) SPN_LAUNCH_NT(GEMM_STORE, ACT_NONE);
+        else if (ep.act == ACT_QUICKGELU) SPN_LAUNCH_NT(GEMM_STORE, ACT_QUICKGELU);
+        else if (ep.act == ACT_GELU_ERF) SPN_LAUNCH_NT(GEMM_STORE, ACT_GELU_ERF);
+        else return SPN_ERR_ARG;
+    } else if (mode == GEMM_RESID) {
+        if (!ep.resid || !ep.out_f32) return SPN_ERR_ARG;
+        SPN_LAUNCH_NT(GEMM_RESID, ACT_NONE);
+    } else if (mode == GEMM_DACT) {
+        if (!ep.aux_in) return SPN_ERR_ARG;
+        if (ep.act == ACT_QUICKGELU) SPN_LAUNCH_NT(GEMM_DACT, ACT_QUICKGELU);
+        else if (ep.act == ACT_GELU_ERF) SPN_LAUNCH_NT(GEMM_DACT, ACT_GELU_ERF);
+        else return SPN_ERR_ARG;
+    } else {
+        return SPN_ERR_ARG;
+    }
+#undef SPN_LAUNCH_NT
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// TN: C[N1,N2] (fp32) = sum_k A[k][n1] * B[k][n2], optional split over k (grid.y).
+// LDS image of a [64 k][128 n] bf16 tile: row k at byte k*256; the 32-byte chunk holding
+// logical columns 16*c..16*c+15 sits at position c ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2, so
+// the 8 rows touched by one 32-lane half of a ds_read_b64_tr_b16 hit 8 distinct bank groups.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+__device__ __forceinline__ void tn_stage(__amdgpu_buffer_rsrc_t rs, char* sT, int kbase, int ld, int col0,
+                                         int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R0 = (wid * 4 + i) * 4;
+        const int r = R0 + (lane >> 4);
+        const int pos16 = lane & 15;
+        const int c32 = (pos16 >> 1) ^ tn_f(r);
+        const uint32_t off = ((uint32_t)(kbase + r) * (uint32_t)ld + (uint32_t)(col0 + c32 * 16 + (pos16 & 1) * 8)) * 2u;
+        glds16(rs, sT + R0 * 256, off);
+    }
+}
+
+// fragment for the 16 columns [cb, cb+16) and the 32 k-rows [ks*32, ks*32+32): lane l gets
+// column cb + (l&15), k = ks*32 + (l>>4)*8 + 0..7
+__device__ __forceinline__ bf16x8 tn_frag(const char* sT, int cb, int ks, int lane) {
+    union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int krow = ks * 32 + (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+        const int p32 = (cb >> 4) ^ tn_f(krow);
+        u.h[h] = lds_tr16_b64(sT + krow * 256 + p32 * 32 + (lane & 3) * 8);
+    }
+    return u.v;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A,
+                                                              const bf16_t* __restrict__ B, int Kr, int N1, int N2,
+                                                              int lda, int ldb, float* __restrict__ C, int ldc,
+                                                              size_t split_stride, int k_chunk) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_n = (N2 + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int kb = blockIdx.y * k_chunk;
+    const int ke = min(Kr, kb + k_chunk);
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)Kr * (uint32_t)lda * 2u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)Kr * (uint32_t)ldb * 2u);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (ke - kb + BK - 1) / BK;
+    if (nk > 0) {
+        tn_stage(rsA, smem, kb, lda, m0, wid, lane);
+        tn_stage(rsB, smem + TILE_BYTES, kb, ldb, n0, wid, lane);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        wait_vm0();
+        __syncthreads();
+        if (kt + 1 < nk) {
+            char* nxt = smem + (buf ^ 1) * 2 * TILE_BYTES;
+            tn_stage(rsA, nxt, kb + (kt + 1) * BK, lda, m0, wid, lane);
+            tn_stage(rsB, nxt + TILE_BYTES, kb + (kt + 1) * BK, ldb, n0, wid, lane);
+        }
+        const char* sA = smem + buf * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = tn_frag(sA, wr * 64 + i * 16, ks, lane);
+                b[i] = tn_frag(sB, wc * 64 + i * 16, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.y * split_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= N1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= N2) continue;
+            *(f32x4*)(Cz + (size_t)m * ldc + n) = acc[i][j];
+        }
+    }
+}
+
+// out[r*ldo + c] = (accumulate ? out : 0) + alpha * sum_z ws[z][r][c]
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int rows, int cols,
+                                     float* __restrict__ out, int ldo, float alpha, int accumulate) {
+    const int c4 = cols >> 2;
+    const size_t total = (size_t)rows * c4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splits; ++z) s += *(const f32x4*)(ws + ((size_t)z * rows + r) * cols + c);
+        s *= alpha;
+        float* o = out + (size_t)r * ldo + c;
+        if (accumulate) s += *(const f32x4*)o;
+        *(f32x4*)o = s;
+    }
+}
+
+int gemm_tn_splits(int Kr, int N1, int N2) {
+    const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    const int ktiles = (Kr + BK - 1) / BK;
+    int s = 512 / tiles;
+    if (s < 1) s = 1;
+    const int max_s = (ktiles + 3) / 4;   // at least ~4 k-tiles per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return s;
+}
+
+size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2) {
+    const int s = gemm_tn_splits(Kr, N1, N2);
+    return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+}
+
+int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
+            float alpha, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (Kr <= 0 || N1 <= 0 || N2 <= 0) return SPN_ERR_ARG;
+    if (N1 % 8 || N2 % 8 || lda % 8 || ldb % 8 || ldc % 4) return SPN_ERR_SHAPE;
+    if ((uint64_t)Kr * lda * 2 >= (1ull << 32) || (uint64_t)Kr * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    int splits = gemm_tn_splits(Kr, N1, N2);
+    const bool direct = (splits == 1 && !accumulate && alpha == 1.0f);
+    if (!direct && ws_bytes < (size_t)splits * N1 * N2 * sizeof(float)) return SPN_ERR_WORKSPACE;
+    const int ktiles = (Kr + BK - 1) / BK;
+    const int k_chunk = ((ktiles + splits - 1) / splits) * BK;
+    splits = (Kr + k_chunk - 1) / k_chunk;
+    if (direct) {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, 1), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, C, ldc,
+                           (size_t)0, k_chunk);
+        SPN_CHECK_LAUNCH();
+        return SPN_OK;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, ws, N2,
+                       (size_t)N1 * N2, k_chunk);
+    SPN_CHECK_LAUNCH();
+    const size_t total = (size_t)N1 * (N2 / 4);
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha,
+                       accumulate);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+}  // namespace spn

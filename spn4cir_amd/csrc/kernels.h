@@ -1,0 +1,106 @@
+// Internal C++ interface between the kernel translation units and the C-ABI (api.hip).
+#pragma once
+#include "common.h"
+#include <stddef.h>
+
+namespace spn {
+
+enum { GEMM_STORE = 0, GEMM_RESID = 1, GEMM_DACT = 2 };
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2 };
+
+struct GemmEpilogue {
+    const float* bias = nullptr;     // [N] fp32, added before everything else
+    const float* resid = nullptr;    // GEMM_RESID: fp32 [M, ldr] added to the result
+    const bf16_t* aux_in = nullptr;  // GEMM_DACT: pre-activation, result *= act'(aux_in)
+    bf16_t* aux_out = nullptr;       // GEMM_STORE with act: pre-activation copy (bf16)
+    bf16_t* out_bf16 = nullptr;
+    float* out_f32 = nullptr;
+    int ldc = 0;                     // leading dim of out_bf16 / out_f32 / aux_in / aux_out
+    int ldr = 0;
+    int act = ACT_NONE;
+    float alpha = 1.0f;
+};
+
+// gemm.hip
+int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
+            const GemmEpilogue& ep, hipStream_t st);
+int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
+            float alpha, int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2);
+
+// elementwise.hip
+int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
+int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);             // y[c][r] = x[r][c]
+int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int cols, hipStream_t st);
+int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
+                hipStream_t st);
+size_t colsum_workspace_bytes(int rows, int cols);
+int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W, int vocab,
+              hipStream_t st);
+int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,
+              int vocab, hipStream_t st);
+int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st);
+int gather_rows_f32(const float* x, const int32_t* eot, float* out, int B, int L, int W, hipStream_t st);
+int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx_bf16, int B, int L, int W,
+                     hipStream_t st);
+int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st);
+int grad_unscale_check(float* g, size_t n, float inv_scale, float* found_inf, hipStream_t st);
+
+// norm.hip
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32, float* mean,
+                  float* rstd, int rows, int W, float eps, hipStream_t st);
+int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
+                  const float* rstd, float* dx, int accumulate_dx, bf16_t* dx_bf16, float* dgamma, float* dbeta,
+                  int accumulate_dparam, int rows, int W, float* ws, size_t ws_bytes, hipStream_t st);
+size_t layernorm_bwd_workspace_bytes(int rows, int W);
+
+// attention.hip
+struct AttnArgs {
+    const bf16_t *q, *k, *v;         // row b*Lq+i (q) / b*Lk+j (k,v); head h at column h*64
+    int ldq, ldk, ldv;
+    bf16_t* o; int ldo;              // [B*Lq, H*64]
+    float* lse;                      // [B, H, Lq] log-sum-exp of the scaled scores
+    const float* key_bias;           // optional additive bias per key [B, Lk] (BERT padding mask), may be null
+    int B, H, Lq, Lk, causal;
+    float scale;
+};
+struct AttnBwdArgs {
+    AttnArgs f;
+    const bf16_t* d_o; int lddo;
+    bf16_t *dq, *dk, *dv; int lddq, lddk, lddv;
+    float* delta;                    // workspace [B, H, Lq]
+};
+int attention_fwd(const AttnArgs& a, hipStream_t st);
+int attention_bwd(const AttnBwdArgs& a, hipStream_t st);
+
+// bank.hip
+int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
+                       bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st);
+int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, float* dtext, int B, int D,
+                       hipStream_t st);
+struct BankArgs {
+    const bf16_t* q; int ldq;        // [B, D] L2-normalised queries
+    const bf16_t* bank;              // [M_local, D]
+    const int64_t* labels;           // [B] global row ids
+    int B, M, D;                     // M = rows in this shard
+    int m_begin;                     // global id of row 0 of this shard
+    float inv_tau;
+};
+// forward: per-row partial softmax statistics over this shard
+//   stats[b] = {max, sum exp(l - max), sum l, label logit (or -inf if the label is not in the shard)}
+int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t ws_bytes, hipStream_t st);
+// finalize on the owner of all shards' stats: row_lse, row_loss and the mean loss
+int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
+                       float* row_lse, float* row_loss, float* loss_mean, hipStream_t st);
+// backward: dq[b] (+)= grad_scale * inv_tau * sum_m (softmax - target) bank[m]
+int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
+                float* dq /*[B,D] fp32*/, float* ws, size_t ws_bytes, hipStream_t st);
+size_t bank_workspace_bytes(int B, int M, int D);
+
+// topk.hip
+int cosine_scores_f64(const float* q, const float* gallery, int Nq, int Ng, int D, double* out, hipStream_t st);
+int topk_from_scores(const double* scores, int Nq, int Ng, int K, const int32_t* exclude, int32_t* idx, double* val,
+                     hipStream_t st);
+
+}  // namespace spn

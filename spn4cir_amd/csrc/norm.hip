@@ -1,0 +1,214 @@
+// LayerNorm forward / backward (fp32 statistics, as clip/model.py:157-163 up-casts to fp32).
+// One wave per row, the row held in registers (W <= 64*4*MAXV); HBM-bound streaming kernels.
+#include "common.h"
+#include "kernels.h"
+
+namespace spn {
+
+static constexpr int LN_MAXV_LIMIT = 8;   // float4 per lane -> W <= 2048
+
+// y = (x - mean) * rstd * gamma + beta
+template <int LN_MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ yb,
+                                                            float* __restrict__ yf, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int W, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = W >> 2;   // float4 count per row
+    const float* xr = x + (size_t)row * W;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            v[i] = *(const f32x4*)(xr + c * 4);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mu = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)W + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+            if (yf) *(f32x4*)(yf + (size_t)row * W + c * 4) = o;
+            if (yb) {
+                bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                *(bf16x4*)(yb + (size_t)row * W + c * 4) = ob;
+            }
+        }
+    }
+}
+
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32, float* mean,
+                  float* rstd, int rows, int W, float eps, hipStream_t st) {
+    if (rows <= 0) return SPN_ERR_ARG;
+    if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
+#define SPN_LN_FWD(V_)                                                                                          \
+    hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3((rows + 3) / 4), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, \
+                       mean, rstd, rows, W, eps)
+    if (W <= 256) SPN_LN_FWD(1);
+    else if (W <= 512) SPN_LN_FWD(2);
+    else if (W <= 1024) SPN_LN_FWD(4);
+    else SPN_LN_FWD(8);
+#undef SPN_LN_FWD
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// Backward.  xhat = (x-mean)*rstd, g = dy*gamma:
+//   dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat));  dgamma = sum_r dy*xhat;  dbeta = sum_r dy
+// Each wave walks rows wave_id, wave_id+nwaves, ... and keeps per-column dgamma/dbeta partials in
+// registers; partials go to ws[nwaves_total][2][W] and are folded by a second kernel.
+static constexpr int LNB_BLOCKS = 512;
+
+template <typename TDY, int LN_MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            int accumulate_dx, bf16_t* __restrict__ dxb,
+                                                            float* __restrict__ ws, int rows, int W) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int nv = W >> 2;
+    f32x4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        dg[i] = f32x4{0, 0, 0, 0};
+        db[i] = f32x4{0, 0, 0, 0};
+        const int c = lane + i * 64;
+        gm[i] = c < nv ? *(const f32x4*)(gamma + c * 4) : f32x4{0, 0, 0, 0};
+    }
+    for (int row = wave; row < rows; row += nwaves) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                const f32x4 xv = *(const f32x4*)(x + (size_t)row * W + c * 4);
+                f32x4 d;
+                if constexpr (sizeof(TDY) == 2) {
+                    const bf16x4 t = *(const bf16x4*)((const bf16_t*)dy + (size_t)row * W + c * 4);
+                    d = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+                } else {
+                    d = *(const f32x4*)((const float*)dy + (size_t)row * W + c * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[i][e] = (xv[e] - mu) * rs;
+                    g[i][e] = d[e] * gm[i][e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                    dg[i][e] += d[e] * xh[i][e];
+                    db[i][e] += d[e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)W;
+        s2 = wave_sum(s2) / (float)W;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
+                float* dp = dx + (size_t)row * W + c * 4;
+                if (accumulate_dx) o += *(const f32x4*)dp;
+                *(f32x4*)dp = o;
+                if (dxb) {
+                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *(bf16x4*)(dxb + (size_t)row * W + c * 4) = ob;
+                }
+            }
+        }
+    }
+    if (ws) {
+        float* w0 = ws + (size_t)wave * 2 * W;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                *(f32x4*)(w0 + c * 4) = dg[i];
+                *(f32x4*)(w0 + W + c * 4) = db[i];
+            }
+        }
+    }
+}
+
+__global__ void layernorm_bwd_fold_kernel(const float* __restrict__ ws, int nwaves, int W, float* __restrict__ dgamma,
+                                          float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * W) return;
+    float s = 0.f;
+    for (int k = 0; k < nwaves; ++k) s += ws[(size_t)k * 2 * W + c];
+    float* o = c < W ? dgamma + c : dbeta + (c - W);
+    *o = accumulate ? *o + s : s;
+}
+
+static int lnb_blocks(int rows) {
+    int b = (rows + 3) / 4;
+    return b > LNB_BLOCKS ? LNB_BLOCKS : b;
+}
+
+size_t layernorm_bwd_workspace_bytes(int rows, int W) { return (size_t)lnb_blocks(rows) * 4 * 2 * W * sizeof(float); }
+
+int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
+                  const float* rstd, float* dx, int accumulate_dx, bf16_t* dx_bf16, float* dgamma, float* dbeta,
+                  int accumulate_dparam, int rows, int W, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (rows <= 0 || (!dy_bf16 && !dy_f32) || !dx) return SPN_ERR_ARG;
+    if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
+    const bool want_param = dgamma && dbeta;
+    if (want_param && ws_bytes < layernorm_bwd_workspace_bytes(rows, W)) return SPN_ERR_WORKSPACE;
+    const int blocks = lnb_blocks(rows);
+    float* wsp = want_param ? ws : nullptr;
+#define SPN_LN_BWD(V_)                                                                                           \
+    do {                                                                                                         \
+        if (dy_bf16)                                                                                             \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_>), dim3(blocks), dim3(256), 0, st, dy_bf16, x, gamma, \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+        else                                                                                                     \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_>), dim3(blocks), dim3(256), 0, st, dy_f32, x, gamma,  \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+    } while (0)
+    if (W <= 256) SPN_LN_BWD(1);
+    else if (W <= 512) SPN_LN_BWD(2);
+    else if (W <= 1024) SPN_LN_BWD(4);
+    else SPN_LN_BWD(8);
+#undef SPN_LN_BWD
+    SPN_CHECK_LAUNCH();
+    if (want_param) {
+        hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3((2 * W + 255) / 256), dim3(256), 0, st, ws, blocks * 4, W, dgamma,
+                           dbeta, accumulate_dparam);
+        SPN_CHECK_LAUNCH();
+    }
+    return SPN_OK;
+}
+
+}  // namespace spn

@@ -1,0 +1,69 @@
+// Tower-level structs (internal C++; the C-ABI mirrors of TextCfg / TextLayout live in
+// include/spn4cir_hip.h and must stay layout-compatible).
+#pragma once
+#include "kernels.h"
+
+namespace spn {
+
+struct BlockCfg {
+    int B, L, W, H, causal, act;
+    float eps;
+};
+
+struct BlockParams {
+    const float *ln1_g, *ln1_b, *b_qkv, *b_o, *ln2_g, *ln2_b, *b_fc, *b_proj;
+    const bf16_t *w_qkv, *w_qkv_t, *w_o, *w_o_t, *w_fc, *w_fc_t, *w_proj, *w_proj_t;
+};
+
+struct BlockGrads {
+    float *ln1_g, *ln1_b, *w_qkv, *b_qkv, *w_o, *b_o, *ln2_g, *ln2_b, *w_fc, *b_fc, *w_proj, *b_proj;
+};
+
+struct BlockActs {
+    float* x_in;
+    float *mean1, *rstd1;
+    bf16_t* h1;
+    bf16_t* qkv;
+    float* lse;
+    bf16_t* attn;
+    float* x_mid;
+    float *mean2, *rstd2;
+    bf16_t* h2;
+    bf16_t* pre;
+    bf16_t* u;
+    float* x_out;
+};
+
+struct TextCfg {       // == spn_text_cfg
+    int B, L, L_ctx, W, H, layers, D, vocab;
+};
+
+struct TextLayout {    // == spn_text_layout_t (element offsets)
+    int64_t tok, pos, blocks, block_size, lnf_g, lnf_b, text_proj, n_params;
+    int64_t block_off[13];
+    int64_t bf16_block_size, bf16_text_proj, bf16_text_proj_t, n_bf16;
+};
+
+void block_param_offsets(int W, int64_t off[13]);
+int64_t block_bf16_size(int W);
+BlockParams block_params_at(const float* p, const bf16_t* wb, int W);
+BlockGrads block_grads_at(float* g, int W);
+int block_refresh_bf16(const float* p, bf16_t* wb, int W, hipStream_t st);
+size_t block_act_bytes(const BlockCfg& c);
+BlockActs block_acts_at(char* base, const BlockCfg& c);
+size_t block_bwd_scratch_bytes(const BlockCfg& c);
+size_t block_op_ws_bytes(const BlockCfg& c);
+int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st);
+int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st);
+
+void text_layout(const TextCfg& c, TextLayout* t);
+size_t text_act_bytes(const TextCfg& c);
+size_t text_ws_bytes(const TextCfg& c);
+int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStream_t st);
+int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
+             hipStream_t st);
+int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+             const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace spn

@@ -1,0 +1,407 @@
+// Transformer tower orchestration: the CLIP pre-LN residual block (clip/model.py:171-192)
+// forward + backward, and the text tower around it (CLIP.encode_text, clip/model.py:345-358).
+// Pure launch sequencing on one stream; every device op is a kernel from this library.
+#include "tower.h"
+
+namespace spn {
+
+#define SPN_TRY(x)                  \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != SPN_OK) return rc__; \
+    } while (0)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------ layouts
+void block_param_offsets(int W, int64_t off[13]) {
+    const int64_t w = W;
+    int64_t o = 0;
+    off[0] = o; o += w;            // ln1_g
+    off[1] = o; o += w;            // ln1_b
+    off[2] = o; o += 3 * w * w;    // w_qkv [3W, W]
+    off[3] = o; o += 3 * w;        // b_qkv
+    off[4] = o; o += w * w;        // w_o [W, W]
+    off[5] = o; o += w;            // b_o
+    off[6] = o; o += w;            // ln2_g
+    off[7] = o; o += w;            // ln2_b
+    off[8] = o; o += 4 * w * w;    // w_fc [4W, W]
+    off[9] = o; o += 4 * w;        // b_fc
+    off[10] = o; o += 4 * w * w;   // w_proj [W, 4W]
+    off[11] = o; o += w;           // b_proj
+    off[12] = o;                   // block size
+}
+
+int64_t block_bf16_size(int W) { return 24ll * W * W; }
+
+BlockParams block_params_at(const float* p, const bf16_t* wb, int W) {
+    int64_t o[13];
+    block_param_offsets(W, o);
+    const int64_t w2 = (int64_t)W * W;
+    BlockParams P;
+    P.ln1_g = p + o[0]; P.ln1_b = p + o[1]; P.b_qkv = p + o[3]; P.b_o = p + o[5];
+    P.ln2_g = p + o[6]; P.ln2_b = p + o[7]; P.b_fc = p + o[9]; P.b_proj = p + o[11];
+    P.w_qkv = wb;                 P.w_qkv_t = wb + 3 * w2;
+    P.w_o = wb + 6 * w2;          P.w_o_t = wb + 7 * w2;
+    P.w_fc = wb + 8 * w2;         P.w_fc_t = wb + 12 * w2;
+    P.w_proj = wb + 16 * w2;      P.w_proj_t = wb + 20 * w2;
+    return P;
+}
+
+BlockGrads block_grads_at(float* g, int W) {
+    int64_t o[13];
+    block_param_offsets(W, o);
+    BlockGrads G;
+    G.ln1_g = g + o[0]; G.ln1_b = g + o[1]; G.w_qkv = g + o[2]; G.b_qkv = g + o[3];
+    G.w_o = g + o[4]; G.b_o = g + o[5]; G.ln2_g = g + o[6]; G.ln2_b = g + o[7];
+    G.w_fc = g + o[8]; G.b_fc = g + o[9]; G.w_proj = g + o[10]; G.b_proj = g + o[11];
+    return G;
+}
+
+// bf16 copies of one block's GEMM weights (+ their transposes for the backward-data GEMMs)
+int block_refresh_bf16(const float* p, bf16_t* wb, int W, hipStream_t st) {
+    int64_t o[13];
+    block_param_offsets(W, o);
+    const int64_t w2 = (int64_t)W * W;
+    SPN_TRY(cast_transpose_f32_bf16(p + o[2], wb, wb + 3 * w2, 3 * W, W, st));
+    SPN_TRY(cast_transpose_f32_bf16(p + o[4], wb + 6 * w2, wb + 7 * w2, W, W, st));
+    SPN_TRY(cast_transpose_f32_bf16(p + o[8], wb + 8 * w2, wb + 12 * w2, 4 * W, W, st));
+    SPN_TRY(cast_transpose_f32_bf16(p + o[10], wb + 16 * w2, wb + 20 * w2, W, 4 * W, st));
+    return SPN_OK;
+}
+
+size_t block_act_bytes(const BlockCfg& c) {
+    const size_t T = (size_t)c.B * c.L, W = c.W;
+    size_t b = 0;
+    b += align256(T * W * 4);                 // x_in
+    b += 2 * align256(T * 4);                 // mean1, rstd1
+    b += align256(T * W * 2);                 // h1
+    b += align256(T * 3 * W * 2);             // qkv
+    b += align256((size_t)c.B * c.H * c.L * 4);   // lse
+    b += align256(T * W * 2);                 // attn
+    b += align256(T * W * 4);                 // x_mid
+    b += 2 * align256(T * 4);                 // mean2, rstd2
+    b += align256(T * W * 2);                 // h2
+    b += 2 * align256(T * 4 * W * 2);         // pre, u
+    return b;
+}
+
+BlockActs block_acts_at(char* base, const BlockCfg& c) {
+    const size_t T = (size_t)c.B * c.L, W = c.W;
+    BlockActs A;
+    char* p = base;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    A.x_in = (float*)take(T * W * 4);
+    A.mean1 = (float*)take(T * 4);
+    A.rstd1 = (float*)take(T * 4);
+    A.h1 = (bf16_t*)take(T * W * 2);
+    A.qkv = (bf16_t*)take(T * 3 * W * 2);
+    A.lse = (float*)take((size_t)c.B * c.H * c.L * 4);
+    A.attn = (bf16_t*)take(T * W * 2);
+    A.x_mid = (float*)take(T * W * 4);
+    A.mean2 = (float*)take(T * 4);
+    A.rstd2 = (float*)take(T * 4);
+    A.h2 = (bf16_t*)take(T * W * 2);
+    A.pre = (bf16_t*)take(T * 4 * W * 2);
+    A.u = (bf16_t*)take(T * 4 * W * 2);
+    A.x_out = nullptr;
+    return A;
+}
+
+// scratch for one block's backward + the op workspaces (shared, used sequentially)
+size_t block_bwd_scratch_bytes(const BlockCfg& c) {
+    const size_t T = (size_t)c.B * c.L, W = c.W;
+    size_t b = 0;
+    b += align256(T * 4 * W * 2);   // dpre
+    b += align256(T * W * 2);       // dh
+    b += align256(T * W * 2);       // dattn
+    b += align256(T * 3 * W * 2);   // dqkv
+    b += align256((size_t)c.B * c.H * c.L * 4);   // delta
+    return b;
+}
+
+size_t block_op_ws_bytes(const BlockCfg& c) {
+    const int T = c.B * c.L, W = c.W;
+    size_t m = 0;
+    auto mx = [&](size_t v) { if (v > m) m = v; };
+    mx(gemm_tn_workspace_bytes(T, W, 4 * W));
+    mx(gemm_tn_workspace_bytes(T, 4 * W, W));
+    mx(gemm_tn_workspace_bytes(T, W, W));
+    mx(gemm_tn_workspace_bytes(T, 3 * W, W));
+    mx(colsum_workspace_bytes(T, 4 * W));
+    mx(layernorm_bwd_workspace_bytes(T, W));
+    return align256(m);
+}
+
+// -------------------------------------------------------------------------------- block
+int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st) {
+    const int T = c.B * c.L, W = c.W;
+    SPN_TRY(layernorm_fwd(A.x_in, P.ln1_g, P.ln1_b, A.h1, nullptr, A.mean1, A.rstd1, T, W, c.eps, st));
+    {
+        GemmEpilogue e;
+        e.bias = P.b_qkv; e.out_bf16 = A.qkv; e.ldc = 3 * W;
+        SPN_TRY(gemm_nt(A.h1, P.w_qkv, T, 3 * W, W, W, W, GEMM_STORE, e, st));
+    }
+    {
+        AttnArgs a;
+        a.q = A.qkv; a.k = A.qkv + W; a.v = A.qkv + 2 * W;
+        a.ldq = a.ldk = a.ldv = 3 * W;
+        a.o = A.attn; a.ldo = W; a.lse = A.lse; a.key_bias = nullptr;
+        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal;
+        a.scale = 0.125f;
+        SPN_TRY(attention_fwd(a, st));
+    }
+    {
+        GemmEpilogue e;
+        e.bias = P.b_o; e.resid = A.x_in; e.ldr = W; e.out_f32 = A.x_mid; e.ldc = W;
+        SPN_TRY(gemm_nt(A.attn, P.w_o, T, W, W, W, W, GEMM_RESID, e, st));
+    }
+    SPN_TRY(layernorm_fwd(A.x_mid, P.ln2_g, P.ln2_b, A.h2, nullptr, A.mean2, A.rstd2, T, W, c.eps, st));
+    {
+        GemmEpilogue e;
+        e.bias = P.b_fc; e.act = c.act; e.aux_out = A.pre; e.out_bf16 = A.u; e.ldc = 4 * W;
+        SPN_TRY(gemm_nt(A.h2, P.w_fc, T, 4 * W, W, W, W, GEMM_STORE, e, st));
+    }
+    {
+        GemmEpilogue e;
+        e.bias = P.b_proj; e.resid = A.x_mid; e.ldr = W; e.out_f32 = A.x_out; e.ldc = W;
+        SPN_TRY(gemm_nt(A.u, P.w_proj, T, W, 4 * W, 4 * W, 4 * W, GEMM_RESID, e, st));
+    }
+    return SPN_OK;
+}
+
+// dx / dx_bf16: gradient w.r.t. the block output on entry, w.r.t. the block input on exit.
+int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st) {
+    const int T = c.B * c.L, W = c.W;
+    const size_t Ts = (size_t)T;
+    char* p = scratch;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    bf16_t* dpre = (bf16_t*)take(Ts * 4 * W * 2);
+    bf16_t* dh = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dattn = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
+    float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
+
+    // MLP
+    SPN_TRY(colsum_bf16(dx_bf16, T, W, W, G.b_proj, 0, ws, ws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.aux_in = A.pre; e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
+        SPN_TRY(gemm_nt(dx_bf16, P.w_proj_t, T, 4 * W, W, W, W, GEMM_DACT, e, st));
+    }
+    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(colsum_bf16(dpre, T, 4 * W, 4 * W, G.b_fc, 0, ws, ws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_bf16 = dh; e.ldc = W;
+        SPN_TRY(gemm_nt(dpre, P.w_fc_t, T, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
+    }
+    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dx_bf16, G.ln2_g, G.ln2_b, 0, T, W, ws,
+                          ws_bytes, st));
+    // attention
+    SPN_TRY(colsum_bf16(dx_bf16, T, W, W, G.b_o, 0, ws, ws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_bf16 = dattn; e.ldc = W;
+        SPN_TRY(gemm_nt(dx_bf16, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
+    }
+    SPN_TRY(gemm_tn(dx_bf16, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, ws, ws_bytes, st));
+    {
+        AttnBwdArgs g;
+        AttnArgs& a = g.f;
+        a.q = A.qkv; a.k = A.qkv + W; a.v = A.qkv + 2 * W;
+        a.ldq = a.ldk = a.ldv = 3 * W;
+        a.o = A.attn; a.ldo = W; a.lse = A.lse; a.key_bias = nullptr;
+        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal;
+        a.scale = 0.125f;
+        g.d_o = dattn; g.lddo = W;
+        g.dq = dqkv; g.dk = dqkv + W; g.dv = dqkv + 2 * W;
+        g.lddq = g.lddk = g.lddv = 3 * W;
+        g.delta = delta;
+        SPN_TRY(attention_bwd(g, st));
+    }
+    SPN_TRY(colsum_bf16(dqkv, T, 3 * W, 3 * W, G.b_qkv, 0, ws, ws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_bf16 = dh; e.ldc = W;
+        SPN_TRY(gemm_nt(dqkv, P.w_qkv_t, T, W, 3 * W, 3 * W, 3 * W, GEMM_STORE, e, st));
+    }
+    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, dx_bf16, G.ln1_g, G.ln1_b, 0, T, W, ws,
+                          ws_bytes, st));
+    return SPN_OK;
+}
+
+// --------------------------------------------------------------------------- text tower
+static BlockCfg text_block_cfg(const TextCfg& c) {
+    BlockCfg b;
+    b.B = c.B; b.L = c.L; b.W = c.W; b.H = c.H; b.causal = 1; b.act = ACT_QUICKGELU; b.eps = 1e-5f;
+    return b;
+}
+
+void text_layout(const TextCfg& c, TextLayout* t) {
+    int64_t bo[13];
+    block_param_offsets(c.W, bo);
+    int64_t o = 0;
+    t->tok = o; o += (int64_t)c.vocab * c.W;
+    t->pos = o; o += (int64_t)c.L_ctx * c.W;
+    t->blocks = o; t->block_size = bo[12]; o += bo[12] * c.layers;
+    t->lnf_g = o; o += c.W;
+    t->lnf_b = o; o += c.W;
+    t->text_proj = o; o += (int64_t)c.W * c.D;
+    t->n_params = o;
+    for (int i = 0; i < 13; ++i) t->block_off[i] = bo[i];
+    t->bf16_block_size = block_bf16_size(c.W);
+    t->bf16_text_proj = t->bf16_block_size * c.layers;
+    t->bf16_text_proj_t = t->bf16_text_proj + (int64_t)c.W * c.D;
+    t->n_bf16 = t->bf16_text_proj_t + (int64_t)c.W * c.D;
+}
+
+// activation arena: [eot][per-layer block acts][x_final][e][mean_f][rstd_f][ln_e]
+struct TextActs {
+    int32_t* eot;
+    char* blocks;
+    size_t block_bytes;
+    float* x_final;
+    float* e;
+    float *mean_f, *rstd_f;
+    bf16_t* ln_e;
+};
+
+size_t text_act_bytes(const TextCfg& c) {
+    const BlockCfg bc = text_block_cfg(c);
+    const size_t T = (size_t)c.B * c.L;
+    size_t b = align256((size_t)c.B * 4);
+    b += block_act_bytes(bc) * c.layers;
+    b += align256(T * c.W * 4);
+    b += align256((size_t)c.B * c.W * 4);
+    b += 2 * align256((size_t)c.B * 4);
+    b += align256((size_t)c.B * c.W * 2);
+    return b;
+}
+
+static TextActs text_acts_at(char* base, const TextCfg& c) {
+    const BlockCfg bc = text_block_cfg(c);
+    const size_t T = (size_t)c.B * c.L;
+    TextActs A;
+    char* p = base;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    A.eot = (int32_t*)take((size_t)c.B * 4);
+    A.block_bytes = block_act_bytes(bc);
+    A.blocks = p; p += A.block_bytes * c.layers;
+    A.x_final = (float*)take(T * c.W * 4);
+    A.e = (float*)take((size_t)c.B * c.W * 4);
+    A.mean_f = (float*)take((size_t)c.B * 4);
+    A.rstd_f = (float*)take((size_t)c.B * 4);
+    A.ln_e = (bf16_t*)take((size_t)c.B * c.W * 2);
+    return A;
+}
+
+size_t text_ws_bytes(const TextCfg& c) {
+    const BlockCfg bc = text_block_cfg(c);
+    const size_t T = (size_t)c.B * c.L;
+    size_t b = block_bwd_scratch_bytes(bc);
+    b += align256(T * c.W * 4);              // dx
+    b += align256(T * c.W * 2);              // dx_bf16
+    b += align256((size_t)c.B * c.D * 2);    // dfeats bf16
+    b += align256((size_t)c.B * c.W * 4);    // dln_e
+    b += align256((size_t)c.B * c.W * 4);    // de
+    size_t op = block_op_ws_bytes(bc);
+    const size_t tp = align256(gemm_tn_workspace_bytes(c.B, c.W, c.D));
+    if (tp > op) op = tp;
+    const size_t lb = align256(layernorm_bwd_workspace_bytes(c.B, c.W));
+    if (lb > op) op = lb;
+    return b + op;
+}
+
+static int text_check(const TextCfg& c) {
+    if (c.B <= 0 || c.L <= 0 || c.L > c.L_ctx || c.layers <= 0 || c.vocab <= 0) return SPN_ERR_ARG;
+    if (c.W % 64 || c.H * 64 != c.W || c.D % 64) return SPN_ERR_SHAPE;
+    return SPN_OK;
+}
+
+int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStream_t st) {
+    SPN_TRY(text_check(c));
+    TextLayout t;
+    text_layout(c, &t);
+    for (int l = 0; l < c.layers; ++l)
+        SPN_TRY(block_refresh_bf16(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W, st));
+    SPN_TRY(cast_transpose_f32_bf16(params + t.text_proj, wb + t.bf16_text_proj, wb + t.bf16_text_proj_t, c.W, c.D, st));
+    return SPN_OK;
+}
+
+int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
+             hipStream_t st) {
+    SPN_TRY(text_check(c));
+    TextLayout t;
+    text_layout(c, &t);
+    const BlockCfg bc = text_block_cfg(c);
+    TextActs A = text_acts_at(acts, c);
+    SPN_TRY(eot_argmax(ids, A.eot, c.B, c.L, st));
+    BlockActs first = block_acts_at(A.blocks, bc);
+    SPN_TRY(embed_fwd(ids, params + t.tok, params + t.pos, first.x_in, c.B, c.L, c.W, c.vocab, st));
+    for (int l = 0; l < c.layers; ++l) {
+        BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
+        a.x_out = (l + 1 < c.layers) ? block_acts_at(A.blocks + A.block_bytes * (l + 1), bc).x_in : A.x_final;
+        const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
+        SPN_TRY(block_fwd(bc, P, a, st));
+    }
+    // ln_final is per-row, so pooling the EOT row first is identical to clip/model.py:352-356
+    SPN_TRY(gather_rows_f32(A.x_final, A.eot, A.e, c.B, c.L, c.W, st));
+    SPN_TRY(layernorm_fwd(A.e, params + t.lnf_g, params + t.lnf_b, A.ln_e, nullptr, A.mean_f, A.rstd_f, c.B, c.W, 1e-5f,
+                          st));
+    GemmEpilogue e;
+    e.out_f32 = feats; e.ldc = c.D;
+    SPN_TRY(gemm_nt(A.ln_e, wb + t.bf16_text_proj_t, c.B, c.D, c.W, c.W, c.W, GEMM_STORE, e, st));
+    return SPN_OK;
+}
+
+int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+             const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
+    SPN_TRY(text_check(c));
+    if (ws_bytes < text_ws_bytes(c)) return SPN_ERR_WORKSPACE;
+    TextLayout t;
+    text_layout(c, &t);
+    const BlockCfg bc = text_block_cfg(c);
+    TextActs A = text_acts_at(acts, c);
+    const size_t T = (size_t)c.B * c.L;
+    char* p = ws;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    char* scratch = p; p += block_bwd_scratch_bytes(bc);
+    float* dx = (float*)take(T * c.W * 4);
+    bf16_t* dxb = (bf16_t*)take(T * c.W * 2);
+    bf16_t* dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
+    float* dln = (float*)take((size_t)c.B * c.W * 4);
+    float* de = (float*)take((size_t)c.B * c.W * 4);
+    float* opws = (float*)p;
+    const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
+
+    SPN_TRY(cast_f32_bf16(dfeats, dfb, (size_t)c.B * c.D, st));
+    SPN_TRY(gemm_tn(A.ln_e, dfb, c.B, c.W, c.D, c.W, c.D, grads + t.text_proj, c.D, 1.0f, 0, opws, opws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_f32 = dln; e.ldc = c.W;
+        SPN_TRY(gemm_nt(dfb, wb + t.bf16_text_proj, c.B, c.W, c.D, c.D, c.D, GEMM_STORE, e, st));
+    }
+    SPN_TRY(layernorm_bwd(nullptr, dln, A.e, params + t.lnf_g, A.mean_f, A.rstd_f, de, 0, nullptr, grads + t.lnf_g,
+                          grads + t.lnf_b, 0, c.B, c.W, opws, opws_bytes, st));
+    SPN_TRY(scatter_rows_f32(de, A.eot, dx, dxb, c.B, c.L, c.W, st));
+    for (int l = c.layers - 1; l >= 0; --l) {
+        BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
+        const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
+        const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+        SPN_TRY(block_bwd(bc, P, a, G, dx, dxb, scratch, opws, opws_bytes, st));
+    }
+    hipError_t he = hipMemsetAsync(grads + t.tok, 0, (size_t)c.vocab * c.W * sizeof(float), st);
+    if (he != hipSuccess) return (int)he;
+    SPN_TRY(embed_bwd(ids, A.eot, dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
+    if (c.L < c.L_ctx) {
+        he = hipMemsetAsync(grads + t.pos + (size_t)c.L * c.W, 0, (size_t)(c.L_ctx - c.L) * c.W * sizeof(float), st);
+        if (he != hipSuccess) return (int)he;
+    }
+    return SPN_OK;
+}
+
+}  // namespace spn

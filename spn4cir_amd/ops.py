@@ -1,0 +1,267 @@
+"""torch-tensor wrappers over the C-ABI (include/spn4cir_hip.h).
+
+PyTorch is used only for device memory and streams: every function takes CUDA(=HIP) tensors,
+passes raw device pointers plus torch's current stream to libspn4cir_hip.so and returns
+tensors.  There is no CPU fallback: CPU tensors are rejected.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF = 0, 1, 2
+BANK_DIMS = (128, 256, 512, 640, 768, 1024)
+
+_ws_cache = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("spn4cir_amd ops need device tensors (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def workspace(nbytes, device, slot="default"):
+    """Grow-only scratch buffer per (device, slot); ops on one stream use it sequentially."""
+    key = (str(device), slot)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _req(t, dtype, name):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+# ------------------------------------------------------------------------------- GEMMs
+def gemm_nt(a, b, bias=None, act=ACT_NONE, out_dtype=torch.bfloat16, want_pre=False):
+    """a [M,K] bf16, b [N,K] bf16 -> act(a @ b.T + bias) ; optionally also the pre-activation."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if want_pre else None
+    ob, of = (out, None) if out_dtype == torch.bfloat16 else (None, out)
+    check(lib().spn_gemm_nt(_p(a), _p(b), M, N, K, K, K, _p(bias), act, _p(ob), _p(of), _p(pre), N, _stream()), "gemm_nt")
+    return (out, pre) if want_pre else out
+
+
+def gemm_nt_resid(a, b, bias, resid):
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(resid, torch.float32, "resid")
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    check(lib().spn_gemm_nt_resid(_p(a), _p(b), M, N, K, K, K, _p(bias), _p(resid), N, _p(out), None, N, _stream()),
+          "gemm_nt_resid")
+    return out
+
+
+def gemm_nt_dact(a, b, pre, act):
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b"); _req(pre, torch.bfloat16, "pre")
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    check(lib().spn_gemm_nt_dact(_p(a), _p(b), M, N, K, K, K, _p(pre), act, _p(out), N, _stream()), "gemm_nt_dact")
+    return out
+
+
+def gemm_tn(a, b, alpha=1.0, out=None, accumulate=False):
+    """a [Kr,N1] bf16, b [Kr,N2] bf16 -> a.T @ b  (fp32 [N1,N2])."""
+    _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+    Kr, N1 = a.shape
+    N2 = b.shape[1]
+    if out is None:
+        out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
+    nb = lib().spn_gemm_tn_workspace_bytes(Kr, N1, N2)
+    nb = max(nb, N1 * N2 * 4)   # the accumulate / alpha path always goes through the workspace
+    ws = workspace(nb, a.device)
+    check(lib().spn_gemm_tn(_p(a), _p(b), Kr, N1, N2, N1, N2, _p(out), N2, float(alpha), int(accumulate), _p(ws),
+                            ws.numel(), _stream()), "gemm_tn")
+    return out
+
+
+# ------------------------------------------------------------------------- elementwise
+def cast_bf16(x):
+    _req(x, torch.float32, "x")
+    y = torch.empty_like(x, dtype=torch.bfloat16)
+    check(lib().spn_cast_f32_bf16(_p(x), _p(y), x.numel(), _stream()), "cast")
+    return y
+
+
+def cast_transpose_bf16(x):
+    _req(x, torch.float32, "x")
+    r, c = x.shape
+    y = torch.empty(r, c, dtype=torch.bfloat16, device=x.device)
+    yt = torch.empty(c, r, dtype=torch.bfloat16, device=x.device)
+    check(lib().spn_cast_transpose_f32_bf16(_p(x), _p(y), _p(yt), r, c, _stream()), "cast_transpose")
+    return y, yt
+
+
+def colsum(x):
+    _req(x, torch.bfloat16, "x")
+    r, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().spn_colsum_workspace_bytes(r, c), x.device)
+    check(lib().spn_colsum_bf16(_p(x), r, c, c, _p(out), 0, _p(ws), ws.numel(), _stream()), "colsum")
+    return out
+
+
+# --------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_dtype=torch.bfloat16):
+    _req(x, torch.float32, "x")
+    rows, W = x.shape
+    y = torch.empty(rows, W, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    yb, yf = (y, None) if out_dtype == torch.bfloat16 else (None, y)
+    check(lib().spn_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(yb), _p(yf), _p(mean), _p(rstd), rows, W, eps,
+                                  _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_accum=None):
+    """Returns (dx fp32, dx bf16, dgamma, dbeta); dx_accum (fp32) is added into if given."""
+    rows, W = x.shape
+    dx = dx_accum if dx_accum is not None else torch.empty(rows, W, dtype=torch.float32, device=x.device)
+    dxb = torch.empty(rows, W, dtype=torch.bfloat16, device=x.device)
+    dg = torch.empty(W, dtype=torch.float32, device=x.device)
+    db = torch.empty(W, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().spn_layernorm_bwd_workspace_bytes(rows, W), x.device)
+    dyb, dyf = (dy, None) if dy.dtype == torch.bfloat16 else (None, dy)
+    check(lib().spn_layernorm_bwd(_p(dyb), _p(dyf), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx),
+                                  int(dx_accum is not None), _p(dxb), _p(dg), _p(db), 0, rows, W, _p(ws), ws.numel(),
+                                  _stream()), "layernorm_bwd")
+    return dx, dxb, dg, db
+
+
+# --------------------------------------------------------------------------- attention
+def attention_fwd(q, k, v, B, H, Lq, Lk, causal=False, key_bias=None, scale=0.125):
+    """q [B*Lq, H*64], k/v [B*Lk, H*64] bf16 (may be column views of a packed qkv) -> (o, lse)."""
+    o = torch.empty(B * Lq, H * 64, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    check(lib().spn_attention_fwd(_p(q), _p(k), _p(v), q.stride(0), k.stride(0), v.stride(0), _p(o), H * 64, _p(lse),
+                                  _p(key_bias), B, H, Lq, Lk, int(causal), scale, _stream()), "attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, lse, d_o, B, H, Lq, Lk, causal=False, key_bias=None, scale=0.125):
+    dq = torch.empty(B * Lq, H * 64, dtype=torch.bfloat16, device=q.device)
+    dk = torch.empty(B * Lk, H * 64, dtype=torch.bfloat16, device=q.device)
+    dv = torch.empty(B * Lk, H * 64, dtype=torch.bfloat16, device=q.device)
+    delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    check(lib().spn_attention_bwd(_p(q), _p(k), _p(v), q.stride(0), k.stride(0), v.stride(0), _p(o), o.stride(0),
+                                  _p(lse), _p(key_bias), _p(d_o), d_o.stride(0), _p(dq), _p(dk), _p(dv), H * 64, H * 64,
+                                  H * 64, _p(delta), B, H, Lq, Lk, int(causal), scale, _stream()), "attention_bwd")
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------- combiner + bank loss
+def bank_dim(D):
+    """Smallest supported bank width >= D (queries/banks are zero-padded to it)."""
+    for d in BANK_DIMS:
+        if d >= D:
+            return d
+    raise ValueError(f"embedding dim {D} > {BANK_DIMS[-1]} not supported by the bank kernels")
+
+
+def prepare_bank(bank_f32):
+    """fp32 [M, D] (L2-normalised rows) -> device bf16 [M, bank_dim(D)], zero padded."""
+    M, D = bank_f32.shape
+    Dp = bank_dim(D)
+    out = torch.zeros(M, Dp, dtype=torch.bfloat16, device=bank_f32.device)
+    out[:, :D] = bank_f32.to(torch.bfloat16)
+    return out
+
+
+def combine_l2norm_fwd(refer_bank, ref_idx, text, ldq=None):
+    """-> (q fp32 [B,D], q bf16 [B,ldq], inv_norm [B])"""
+    _req(text, torch.float32, "text")
+    B, D = text.shape
+    ldq = ldq or bank_dim(D)
+    q = torch.empty(B, D, dtype=torch.float32, device=text.device)
+    qb = torch.empty(B, ldq, dtype=torch.bfloat16, device=text.device)
+    inv = torch.empty(B, dtype=torch.float32, device=text.device)
+    check(lib().spn_combine_l2norm_fwd(_p(refer_bank), _p(ref_idx), _p(text), _p(q), _p(qb), _p(inv), B, D, ldq,
+                                       _stream()), "combine_l2norm_fwd")
+    return q, qb, inv
+
+
+def combine_l2norm_bwd(q, inv_norm, dq):
+    B, D = q.shape
+    dtext = torch.empty(B, D, dtype=torch.float32, device=q.device)
+    check(lib().spn_combine_l2norm_bwd(_p(q), _p(inv_norm), _p(dq), _p(dtext), B, D, _stream()), "combine_l2norm_bwd")
+    return dtext
+
+
+def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0):
+    B, Dp = q_bf16.shape
+    M = bank_bf16.shape[0]
+    stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
+    ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
+    check(lib().spn_bank_stats_fwd(_p(q_bf16), Dp, _p(bank_bf16), _p(labels), B, M, Dp, m_begin, inv_tau, _p(stats),
+                                   _p(ws), ws.numel(), _stream()), "bank_stats_fwd")
+    return stats
+
+
+def bank_loss_finalize(stats, M_total, label_smoothing=0.0):
+    """stats [nshards, B, 4] or [B, 4] -> (row_lse [B], row_loss [B], loss_mean [1])"""
+    if stats.dim() == 2:
+        stats = stats.unsqueeze(0)
+    stats = stats.contiguous()
+    n, B, _ = stats.shape
+    lse = torch.empty(B, dtype=torch.float32, device=stats.device)
+    row = torch.empty(B, dtype=torch.float32, device=stats.device)
+    mean = torch.empty(1, dtype=torch.float32, device=stats.device)
+    check(lib().spn_bank_loss_finalize(_p(stats), n, B, M_total, label_smoothing, _p(lse), _p(row), _p(mean), _stream()),
+          "bank_loss_finalize")
+    return lse, row, mean
+
+
+def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total=None, label_smoothing=0.0, m_begin=0):
+    B, Dp = q_bf16.shape
+    M = bank_bf16.shape[0]
+    dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
+    ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
+    check(lib().spn_bank_grad_q(_p(q_bf16), Dp, _p(bank_bf16), _p(labels), B, M, Dp, m_begin, inv_tau, _p(row_lse),
+                                label_smoothing, M_total or M, grad_scale, _p(dq), _p(ws), ws.numel(), _stream()),
+          "bank_grad_q")
+    return dq
+
+
+# -------------------------------------------------------------------------------- AdamW
+def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, inv_scale=1.0, found_inf=None):
+    check(lib().spn_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
+                               inv_scale, _p(found_inf), _stream()), "adamw_step")
+
+
+def grad_check_finite(g, found_inf):
+    check(lib().spn_grad_check_finite(_p(g), g.numel(), _p(found_inf), _stream()), "grad_check_finite")
+
+
+# ----------------------------------------------------------------------------- Recall@K
+def cosine_scores_f64(q, gallery):
+    _req(q, torch.float32, "q"); _req(gallery, torch.float32, "gallery")
+    Nq, D = q.shape
+    Ng = gallery.shape[0]
+    out = torch.empty(Nq, Ng, dtype=torch.float64, device=q.device)
+    check(lib().spn_cosine_scores_f64(_p(q), _p(gallery), Nq, Ng, D, _p(out), _stream()), "cosine_scores_f64")
+    return out
+
+
+def topk_from_scores(scores, K, exclude=None):
+    Nq, Ng = scores.shape
+    idx = torch.empty(Nq, K, dtype=torch.int32, device=scores.device)
+    val = torch.empty(Nq, K, dtype=torch.float64, device=scores.device)
+    check(lib().spn_topk_from_scores(_p(scores), Nq, Ng, K, _p(exclude), _p(idx), _p(val), _stream()), "topk")
+    return idx, val

@@ -1,0 +1,137 @@
+"""Host side of the CLIP text tower (CLIP.encode_text, clip4cir/clip/model.py:345-358).
+
+All parameters live in ONE flat fp32 device buffer (layout: spn_text_layout in
+include/spn4cir_hip.h) so that the optimizer is a single fused launch and the DDP gradient
+all-reduce runs over contiguous buckets; `named_views()` exposes it under the reference's
+state-dict keys.  bf16 mirrors (+ transposes) of the GEMM weights are refreshed after every
+optimizer step.  Forward/backward are single C-ABI calls that enqueue the whole launch chain.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .ops import _p, _stream
+
+_BLOCK_KEYS = ["ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+               "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+               "mlp.c_proj.weight", "mlp.c_proj.bias"]
+
+
+def text_cfg_from_state_dict(sd, prefix=""):
+    """Shape inference as build_model does it (clip4cir/clip/model.py:420-426)."""
+    width = sd[prefix + "ln_final.weight"].shape[0]
+    layers = len({k[len(prefix):].split(".")[2] for k in sd if k.startswith(prefix + "transformer.resblocks.")})
+    return dict(width=width, layers=layers, heads=width // 64, embed_dim=sd[prefix + "text_projection"].shape[1],
+                vocab=sd[prefix + "token_embedding.weight"].shape[0], ctx=sd[prefix + "positional_embedding"].shape[0])
+
+
+class TextTower:
+    def __init__(self, width, layers, heads, embed_dim, vocab=49408, ctx=77, device="cuda"):
+        if heads * 64 != width:
+            raise ValueError("CLIP text towers use head_dim 64 (heads = width // 64, clip/model.py:425)")
+        self.width, self.layers, self.heads = width, layers, heads
+        self.embed_dim, self.vocab, self.ctx = embed_dim, vocab, ctx
+        self.device = torch.device(device)
+        self._lay = _lib.TextLayout()
+        check(lib().spn_text_layout(C.byref(self._cfg(1, ctx)), C.byref(self._lay)), "text_layout")
+        self.n_params = int(self._lay.n_params)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.wbf16 = torch.zeros(int(self._lay.n_bf16), dtype=torch.bfloat16, device=self.device)
+        self._acts = None
+        self._acts_key = None
+        self._ws = None
+        self._last = None
+        self._stale = True
+
+    # ------------------------------------------------------------------ layout
+    def _cfg(self, B, L):
+        return _lib.TextCfg(B, L, self.ctx, self.width, self.heads, self.layers, self.embed_dim, self.vocab)
+
+    def spans(self):
+        """[(clip state-dict key, offset, shape)] in flat-buffer order."""
+        lay, W, D = self._lay, self.width, self.embed_dim
+        out = [("token_embedding.weight", lay.tok, (self.vocab, W)), ("positional_embedding", lay.pos, (self.ctx, W))]
+        shapes = [(W,), (W,), (3 * W, W), (3 * W,), (W, W), (W,), (W,), (W,), (4 * W, W), (4 * W,), (W, 4 * W), (W,)]
+        for l in range(self.layers):
+            base = lay.blocks + lay.block_size * l
+            for j, key in enumerate(_BLOCK_KEYS):
+                out.append((f"transformer.resblocks.{l}.{key}", base + lay.block_off[j], shapes[j]))
+        out += [("ln_final.weight", lay.lnf_g, (W,)), ("ln_final.bias", lay.lnf_b, (W,)),
+                ("text_projection", lay.text_proj, (W, D))]
+        return [(k, int(o), s) for k, o, s in out]
+
+    def named_views(self, flat=None):
+        flat = self.params if flat is None else flat
+        views = {}
+        for key, off, shape in self.spans():
+            n = 1
+            for s in shape:
+                n *= s
+            views[key] = flat[off:off + n].view(shape)
+        return views
+
+    def layer_spans(self):
+        """Flat (start, end) ranges in backward-completion order (last layer first): DDP buckets."""
+        lay = self._lay
+        tail = (int(lay.lnf_g), self.n_params)
+        blocks = [(int(lay.blocks + lay.block_size * l), int(lay.blocks + lay.block_size * (l + 1)))
+                  for l in reversed(range(self.layers))]
+        head = (0, int(lay.blocks))
+        return [tail] + blocks + [head]
+
+    def load_clip_state_dict(self, sd, prefix=""):
+        views = self.named_views()
+        with torch.no_grad():
+            for key, v in views.items():
+                v.copy_(sd[prefix + key].to(device=self.device, dtype=torch.float32))
+        self._stale = True
+
+    def refresh(self):
+        """Rewrite the bf16 GEMM operands from the fp32 master weights."""
+        check(lib().spn_text_refresh_bf16(C.byref(self._cfg(1, self.ctx)), _p(self.params), _p(self.wbf16), _stream()),
+              "text_refresh_bf16")
+        self._stale = False
+
+    def mark_stale(self):
+        self._stale = True
+
+    # ------------------------------------------------------------------ compute
+    def _buffers(self, B, L, need_ws):
+        cfg = self._cfg(B, L)
+        if self._acts_key != (B, L):
+            self._acts = None
+            self._acts = torch.empty(lib().spn_text_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self._acts_key = (B, L)
+            self._ws = None
+        if need_ws and self._ws is None:
+            self._ws = torch.empty(lib().spn_text_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+        return cfg
+
+    def forward(self, ids):
+        """ids int32 [B, L] on device -> fp32 [B, D]; activations are kept for backward()."""
+        if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
+            raise ValueError("ids must be a contiguous int32 device tensor")
+        B, L = ids.shape
+        if self._stale:
+            self.refresh()
+        cfg = self._buffers(B, L, False)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        check(lib().spn_text_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(feats),
+                                 _stream()), "text_fwd")
+        self._last = ids
+        return feats
+
+    def backward(self, dfeats):
+        """d(loss)/d(feats) fp32 [B, D] -> fills self.grads (overwrites) and returns it."""
+        ids = self._last
+        if ids is None:
+            raise RuntimeError("backward() without a preceding forward()")
+        B, L = ids.shape
+        cfg = self._buffers(B, L, True)
+        dfeats = dfeats.contiguous()
+        check(lib().spn_text_bwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(dfeats),
+                                 _p(self.grads), _p(self._ws), self._ws.numel(), _stream()), "text_bwd")
+        return self.grads

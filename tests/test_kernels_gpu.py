@@ -1,0 +1,336 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the CPU oracle.
+
+Tolerances (stated per test): GEMM-type kernels take bf16 inputs and accumulate in fp32, so
+they are compared with an fp64 reference evaluated on the SAME bf16-rounded inputs; bf16
+outputs add one rounding (2^-9 relative)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (308, 192, 128), (462, 64, 256), (1000, 2304, 768), (77, 512, 3072)])
+def test_gemm_nt_plain_and_bias(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g))
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ b.double().t() + bias.double()
+    out32 = ops.gemm_nt(dev(a), dev(b), dev(bias), out_dtype=torch.float32)
+    assert rel_err(out32, ref) < 2e-5          # fp32 accumulation of exact bf16 products
+    out16 = ops.gemm_nt(dev(a), dev(b), dev(bias))
+    assert rel_err(out16, ref) < 6e-3          # + one bf16 rounding of the output
+
+
+def test_gemm_nt_is_not_transposed(ops):
+    # A = I-like / asymmetric B catches a swapped C layout (cdna guide rule 16)
+    M = N = 128
+    K = 128
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    b = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 / 16.0
+    ref = a.double() @ bf(b).double().t()
+    out = ops.gemm_nt(dev(bf(a)), dev(bf(b)), out_dtype=torch.float32)
+    assert torch.equal(out.cpu().double(), ref)
+
+
+def test_gemm_nt_epilogues(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 256, 128
+    a, b = bf(torch.randn(M, K, generator=g) * 0.5), bf(torch.randn(N, K, generator=g) * 0.2)
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = torch.randn(M, N, generator=g)
+    lin = a.double() @ b.double().t() + bias.double()
+    # quick-gelu with the pre-activation copy
+    u, pre = ops.gemm_nt(dev(a), dev(b), dev(bias), act=ops.ACT_QUICKGELU, want_pre=True)
+    assert rel_err(pre, lin) < 6e-3
+    assert rel_err(u, quick_gelu(lin)) < 8e-3
+    # exact gelu
+    u2 = ops.gemm_nt(dev(a), dev(b), dev(bias), act=ops.ACT_GELU_ERF, out_dtype=torch.float32)
+    assert rel_err(u2, torch.nn.functional.gelu(lin)) < 1e-4
+    # residual
+    r = ops.gemm_nt_resid(dev(a), dev(b), dev(bias), dev(resid))
+    assert rel_err(r, lin + resid.double()) < 2e-5
+    # d-activation: (a b^T) * act'(pre)
+    pre_b = bf(torch.randn(M, N, generator=g))
+    x = pre_b.double().requires_grad_(True)
+    quick_gelu(x).sum().backward()
+    d = ops.gemm_nt_dact(dev(a), dev(b), dev(pre_b), ops.ACT_QUICKGELU)
+    assert rel_err(d, (a.double() @ b.double().t()) * x.grad) < 8e-3
+    x2 = pre_b.double().requires_grad_(True)
+    torch.nn.functional.gelu(x2).sum().backward()
+    d2 = ops.gemm_nt_dact(dev(a), dev(b), dev(pre_b), ops.ACT_GELU_ERF)
+    assert rel_err(d2, (a.double() @ b.double().t()) * x2.grad) < 8e-3
+
+
+@pytest.mark.parametrize("Kr,N1,N2", [(64, 128, 128), (462, 128, 384), (1000, 64, 512), (19712, 768, 768), (77 * 6, 384, 128),
+                                      (6, 128, 64)])
+def test_gemm_tn(ops, Kr, N1, N2):
+    g = torch.Generator().manual_seed(Kr + N1)
+    a, b = bf(torch.randn(Kr, N1, generator=g)), bf(torch.randn(Kr, N2, generator=g))
+    ref = a.double().t() @ b.double()
+    out = ops.gemm_tn(dev(a), dev(b))
+    assert rel_err(out, ref) < 3e-5
+    # alpha + accumulate path
+    base = torch.randn(N1, N2, generator=g)
+    acc = dev(base.clone())
+    ops.gemm_tn(dev(a), dev(b), alpha=0.5, out=acc, accumulate=True)
+    assert rel_err(acc, base.double() + 0.5 * ref) < 3e-5
+
+
+def test_gemm_tn_asymmetric(ops):
+    # one-hot A picks single rows of B: exact, catches any row/column permutation in the
+    # transpose-read fragments
+    Kr, N1, N2 = 128, 128, 128
+    a = torch.zeros(Kr, N1)
+    perm = (torch.arange(N1) * 37 + 11) % Kr
+    a[perm, torch.arange(N1)] = 1.0                      # column n1 has its 1 at row perm[n1]
+    b = (torch.arange(Kr * N2, dtype=torch.float32).reshape(Kr, N2) % 509) / 8.0
+    out = ops.gemm_tn(dev(bf(a)), dev(bf(b)))
+    assert torch.equal(out.cpu(), bf(b).float()[perm])
+
+
+def test_cast_transpose_colsum(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(300, 200, generator=g)
+    y, yt = ops.cast_transpose_bf16(dev(x))
+    assert torch.equal(y.cpu(), bf(x)) and torch.equal(yt.cpu(), bf(x).t())
+    assert torch.equal(ops.cast_bf16(dev(x)).cpu(), bf(x))
+    xb = bf(torch.randn(1234, 384, generator=g))
+    assert rel_err(ops.colsum(dev(xb)), xb.double().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,W", [(7, 128), (462, 768), (50, 512), (33, 1024)])
+def test_layernorm(ops, rows, W):
+    g = torch.Generator().manual_seed(rows + W)
+    x = torch.randn(rows, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(W, generator=g), torch.randn(W, generator=g)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yref = torch.nn.functional.layer_norm(xd, (W,), gd, bd, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta), out_dtype=torch.float32)
+    assert rel_err(y, yref.detach()) < 1e-5
+    yb, _, _ = ops.layernorm_fwd(dev(x), dev(gamma), dev(beta))
+    assert rel_err(yb, yref.detach()) < 6e-3
+    dy = torch.randn(rows, W, generator=g)
+    yref.backward(dy.double())
+    dx, dxb, dg, db = ops.layernorm_bwd(dev(dy), dev(x), dev(gamma), mean, rstd)
+    assert rel_err(dx, xd.grad) < 2e-5 and rel_err(dg, gd.grad) < 2e-5 and rel_err(db, bd.grad) < 2e-5
+    assert rel_err(dxb, xd.grad) < 6e-3
+    # bf16 dy + accumulate into an existing dx
+    base = torch.randn(rows, W, generator=g)
+    dyb = bf(dy)
+    xd2 = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd2, (W,), gamma.double(), beta.double(), 1e-5).backward(dyb.double())
+    acc = dev(base.clone())
+    ops.layernorm_bwd(dev(dyb), dev(x), dev(gamma), mean, rstd, dx_accum=acc)
+    assert rel_err(acc, base.double() + xd2.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, B, H, Lq, Lk, causal, key_bias, scale):
+    q = q.double().view(B, Lq, H, 64).transpose(1, 2)
+    k = k.double().view(B, Lk, H, 64).transpose(1, 2)
+    v = v.double().view(B, Lk, H, 64).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) * scale
+    if key_bias is not None:
+        s = s + key_bias.double()[:, None, None, :]
+    if causal:
+        s = s + torch.full((Lq, Lk), float("-inf"), dtype=torch.float64).triu_(1)
+    p = torch.softmax(s, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * Lq, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal,bias", [(3, 2, 77, 77, True, False), (2, 3, 50, 50, False, False),
+                                                   (1, 2, 257, 257, False, False), (2, 2, 9, 577, False, False),
+                                                   (3, 2, 20, 20, False, True), (2, 1, 130, 130, True, False)])
+def test_attention_fwd_bwd(ops, B, H, Lq, Lk, causal, bias):
+    g = torch.Generator().manual_seed(B * 1000 + Lq)
+    W = H * 64
+    if Lq == Lk:     # packed qkv, as in the towers
+        qkv = bf(torch.randn(B * Lq, 3 * W, generator=g))
+        q, k, v = qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:]
+        dq_, dk_, dv_ = dev(qkv)[:, :W], dev(qkv)[:, W:2 * W], dev(qkv)[:, 2 * W:]
+    else:
+        q, k, v = (bf(torch.randn(B * Lq, W, generator=g)), bf(torch.randn(B * Lk, W, generator=g)),
+                   bf(torch.randn(B * Lk, W, generator=g)))
+        dq_, dk_, dv_ = dev(q), dev(k), dev(v)
+    kb = None
+    if bias:
+        kb = torch.zeros(B, Lk)
+        for b in range(B):
+            kb[b, Lk - 1 - 3 * b:] = -10000.0        # BERT-style padding mask (blip4cir/med.py:686)
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    oref, lseref = attn_ref(qd, kd, vd, B, H, Lq, Lk, causal, kb, 0.125)
+    o, lse = ops.attention_fwd(dq_, dk_, dv_, B, H, Lq, Lk, causal=causal, key_bias=None if kb is None else dev(kb))
+    assert rel_err(o, oref.detach()) < 1e-2          # P and O are rounded to bf16
+    assert (lse.cpu().double() - lseref.detach()).abs().max() < 2e-3
+    d_o = bf(torch.randn(B * Lq, W, generator=g))
+    oref.backward(d_o.double())
+    dq, dk, dv = ops.attention_bwd(dq_, dk_, dv_, o, lse, dev(d_o), B, H, Lq, Lk, causal=causal,
+                                   key_bias=None if kb is None else dev(kb))
+    assert rel_err(dq, qd.grad) < 2e-2 and rel_err(dk, kd.grad) < 2e-2 and rel_err(dv, vd.grad) < 2e-2
+
+
+# ------------------------------------------------------------------------------- bank loss
+def _bank_case(B, M, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randn(B, D, generator=g)
+    refer = torch.randn(M, D, generator=g)
+    bank = torch.nn.functional.normalize(torch.randn(M, D, generator=g))
+    ridx = torch.randint(0, M, (B,), generator=g)
+    labels = torch.randint(0, M, (B,), generator=g)
+    labels[0] = 0
+    labels[-1] = M - 1
+    return text, refer, bank, ridx, labels
+
+
+@pytest.mark.parametrize("B,M,D,tau", [(4, 500, 64, 0.01), (32, 4099, 512, 0.02), (16, 40000, 768, 0.03),
+                                        (70, 3000, 768, 0.02), (256, 40000, 768, 0.02), (33, 1500, 640, 0.02)])
+def test_bank_infonce(ops, B, M, D, tau):
+    from oracle import bank_loss
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, B + M)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    qref = bank_loss.l2_normalize(refer[ridx] + text)
+    assert rel_err(q, qref) < 1e-6
+    Dp = ops.bank_dim(D)
+    assert qb.shape == (B, Dp) and torch.equal(qb[:, :D].cpu(), bf(q.cpu())) and not qb[:, D:].any()
+    bank_b = ops.prepare_bank(dev(bank))
+    # reference on the same bf16-rounded operands: only accumulation order differs
+    qr, br = qb[:, :D].cpu().float(), bank_b[:, :D].cpu().float()
+    lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+    stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+    assert (stats[:, 3].cpu().double() - lab_ref).abs().max() < 2e-4
+    assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+    # the bf16 operand rounding itself: loss within 1e-2 of the fp32 oracle (tau amplifies x50..100)
+    full = bank_loss.infonce(qref, bank, labels, tau).item()
+    assert abs(mean.item() - full) < 1e-2 * max(1.0, abs(full))
+    # gradient
+    gs = 1.0 / B
+    dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, gs)
+    dq_ref = bank_loss.infonce_grad_q(qr, br, labels, tau)
+    assert rel_err(dq[:, :D], dq_ref) < 1.5e-2     # G is rounded to bf16 before the second GEMM
+    assert not dq[:, D:].any()
+    # combiner backward
+    dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :D].contiguous())
+    x = (refer[ridx] + text).double().requires_grad_(True)
+    (bank_loss.l2_normalize(x) * dq[:, :D].cpu().double()).sum().backward()
+    assert rel_err(dtext, x.grad) < 1e-5
+
+
+def test_bank_label_smoothing_and_shards(ops):
+    from oracle import bank_loss
+    B, M, D, tau, eps = 24, 2500, 256, 0.02, 0.1
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 77)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    bank_b = ops.prepare_bank(dev(bank))
+    qr, br = qb.cpu().float(), bank_b.cpu().float()
+    ref = torch.nn.functional.cross_entropy((qr.double() @ br.double().t()) / tau, labels, label_smoothing=eps)
+    # two unequal shards, as two ranks would hold them
+    cut = 1000
+    s0 = ops.bank_stats_fwd(qb, bank_b[:cut].contiguous(), dev(labels), 1.0 / tau, m_begin=0)
+    s1 = ops.bank_stats_fwd(qb, bank_b[cut:].contiguous(), dev(labels), 1.0 / tau, m_begin=cut)
+    lse, row, mean = ops.bank_loss_finalize(torch.stack([s0, s1]), M, label_smoothing=eps)
+    assert abs(mean.item() - ref.item()) < 3e-4
+    qd = qr.double().requires_grad_(True)
+    torch.nn.functional.cross_entropy((qd @ br.double().t()) / tau, labels, label_smoothing=eps).backward()
+    d0 = ops.bank_grad_q(qb, bank_b[:cut].contiguous(), dev(labels), 1.0 / tau, lse, 1.0 / B, M_total=M,
+                         label_smoothing=eps, m_begin=0)
+    d1 = ops.bank_grad_q(qb, bank_b[cut:].contiguous(), dev(labels), 1.0 / tau, lse, 1.0 / B, M_total=M,
+                         label_smoothing=eps, m_begin=cut)
+    assert rel_err(d0 + d1, qd.grad) < 1.5e-2
+
+
+def test_bank_matches_golden_loss_cases(ops, golden_dir):
+    import os
+    from cases import LOSS_CASES, loss_case_inputs
+    z = np.load(os.path.join(golden_dir, "loss_cases.npz"))
+    for ci in range(len(LOSS_CASES)):
+        text, rb, bank, ridx, labels, tau = loss_case_inputs(ci)
+        q, qb, inv = ops.combine_l2norm_fwd(dev(rb), dev(ridx), dev(text))
+        bank_b = ops.prepare_bank(dev(bank))
+        stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau)
+        lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
+        ref = float(z[f"c{ci}_loss"])
+        assert abs(mean.item() - ref) < 1e-2 * max(1.0, abs(ref))
+        dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / text.shape[0])
+        dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :text.shape[1]].contiguous())
+        assert rel_err(dtext, torch.from_numpy(z[f"c{ci}_dtext"])) < 3e-2
+
+
+# ----------------------------------------------------------------------------------- AdamW
+def test_adamw_matches_golden(ops, golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "adamw.npz"))
+    p = dev(torch.from_numpy(z["p0"]).clone())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    ops.adamw_step(p, dev(torch.from_numpy(z["g1"])), m, v, 1, float(z["lr"]))
+    assert torch.allclose(p.cpu(), torch.from_numpy(z["p1"]), atol=2e-7, rtol=1e-6)
+    # second step through the GradScaler path: scaled grads + inv_scale, found_inf = 0
+    found = torch.zeros(1, device="cuda")
+    g2 = dev(torch.from_numpy(z["g2"])) * 1024.0
+    ops.grad_check_finite(g2, found)
+    ops.adamw_step(p, g2, m, v, 2, float(z["lr"]), inv_scale=1.0 / 1024.0, found_inf=found)
+    assert torch.allclose(p.cpu(), torch.from_numpy(z["p2"]), atol=2e-7, rtol=1e-6)
+    # an inf gradient skips the step
+    before = p.clone()
+    g2[5] = float("inf")
+    ops.grad_check_finite(g2, found)
+    assert found.item() == 1.0
+    ops.adamw_step(p, g2, m, v, 3, float(z["lr"]), found_inf=found)
+    assert torch.equal(p, before)
+
+
+# -------------------------------------------------------------------------------- Recall@K
+def test_topk_identical_sets(ops, golden_dir):
+    import json, os
+    from oracle import recall
+    z = np.load(os.path.join(golden_dir, "recall.npz"))
+    pred, gallery = torch.from_numpy(z["pred"]), torch.from_numpy(z["gallery"])
+    gn, _, _ = ops.combine_l2norm_fwd(None, None, dev(gallery))
+    scores = ops.cosine_scores_f64(dev(pred), gn)
+    idx, val = ops.topk_from_scores(scores, 50)
+    order, sc = recall.ranked_indices(pred.numpy(), gallery.numpy())
+    assert np.abs(scores.cpu().numpy() - sc).max() < 1e-6
+    got = idx.cpu().numpy()
+    assert all(set(got[i]) == set(z["top50"][i]) for i in range(got.shape[0]))       # vs the reference
+    assert (got == order[:, :50]).mean() > 0.999                                      # vs the oracle, in order
+    # exclusion of the reference image (validate.py:39)
+    ex = torch.from_numpy(z["ref_idx"].astype(np.int32))
+    idx2, _ = ops.topk_from_scores(scores, 10, exclude=dev(ex))
+    got2 = idx2.cpu().numpy()
+    for i in range(got2.shape[0]):
+        row = [j for j in order[i] if j != int(ex[i])][:10]
+        assert list(got2[i]) == row

@@ -1,0 +1,93 @@
+"""GPU parity: the whole text tower + bank-loss step through the C-ABI vs golden vectors
+captured from the reference (tests/golden/tiny_clip.npz, cirplus_step.npz).
+
+Tolerances: the HIP path runs its GEMMs on bf16 operands with fp32 accumulation while the
+reference CPU path is fp32; north_star's gate is 1e-3 cosine on the embeddings.  Gradients
+are compared per parameter tensor in relative L2 norm (5e-2; observed ~1e-2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(golden_dir):
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    return z, sd
+
+
+def _tower(sd):
+    from spn4cir_amd.text_tower import TextTower, text_cfg_from_state_dict
+    cfg = text_cfg_from_state_dict(sd)
+    t = TextTower(cfg["width"], cfg["layers"], cfg["heads"], cfg["embed_dim"], cfg["vocab"], cfg["ctx"], "cuda")
+    t.load_clip_state_dict(sd)
+    return t
+
+
+def cosine(a, b):
+    return torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1)
+
+
+def test_text_features_match_reference(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    z, sd = _tiny(golden_dir)
+    t = _tower(sd)
+    feats = t.forward(torch.from_numpy(z["ids"]).cuda()).cpu()
+    ref = torch.from_numpy(z["text_feats"])
+    assert (1 - cosine(feats, ref)).max() < 1e-3
+    assert (feats - ref).norm() / ref.norm() < 2e-2
+
+
+def test_step_loss_and_grads_match_reference(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import ops
+    z, sd = _tiny(golden_dir)
+    s = np.load(os.path.join(golden_dir, "cirplus_step.npz"))
+    t = _tower(sd)
+    ids = torch.from_numpy(z["ids"]).cuda()
+    B = ids.shape[0]
+    tau = float(s["tau"])
+    feats = t.forward(ids)
+    q, qb, inv = ops.combine_l2norm_fwd(torch.from_numpy(s["refer_bank"]).cuda(), torch.from_numpy(s["ref_img_ids"]).cuda(),
+                                        feats)
+    bank = ops.prepare_bank(torch.from_numpy(s["target_bank"]).cuda())
+    labels = torch.from_numpy(s["tgt_img_ids"]).cuda()
+    stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau)
+    lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
+    assert abs(mean.item() - float(s["loss_plus"])) < 1e-2 * max(1.0, abs(float(s["loss_plus"])))
+    dq = ops.bank_grad_q(qb, bank, labels, 1.0 / tau, lse, 1.0 / B)
+    dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :t.embed_dim].contiguous())
+    grads = t.backward(dtext)
+    views = t.named_views(grads)
+    worst = 0.0
+    for key, g in views.items():
+        ref = torch.from_numpy(s["grad_plus::" + key])
+        err = ((g.cpu() - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+        worst = max(worst, err)
+        assert err < 5e-2, (key, err)
+    print("worst per-parameter relative L2 grad error:", worst)
+
+
+def test_adamw_on_flat_buffer_and_refresh(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import ops
+    z, sd = _tiny(golden_dir)
+    t = _tower(sd)
+    ids = torch.from_numpy(z["ids"]).cuda()
+    f0 = t.forward(ids).clone()
+    g = torch.randn(t.n_params, device="cuda") * 1e-3
+    m, v = torch.zeros_like(t.params), torch.zeros_like(t.params)
+    p_ref = t.params.cpu().clone()
+    from oracle import optim
+    optim.adamw_step(p_ref, g.cpu(), torch.zeros_like(p_ref), torch.zeros_like(p_ref), 1, 1e-3)
+    ops.adamw_step(t.params, g, m, v, 1, 1e-3)
+    assert torch.allclose(t.params.cpu(), p_ref, atol=1e-6, rtol=1e-5)
+    t.mark_stale()
+    f1 = t.forward(ids)
+    assert (f1 - f0).abs().max() > 1e-4          # the bf16 mirrors were refreshed from the new weights
