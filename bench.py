@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Stage-2 hot-path benchmark: triplets/sec of the SPN4CIR second-stage step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = the loop body of clip4cir/train_negplus.py:107-123 on config 2 of BASELINE.json
+(CLIP ViT-L/14 text tower, B = 256 per GPU, 77-token captions, 40 000 x 768 static negative bank,
+tau 0.02, AdamW lr 2e-5): token ids already on the device -> text tower fwd -> combiner + L2-norm
+-> bank InfoNCE -> backward -> (gradient all-reduce) -> AdamW -> bf16 weight refresh.
+Synthetic data, seeded random-init weights (no datasets / checkpoints offline).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel's achieved FLOP/s, timed live with HIP events on its stream
+  cpu_baseline - the CPU oracle (a port of the reference's fp32 CPU path) timed on the host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E spec
+FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 2MD + projection
+
+KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn_kernel", "mfma"), 2: ("attention_fwd_kernel", "mfma"),
+           3: ("attention_bwd_{delta,dq,dkv}", "mfma"), 4: ("bank_stream_kernel<fwd>", "hbm"),
+           5: ("bank_stream_kernel<bwd>", "hbm")}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch-per-gpu", type=int, default=256)
+    p.add_argument("--bank", type=int, default=40000)
+    p.add_argument("--model", default="ViT-L/14")
+    p.add_argument("--tau", type=float, default=0.02)
+    p.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-prof", action="store_true")
+    p.add_argument("--cpu-batch", type=int, default=16)
+    p.add_argument("--cpu-steps", type=int, default=3)
+    p.add_argument("--cpu-threads", type=int, default=32)
+    p.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return p.parse_args()
+
+
+def cpu_baseline(args, sd, target, refer):
+    """The oracle (a CPU port of the reference's fp32 path: text fwd -> bank_large_step -> autograd
+    backward -> torch AdamW as train_negplus.py:77-83 configures it) on the host cores."""
+    from oracle import bank_loss, clip_text
+    from spn4cir_amd import synthetic
+    B = args.cpu_batch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and thrashes) far below the core count of a big host
+    threads = max(1, min(avail, args.cpu_threads))
+    torch.set_num_threads(threads)
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW([{"params": list(params.values()), "lr": 2e-5, "betas": (0.9, 0.999), "eps": 1e-7}])
+    ids = synthetic.token_ids(B, seed=1)
+    ridx, labels = synthetic.triplet_indices(B, target.shape[0], seed=4)
+
+    def step():
+        opt.zero_grad()
+        feats = clip_text.encode_text(params, ids)
+        loss = bank_loss.bank_large_step(refer, ridx, feats, target, labels, args.tau)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    t0 = time.perf_counter()
+    step()
+    warm = time.perf_counter() - t0
+    n, t0 = 0, time.perf_counter()
+    while n < args.cpu_steps and (n == 0 or time.perf_counter() - t0 < args.cpu_budget_s) and warm < 4 * args.cpu_budget_s:
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n if n else warm      # a pathological host: report the warm-up step
+    return {"value": round(B / dt, 3), "unit": "triplets/sec", "cores": threads, "kind": "port",
+            "sample": f"{max(n, 1)} steps of B={B} at the config-2 shape (ViT-L/14 text tower, M={target.shape[0]}, "
+                      f"D={target.shape[1]}, fp32, torch CPU kernels, {threads} threads of {avail} available cores), "
+                      f"after 1 warm-up step",
+            "ms_per_step": round(dt * 1e3, 1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from spn4cir_amd import _lib, synthetic
+    from spn4cir_amd.models import CIRPlus
+    from spn4cir_amd.trainer import Stage2Trainer
+
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS[args.model]
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    model = CIRPlus(sd, tau=args.tau, device=dev, plus=True)
+    target, refer = synthetic.banks(args.bank, D, seed=2)
+    trainer = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode)
+    trainer.set_banks(refer, target)
+
+    B = args.batch_per_gpu
+    B_global = B * world
+    ids_all = synthetic.token_ids(B_global, seed=1)
+    ridx_all, lab_all = synthetic.triplet_indices(B_global, args.bank, seed=4)
+    sl = slice(rank * B, (rank + 1) * B)
+    ids, ridx, labels = ids_all[sl].to(dev), ridx_all[sl].to(dev), lab_all[sl].to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.step(ids, ridx, labels)
+    lib = _lib.lib()
+    prof = not args.no_prof
+    if prof:
+        lib.spn_prof_enable(max(64, 200 * args.steps))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(ids, ridx, labels)
+    barrier()
+    dt = time.perf_counter() - t0
+    if prof:
+        lib.spn_prof_disable()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        per_kernel = {}
+        if prof:
+            for kid, (name, bound) in KERNELS.items():
+                ms, work, n = C.c_double(), C.c_double(), C.c_int()
+                lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(n))
+                if n.value:
+                    per_kernel[kid] = dict(kernel=name, bound=bound, launches=n.value, total_ms=ms.value,
+                                           avg_us=ms.value / n.value * 1e3, work=work.value)
+        roof = None
+        extra = {}
+        if per_kernel:
+            dom = max((k for k in per_kernel.values() if k["bound"] == "mfma"), key=lambda k: k["total_ms"])
+            ach = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom["kernel"],
+                    "launches": dom["launches"], "avg_us": round(dom["avg_us"], 1),
+                    "share_of_step": round(dom["total_ms"] / (dt * 1e3), 3)}
+            ks = []
+            for k in per_kernel.values():
+                rate = k["work"] / (k["total_ms"] * 1e-3)
+                ent = {"kernel": k["kernel"], "bound": k["bound"], "launches": k["launches"],
+                       "avg_us": round(k["avg_us"], 1), "share_of_step": round(k["total_ms"] / (dt * 1e3), 3)}
+                if k["bound"] == "mfma":
+                    ent.update(achieved=round(rate / 1e12, 1), unit="TFLOP/s", frac=round(rate / 1e12 / PEAK_BF16_TFLOPS, 4))
+                else:
+                    ent.update(achieved=round(rate / 1e9, 1), unit="GB/s", frac=round(rate / 1e9 / PEAK_HBM_GBS, 4))
+                ks.append(ent)
+            extra["kernels"] = ks
+        tps = B_global * args.steps / dt
+        out = {
+            "metric": "triplets/sec", "value": round(tps, 1), "unit": "triplets/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"clip4cir {args.model} text tower + {args.bank}x{D} static negative bank "
+                                   f"(train_negplus.py second stage), B={B}/GPU, 77-token captions, tau={args.tau}, "
+                                   f"AdamW lr 2e-5, random-init weights",
+                       "global_batch": B_global, "seq_len": 77, "bank_rows": args.bank, "embed_dim": D,
+                       "parallelism": f"dp{world}" + (f"+bank-{args.bank_mode}" if world > 1 else "")},
+            "loss_last": round(loss_val, 5),
+            "step_model_tflops": round(tps * FLOP_PER_TRIPLET / 1e12 / world, 1),
+            "step_frac_of_bf16_peak": round(tps * FLOP_PER_TRIPLET / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+            "roofline": roof,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,25 @@ int spn_text_fwd(const spn_text_cfg* cfg, const float* params, const void* weigh
                  void* acts, float* feats, void* stream);
 int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                  void* acts, const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
+/* The same backward in three phases (head, layers-1..0, tail) so a data-parallel host can start
+ * the gradient all-reduce of a layer's span as soon as that layer's call has been enqueued
+ * (autograd's reverse-order hooks in DDP).  ws must be the same buffer in every phase. */
+int spn_text_bwd_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                      const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
+int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                       float* grads, int layer, void* ws, size_t ws_bytes, void* stream);
+int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- opt-in kernel timing
+ * HIP events recorded on the launch stream around the main kernels (bench.py's live roofline).
+ * The only process-global state in the library; off unless spn_prof_enable() is called.
+ * kernel ids: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd, 4 bank fwd, 5 bank bwd.
+ * total_work is FLOPs for ids 0-3 and algorithmic HBM bytes for ids 4-5. */
+int spn_prof_enable(int max_records);
+int spn_prof_disable(void);
+int spn_prof_reset(void);
+int spn_prof_collect(int kernel_id, double* total_ms, double* total_work, int* count);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,13 @@ _SIGS = {
     "spn_text_refresh_bf16": (i32, [C.POINTER(TextCfg), vp, vp, vp]),
     "spn_text_fwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp]),
     "spn_text_bwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
+    "spn_text_bwd_tail": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),
+    "spn_prof_enable": (i32, [i32]),
+    "spn_prof_disable": (i32, []),
+    "spn_prof_reset": (i32, []),
+    "spn_prof_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 

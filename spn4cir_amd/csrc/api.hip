@@ -218,4 +218,22 @@ int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weigh
                     ST(stream));
 }
 
+int spn_text_bwd_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                      const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !acts || !dfeats || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_head(tc(cfg), params, CBF(weights_bf16), (char*)acts, dfeats, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
+int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                       float* grads, int layer, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_layer(tc(cfg), params, CBF(weights_bf16), (char*)acts, grads, layer, (char*)ws, ws_bytes, ST(stream));
+}
+
+int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
+                      size_t ws_bytes, void* stream) {
+    if (!cfg || !ids || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_tail(tc(cfg), ids, (char*)acts, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
 }  // extern "C"

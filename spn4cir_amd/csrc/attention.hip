@@ -10,6 +10,7 @@
 // need 2 cross-lane steps, P goes back to LDS as 8-byte rows, and O is stored 8 bytes per lane.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace spn {
 
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
 int attention_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return SPN_ERR_ARG;
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return SPN_ERR_SHAPE;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, a);
+    {
+        ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
+        hipLaunchKernelGGL(attention_fwd_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, a);
+    }
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -379,6 +383,7 @@ int attention_bwd(const AttnBwdArgs& g, hipStream_t st) {
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 8 || g.lddo % 8 || g.lddq % 4 || g.lddk % 4 || g.lddv % 4)
         return SPN_ERR_SHAPE;
     const int n = a.B * a.Lq * a.H;
+    ProfScope prof(PK_ATTN_BWD, 10.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
     hipLaunchKernelGGL(attention_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)a.o, a.ldo, g.d_o,
                        g.lddo, g.delta, a.B, a.H, a.Lq);
     SPN_CHECK_LAUNCH();

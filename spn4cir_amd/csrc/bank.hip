@@ -15,6 +15,7 @@
 // chunk are co-scheduled on one XCD so the chunk is served from that XCD's L2.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace spn {
 
@@ -327,20 +328,29 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
 }
 
 // fold per-chunk statistics [n][B][4] -> [B][4]
+// one wave per query row: lanes take chunks i = lane, lane+64, ... then merge across the wave
 __global__ void bank_stats_fold_kernel(const float* __restrict__ ws, int n, int B, float* __restrict__ stats) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= B) return;
     float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
-    for (int i = 0; i < n; ++i) {
-        const float* p = ws + ((size_t)i * B + q) * 4;
+    for (int i = lane; i < n; i += 64) {
+        const f32x4 p = *(const f32x4*)(ws + ((size_t)i * B + q) * 4);
         const float mn = fmaxf(m, p[0]);
         if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
         m = mn;
         sl += p[2];
         lab = fmaxf(lab, p[3]);
     }
-    float* o = stats + (size_t)q * 4;
-    o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+    const float mw = wave_max(m);
+    l = (m > -INFINITY) ? l * __expf(m - mw) : 0.f;
+    l = wave_sum(l);
+    sl = wave_sum(sl);
+    lab = wave_max(lab);
+    if (lane == 0) {
+        float* o = stats + (size_t)q * 4;
+        o[0] = mw; o[1] = l; o[2] = sl; o[3] = lab;
+    }
 }
 
 // loss_row = lse - (1-eps)*label_logit - eps*mean_j logit_j   (CrossEntropyLoss w/ label smoothing)
@@ -392,7 +402,12 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
+    {
+        // "work" = algorithmic HBM bytes of one pass: the bank shard once + q in (+ dq out)
+        const double bytes = (double)a.M * D * 2 + (double)a.B * D * (BWD ? 6 : 2) + (double)a.B * 16;
+        ProfScope prof(BWD ? PK_BANK_BWD : PK_BANK_FWD, bytes, st);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
+    }
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -422,7 +437,7 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     if (ws_bytes < (size_t)c.nchunks * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
     SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)
     if (rc) return rc;
-    hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, ws, c.nchunks, a.B, stats);
+    hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, ws, c.nchunks, a.B, stats);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -436,19 +451,6 @@ int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, 
     return SPN_OK;
 }
 
-__global__ void bank_dq_fold_kernel(const float* __restrict__ ws, int n, int B, int D, float alpha,
-                                    float* __restrict__ dq, int accumulate) {
-    const int d4 = D >> 2;
-    const size_t total = (size_t)B * d4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 s = {0, 0, 0, 0};
-        for (int z = 0; z < n; ++z) s += *(const f32x4*)(ws + (size_t)z * B * D + i * 4);
-        s *= alpha;
-        if (accumulate) s += *(const f32x4*)(dq + i * 4);
-        *(f32x4*)(dq + i * 4) = s;
-    }
-}
-
 int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
                 float* dq, float* ws, size_t ws_bytes, hipStream_t st) {
     int rc = bank_check(a);
@@ -458,12 +460,7 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     if (ws_bytes < (size_t)c.nchunks * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
     SPN_BANK_DISPATCH(true, a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
     if (rc) return rc;
-    const size_t total = (size_t)a.B * (a.D / 4);
-    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-    hipLaunchKernelGGL(bank_dq_fold_kernel, dim3(blocks), dim3(256), 0, st, ws, c.nchunks, a.B, a.D,
-                       grad_scale * a.inv_tau, dq, 0);
-    SPN_CHECK_LAUNCH();
-    return SPN_OK;
+    return fold_rows(ws, (size_t)a.B * a.D, c.nchunks, (size_t)a.B * a.D, dq, grad_scale * a.inv_tau, 0, st);
 }
 
 }  // namespace spn

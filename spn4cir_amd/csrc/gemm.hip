@@ -12,6 +12,7 @@
 // Two LDS stages: tile t+1 streams in while tile t is multiplied.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace spn {
 
@@ -143,7 +144,8 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-#define SPN_LAUNCH_NT(MODE_, ACT_)                                                                              \
+    ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
+#define SPN_LAUNCH_NT(MODE_, ACT_)                                                                             \
     hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K, lda, ldb, ep)
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) SPN_LAUNCH_NT(GEMM_STORE, ACT_NONE);
@@ -311,13 +313,17 @@ int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, i
     const int k_chunk = ((ktiles + splits - 1) / splits) * BK;
     splits = (Kr + k_chunk - 1) / k_chunk;
     if (direct) {
+        ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, 1), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, C, ldc,
                            (size_t)0, k_chunk);
         SPN_CHECK_LAUNCH();
         return SPN_OK;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, ws, N2,
-                       (size_t)N1 * N2, k_chunk);
+    {
+        ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, ws,
+                           N2, (size_t)N1 * N2, k_chunk);
+    }
     SPN_CHECK_LAUNCH();
     const size_t total = (size_t)N1 * (N2 / 4);
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);

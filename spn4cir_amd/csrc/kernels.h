@@ -35,6 +35,7 @@ int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int
 int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
                 hipStream_t st);
 size_t colsum_workspace_bytes(int rows, int cols);
+int fold_rows(const float* ws, size_t stride, int n, size_t C, float* out, float alpha, int accumulate, hipStream_t st);
 int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W, int vocab,
               hipStream_t st);
 int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,

@@ -2,6 +2,7 @@
 // One wave per row, the row held in registers (W <= 64*4*MAXV); HBM-bound streaming kernels.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace spn {
 
@@ -150,26 +151,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
         }
     }
     if (ws) {
-        float* w0 = ws + (size_t)wave * 2 * W;
+        // combine the block's 4 waves through LDS, one partial row [2W] per block
+        extern __shared__ __attribute__((aligned(16))) float lnred[];
+        const int wv = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                *(f32x4*)(w0 + c * 4) = dg[i];
-                *(f32x4*)(w0 + W + c * 4) = db[i];
+                *(f32x4*)(lnred + (size_t)wv * 2 * W + c * 4) = dg[i];
+                *(f32x4*)(lnred + (size_t)wv * 2 * W + W + c * 4) = db[i];
             }
         }
+        __syncthreads();
+        float* w0 = ws + (size_t)blockIdx.x * 2 * W;
+        for (int c = threadIdx.x * 4; c < 2 * W; c += 1024) {
+            f32x4 s = *(const f32x4*)(lnred + c);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s += *(const f32x4*)(lnred + (size_t)k * 2 * W + c);
+            *(f32x4*)(w0 + c) = s;
+        }
     }
-}
-
-__global__ void layernorm_bwd_fold_kernel(const float* __restrict__ ws, int nwaves, int W, float* __restrict__ dgamma,
-                                          float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * W) return;
-    float s = 0.f;
-    for (int k = 0; k < nwaves; ++k) s += ws[(size_t)k * 2 * W + c];
-    float* o = c < W ? dgamma + c : dbeta + (c - W);
-    *o = accumulate ? *o + s : s;
 }
 
 static int lnb_blocks(int rows) {
@@ -177,7 +178,7 @@ static int lnb_blocks(int rows) {
     return b > LNB_BLOCKS ? LNB_BLOCKS : b;
 }
 
-size_t layernorm_bwd_workspace_bytes(int rows, int W) { return (size_t)lnb_blocks(rows) * 4 * 2 * W * sizeof(float); }
+size_t layernorm_bwd_workspace_bytes(int rows, int W) { return (size_t)lnb_blocks(rows) * 2 * W * sizeof(float); }
 
 int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
                   const float* rstd, float* dx, int accumulate_dx, bf16_t* dx_bf16, float* dgamma, float* dbeta,
@@ -188,13 +189,14 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     if (want_param && ws_bytes < layernorm_bwd_workspace_bytes(rows, W)) return SPN_ERR_WORKSPACE;
     const int blocks = lnb_blocks(rows);
     float* wsp = want_param ? ws : nullptr;
+    const size_t lds = want_param ? (size_t)4 * 2 * W * sizeof(float) : 0;
 #define SPN_LN_BWD(V_)                                                                                           \
     do {                                                                                                         \
         if (dy_bf16)                                                                                             \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_>), dim3(blocks), dim3(256), 0, st, dy_bf16, x, gamma, \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
                                mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
         else                                                                                                     \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_>), dim3(blocks), dim3(256), 0, st, dy_f32, x, gamma,  \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
                                mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
     } while (0)
     if (W <= 256) SPN_LN_BWD(1);
@@ -204,9 +206,11 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
 #undef SPN_LN_BWD
     SPN_CHECK_LAUNCH();
     if (want_param) {
-        hipLaunchKernelGGL(layernorm_bwd_fold_kernel, dim3((2 * W + 255) / 256), dim3(256), 0, st, ws, blocks * 4, W, dgamma,
-                           dbeta, accumulate_dparam);
         SPN_CHECK_LAUNCH();
+        int rc = fold_rows(ws, (size_t)2 * W, blocks, (size_t)W, dgamma, 1.0f, accumulate_dparam, st);
+        if (rc) return rc;
+        rc = fold_rows(ws + W, (size_t)2 * W, blocks, (size_t)W, dbeta, 1.0f, accumulate_dparam, st);
+        if (rc) return rc;
     }
     return SPN_OK;
 }

@@ -65,5 +65,11 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
              hipStream_t st);
 int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
              const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
+int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
+                  float* grads, char* ws, size_t ws_bytes, hipStream_t st);
+int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l, char* ws,
+                   size_t ws_bytes, hipStream_t st);
+int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                  hipStream_t st);
 
 }  // namespace spn

@@ -358,50 +358,97 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
     return SPN_OK;
 }
 
-int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
-             const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
-    SPN_TRY(text_check(c));
+// backward workspace carve-up (identical in every phase, so dx survives between the calls)
+struct TextBwdWs {
+    char* scratch;
+    float* dx;
+    bf16_t* dxb;
+    bf16_t* dfb;
+    float *dln, *de;
+    float* opws;
+    size_t opws_bytes;
+};
+
+static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w) {
     if (ws_bytes < text_ws_bytes(c)) return SPN_ERR_WORKSPACE;
+    const BlockCfg bc = text_block_cfg(c);
+    const size_t T = (size_t)c.B * c.L;
+    char* p = ws;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    w->scratch = p; p += block_bwd_scratch_bytes(bc);
+    w->dx = (float*)take(T * c.W * 4);
+    w->dxb = (bf16_t*)take(T * c.W * 2);
+    w->dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
+    w->dln = (float*)take((size_t)c.B * c.W * 4);
+    w->de = (float*)take((size_t)c.B * c.W * 4);
+    w->opws = (float*)p;
+    w->opws_bytes = ws_bytes - (size_t)(p - ws);
+    return SPN_OK;
+}
+
+// phase 1: text_projection, ln_final, scatter of the EOT-row gradient into dx
+int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
+                  float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
+    SPN_TRY(text_check(c));
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    TextLayout t;
+    text_layout(c, &t);
+    TextActs A = text_acts_at(acts, c);
+    SPN_TRY(cast_f32_bf16(dfeats, w.dfb, (size_t)c.B * c.D, st));
+    SPN_TRY(gemm_tn(A.ln_e, w.dfb, c.B, c.W, c.D, c.W, c.D, grads + t.text_proj, c.D, 1.0f, 0, w.opws, w.opws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_f32 = w.dln; e.ldc = c.W;
+        SPN_TRY(gemm_nt(w.dfb, wb + t.bf16_text_proj, c.B, c.W, c.D, c.D, c.D, GEMM_STORE, e, st));
+    }
+    SPN_TRY(layernorm_bwd(nullptr, w.dln, A.e, params + t.lnf_g, A.mean_f, A.rstd_f, w.de, 0, nullptr, grads + t.lnf_g,
+                          grads + t.lnf_b, 0, c.B, c.W, w.opws, w.opws_bytes, st));
+    SPN_TRY(scatter_rows_f32(w.de, A.eot, w.dx, w.dxb, c.B, c.L, c.W, st));
+    return SPN_OK;
+}
+
+// phase 2 (layers-1 .. 0): one residual block; its parameter gradients are final on return
+int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l, char* ws,
+                   size_t ws_bytes, hipStream_t st) {
+    SPN_TRY(text_check(c));
+    if (l < 0 || l >= c.layers) return SPN_ERR_ARG;
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
     TextLayout t;
     text_layout(c, &t);
     const BlockCfg bc = text_block_cfg(c);
     TextActs A = text_acts_at(acts, c);
-    const size_t T = (size_t)c.B * c.L;
-    char* p = ws;
-    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
-    char* scratch = p; p += block_bwd_scratch_bytes(bc);
-    float* dx = (float*)take(T * c.W * 4);
-    bf16_t* dxb = (bf16_t*)take(T * c.W * 2);
-    bf16_t* dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
-    float* dln = (float*)take((size_t)c.B * c.W * 4);
-    float* de = (float*)take((size_t)c.B * c.W * 4);
-    float* opws = (float*)p;
-    const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
+    BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
+    const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
+    const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+    return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st);
+}
 
-    SPN_TRY(cast_f32_bf16(dfeats, dfb, (size_t)c.B * c.D, st));
-    SPN_TRY(gemm_tn(A.ln_e, dfb, c.B, c.W, c.D, c.W, c.D, grads + t.text_proj, c.D, 1.0f, 0, opws, opws_bytes, st));
-    {
-        GemmEpilogue e;
-        e.out_f32 = dln; e.ldc = c.W;
-        SPN_TRY(gemm_nt(dfb, wb + t.bf16_text_proj, c.B, c.W, c.D, c.D, c.D, GEMM_STORE, e, st));
-    }
-    SPN_TRY(layernorm_bwd(nullptr, dln, A.e, params + t.lnf_g, A.mean_f, A.rstd_f, de, 0, nullptr, grads + t.lnf_g,
-                          grads + t.lnf_b, 0, c.B, c.W, opws, opws_bytes, st));
-    SPN_TRY(scatter_rows_f32(de, A.eot, dx, dxb, c.B, c.L, c.W, st));
-    for (int l = c.layers - 1; l >= 0; --l) {
-        BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
-        const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
-        const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
-        SPN_TRY(block_bwd(bc, P, a, G, dx, dxb, scratch, opws, opws_bytes, st));
-    }
+// phase 3: token / positional embedding gradients
+int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                  hipStream_t st) {
+    SPN_TRY(text_check(c));
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    TextLayout t;
+    text_layout(c, &t);
+    TextActs A = text_acts_at(acts, c);
     hipError_t he = hipMemsetAsync(grads + t.tok, 0, (size_t)c.vocab * c.W * sizeof(float), st);
     if (he != hipSuccess) return (int)he;
-    SPN_TRY(embed_bwd(ids, A.eot, dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
+    SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
     if (c.L < c.L_ctx) {
         he = hipMemsetAsync(grads + t.pos + (size_t)c.L * c.W, 0, (size_t)(c.L_ctx - c.L) * c.W * sizeof(float), st);
         if (he != hipSuccess) return (int)he;
     }
     return SPN_OK;
+}
+
+int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+             const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
+    SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));
+    for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    return text_bwd_tail(c, ids, acts, grads, ws, ws_bytes, st);
 }
 
 }  // namespace spn

@@ -1,0 +1,140 @@
+"""Data-parallel logic of the stage-2 step (one process per GPU, torch.distributed over RCCL).
+
+The reference is single-GPU (no collective on its hot path); this module is
+the MI355X-native multi-GPU design of SURVEY.md section 8(e):
+
+* triplets are sharded across ranks; the text tower is replicated and its flat gradient is
+  all-reduced in per-layer buckets as soon as each layer's backward has been enqueued;
+* bank loss, two modes
+    "replicated": every rank scores its own rows against the whole bank - no data-path exchange;
+    "sharded"   : RCCL all-gather of the (bf16) query embeddings, every rank scores ALL rows
+                  against its 1/G bank shard, all-gather of the [B,4] softmax statistics, then
+                  reduce-scatter of the partial dq back to the row owners.  Per-GPU HBM traffic on
+                  the bank drops by G; this is the variant north_star names.
+
+The math is backend-agnostic: `ops` is any object with bank_stats_fwd / bank_loss_finalize /
+bank_grad_q (the HIP ops in production; tests inject a CPU implementation over gloo).
+"""
+import torch
+import torch.distributed as dist
+
+
+def _world(group):
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def shard_range(total, world, rank):
+    """Contiguous, balanced [begin, end) split (remainder to the first ranks)."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def all_gather_cat(x, group=None):
+    world, _ = _world(group)
+    if world == 1:
+        return x
+    out = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(out, x.contiguous(), group=group)
+    return torch.cat(out, dim=0)
+
+
+def reduce_scatter_rows(x, group=None):
+    """x [world * B_local, ...] summed over ranks; this rank keeps its B_local rows."""
+    world, rank = _world(group)
+    if world == 1:
+        return x
+    n = x.shape[0] // world
+    if dist.get_backend(group) == "gloo":        # gloo has no reduce_scatter
+        y = x.contiguous().clone()
+        dist.all_reduce(y, group=group)
+        return y[rank * n:(rank + 1) * n].contiguous()
+    out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.reduce_scatter_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+class BankLossDP:
+    def __init__(self, ops, group=None, mode="sharded"):
+        if mode not in ("replicated", "sharded"):
+            raise ValueError(mode)
+        self.ops, self.group, self.mode = ops, group, mode
+        self.world, self.rank = _world(group)
+
+    def forward(self, qb_local, labels_local, bank, m_begin, M_total, inv_tau, label_smoothing=0.0):
+        """qb_local [B_local, Dp] bf16 L2-normalised queries, labels_local [B_local] int64 GLOBAL bank
+        rows, `bank` = full bank (replicated) or this rank's shard starting at global row m_begin.
+        Returns a ctx dict; ctx['loss'] is the GLOBAL mean loss (identical on every rank)."""
+        ops = self.ops
+        if self.mode == "replicated" or self.world == 1:
+            stats = ops.bank_stats_fwd(qb_local, bank, labels_local, inv_tau, m_begin)
+            lse, row, mean = ops.bank_loss_finalize(stats, M_total, label_smoothing)
+            loss = row.sum().reshape(1)
+            if self.world > 1:
+                dist.all_reduce(loss, group=self.group)          # reporting only
+            B_global = qb_local.shape[0] * self.world
+            return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss / B_global, bank=bank, m_begin=m_begin,
+                        M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False)
+        q_all = all_gather_cat(qb_local, self.group)
+        labels_all = all_gather_cat(labels_local, self.group)
+        stats = ops.bank_stats_fwd(q_all, bank, labels_all, inv_tau, m_begin)           # [B, 4] over my shard
+        stats_all = all_gather_cat(stats.unsqueeze(0), self.group)                      # [G, B, 4]
+        lse, row, mean = ops.bank_loss_finalize(stats_all, M_total, label_smoothing)    # identical everywhere
+        return dict(q=q_all, labels=labels_all, lse=lse, loss=mean, bank=bank, m_begin=m_begin, M_total=M_total,
+                    inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True)
+
+    def backward(self, ctx, loss_scale=1.0):
+        """-> d(loss_scale * global mean loss)/d(q_local)  [B_local, Dp] fp32"""
+        gs = loss_scale / ctx["B_global"]
+        dq = self.ops.bank_grad_q(ctx["q"], ctx["bank"], ctx["labels"], ctx["inv_tau"], ctx["lse"], gs,
+                                  M_total=ctx["M_total"], label_smoothing=ctx["ls"], m_begin=ctx["m_begin"])
+        if ctx["gathered"]:
+            dq = reduce_scatter_rows(dq, self.group)
+        return dq
+
+
+class GradBucketReducer:
+    """Sum the flat gradient over ranks in buckets, overlapped with the rest of backward.
+
+    `on_span_ready(start, end)` is called by TextTower.backward_phased as soon as the kernels that
+    finalise flat[start:end] are enqueued; torch's RCCL stream waits for exactly that point of the
+    compute stream and runs the all-reduce concurrently with the following layers.  Small spans are
+    merged until `bucket_elems` is reached (xGMI all-reduce wants >= tens of MB per call)."""
+
+    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20):
+        self.flat, self.group, self.bucket_elems = flat_grads, group, bucket_elems
+        self.world, _ = _world(group)
+        self._pending = []      # [(start, end)] contiguous-or-not spans waiting for a bucket
+        self._works = []
+
+    def _flush(self):
+        if not self._pending:
+            return
+        # merge adjacent spans (backward walks the flat buffer from the end, so they usually abut)
+        spans = sorted(self._pending)
+        merged = [list(spans[0])]
+        for s, e in spans[1:]:
+            if s == merged[-1][1]:
+                merged[-1][1] = e
+            else:
+                merged.append([s, e])
+        for s, e in merged:
+            self._works.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+        self._pending = []
+
+    def on_span_ready(self, start, end):
+        if self.world == 1:
+            return
+        self._pending.append((start, end))
+        if sum(e - s for s, e in self._pending) >= self.bucket_elems:
+            self._flush()
+
+    def finish(self):
+        if self.world == 1:
+            return
+        self._flush()
+        for w in self._works:
+            w.wait()            # the compute stream waits for the RCCL stream; no host sync on RCCL
+        self._works = []

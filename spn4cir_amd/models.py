@@ -1,0 +1,204 @@
+"""`CIRPlus`: the reference's stage-2 model protocol on the MI355X kernels.
+
+Mirrors clip4cir/models_negplus.py:16-154 (and the zero-shot variant zscir/models_bank.py:18-134):
+same constructor arguments, attributes (`tau`, `device`, `output_dim`, `input_dim`, `refer_bank`,
+`target_bank`, `M`, `clip`), methods (`encode_text`, `combining_function`, `forward ->
+{'bank_loss'}`, `load_ckpt`, `load_refer_bank`, bank setters) and state-dict keys (`clip.*`).
+
+Differences that do not change results: the target bank lives on the
+device as bf16 for the whole run instead of being copied host->device every step, and the
+B x M logits are never materialised.
+
+The device work is the C-ABI of include/spn4cir_hip.h; there is no CPU fallback.
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+from .text_tower import TextTower, text_cfg_from_state_dict
+
+
+class _BankStep(torch.autograd.Function):
+    """loss = mean CE((normalize(ref + text_tower(ids)) @ bank.T) / tau, labels).
+
+    Forward enqueues tower fwd + combiner + bank statistics; backward enqueues the bank gradient,
+    combiner and tower backward and leaves the flat gradient in `model.tower.grads`
+    (parameters' `.grad` are views of it).  `anchor` only exists so autograd calls backward()."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, ids, refer_idx, labels):
+        st = model._step_forward(ids, refer_idx, labels)
+        ctx.model, ctx.st = model, st
+        return st["loss"].reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._step_backward(ctx.st, grad_out)
+        return torch.zeros((), device=grad_out.device), None, None, None, None
+
+
+class _Tree(nn.Module):
+    """Nested containers so that parameter names reproduce the reference's dotted keys."""
+
+
+def _attach(root, dotted, param):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if not hasattr(node, p):
+            node.add_module(p, _Tree())
+        node = getattr(node, p)
+    node.register_parameter(parts[-1], param)
+
+
+class CIRPlus(nn.Module):
+    def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
+                 device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
+                 tokenizer=None):
+        """`clip_model_name`: path to a CLIP state-dict file (as clip.load accepts, clip/clip.py:120-123),
+        a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline)."""
+        super().__init__()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("spn4cir_amd.CIRPlus runs on an MI355X (device='cuda'); there is no CPU path")
+        sd = self._resolve_state_dict(clip_model_name)
+        cfg = text_cfg_from_state_dict(sd)
+        self.tower = TextTower(cfg["width"], cfg["layers"], cfg["heads"], cfg["embed_dim"], cfg["vocab"], cfg["ctx"],
+                               self.device)
+        self.tower.load_clip_state_dict(sd)
+        # parameters = views of the flat buffer, registered under the reference's names
+        self.clip = _Tree()
+        self._params = {}
+        for key, view in self.tower.named_views().items():
+            p = nn.Parameter(view, requires_grad=True)
+            _attach(self.clip, key, p)
+            self._params[key] = p
+        self.clip.register_parameter("logit_scale", nn.Parameter(
+            sd.get("logit_scale", torch.tensor(2.6592)).to(self.device, torch.float32).reshape(())))
+        self._visual_sd = {k: v.to(self.device) for k, v in sd.items() if k.startswith("visual.")}
+        for k, v in self._visual_sd.items():       # frozen image tower (models_negplus.py:27-28)
+            _attach(self.clip, k, nn.Parameter(v.float(), requires_grad=False))
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self.combining_function = self.element_wise_sum
+        self.tau = tau
+        self.label_smoothing = label_smoothing
+        self.output_dim = cfg["embed_dim"]
+        self.input_dim = self._input_resolution(sd)
+        self.plus = plus
+        self.neg_num = neg_num
+        self.tokenizer = tokenizer
+        self.preprocess = None
+        self.refer_bank = None
+        self._target_bank = None
+        self._target_bank_dev = None
+        self.M = 0
+        self.grad_scale_hook = None     # set by the DDP wrapper
+
+    # -------------------------------------------------------------------------- loading
+    @staticmethod
+    def _resolve_state_dict(name):
+        if isinstance(name, dict):
+            return name
+        if isinstance(name, str) and name.startswith("synthetic:"):
+            from . import synthetic
+            w, l, h, d = synthetic.CLIP_TEXT_CONFIGS[name.split(":", 1)[1]]
+            return synthetic.text_state_dict(w, l, d)
+        if isinstance(name, str) and os.path.isfile(name):
+            sd = torch.load(name, map_location="cpu")
+            return sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+        raise RuntimeError(f"Model {name} not found (expected a state-dict path, a dict or 'synthetic:<name>')")
+
+    @staticmethod
+    def _input_resolution(sd):
+        if "visual.conv1.weight" in sd and "visual.positional_embedding" in sd:
+            patch = sd["visual.conv1.weight"].shape[-1]
+            grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+            return patch * grid
+        return 224
+
+    def load_ckpt(self, model_path, is_origin=False):
+        """models_negplus.py:52-57: stage-1 `{'CLIP': sd}` when is_origin else `{'state_dict': sd}` (strict=False)."""
+        saved = torch.load(model_path, map_location="cpu")
+        src = {"clip." + k: v for k, v in saved["CLIP"].items()} if is_origin else saved["state_dict"]
+        own = self.state_dict()      # tensors alias the flat parameter buffer
+        with torch.no_grad():
+            for k, v in src.items():
+                if k in own and own[k].shape == v.shape:
+                    own[k].copy_(v.to(own[k].device, own[k].dtype))
+        self.tower.mark_stale()
+
+    # ---------------------------------------------------------------------------- banks
+    @property
+    def target_bank(self):
+        return self._target_bank
+
+    @target_bank.setter
+    def target_bank(self, bank):
+        """fp32 [M, D] L2-normalised rows (models_negplus.py:76-77); mirrored on the device as bf16."""
+        self._target_bank = bank
+        self._target_bank_dev = None if bank is None else ops.prepare_bank(bank.to(self.device, torch.float32))
+
+    def set_target_bank_shard(self, bank_shard_dev, m_begin, m_total):
+        """DDP bank-sharded mode: this rank holds rows [m_begin, m_begin + rows) of the global bank."""
+        self._target_bank_dev = bank_shard_dev
+        self._shard = (m_begin, m_total)
+
+    def load_refer_bank(self, bank_path):
+        self.refer_bank = torch.load(bank_path)
+
+    # -------------------------------------------------------------------------- encoders
+    def tokenize(self, text):
+        if torch.is_tensor(text):
+            return text.to(self.device, torch.int32).contiguous()
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer configured: pass pre-tokenised int32 ids or CIRPlus(tokenizer=...)")
+        return self.tokenizer(text).to(self.device, torch.int32).contiguous()
+
+    def encode_text(self, text):
+        """list[str] (or pre-tokenised ids) -> un-normalised text features [B, D] (models_negplus.py:43-46)."""
+        return self.tower.forward(self.tokenize(text))
+
+    def element_wise_sum(self, refer_image_feats, text_feats):
+        return refer_image_feats + text_feats        # models_negplus.py:48-50
+
+    # ------------------------------------------------------------------------------ step
+    def _refer_rows(self, indexs, refer_indexs):
+        idx = refer_indexs if self.plus else indexs      # models_negplus.py:132-135
+        bank = self.refer_bank
+        if bank.device != self.device:
+            bank = self.refer_bank = bank.to(self.device)
+        return bank, idx.to(self.device, torch.int64)
+
+    def _step_forward(self, ids, refer_idx, labels):
+        bank_dev = self._target_bank_dev
+        feats = self.tower.forward(ids)
+        q, qb, inv = ops.combine_l2norm_fwd(self._refer_f32, refer_idx, feats)
+        M = bank_dev.shape[0]
+        stats = ops.bank_stats_fwd(qb, bank_dev, labels, 1.0 / self.tau)
+        lse, row, mean = ops.bank_loss_finalize(stats, M, self.label_smoothing)
+        return dict(q=q, qb=qb, inv=inv, lse=lse, loss=mean, labels=labels, B=ids.shape[0], M=M)
+
+    def _step_backward(self, st, grad_out):
+        scale = float(grad_out) if not torch.is_tensor(grad_out) else grad_out.item()
+        dq = ops.bank_grad_q(st["qb"], self._target_bank_dev, st["labels"], 1.0 / self.tau, st["lse"],
+                             scale / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing)
+        dtext = ops.combine_l2norm_bwd(st["q"], st["inv"], dq[:, :self.output_dim].contiguous())
+        flat = self.tower.backward(dtext)
+        for key, view in self.tower.named_views(flat).items():
+            p = self._params[key]
+            p.grad = view if p.grad is None else p.grad + view
+
+    def forward(self, text, indexs, target_indexs, refer_indexs):
+        """models_negplus.py:144-148 -> {'bank_loss': 0-dim tensor with grad}."""
+        ids = self.tokenize(text)
+        bank, ridx = self._refer_rows(indexs, refer_indexs)
+        self._refer_f32 = bank if bank.dtype == torch.float32 else bank.float()
+        labels = target_indexs.to(self.device, torch.int64)
+        loss = _BankStep.apply(self._anchor, self, ids, ridx, labels)
+        return {"bank_loss": loss}
+
+    def parameters_changed(self):
+        """Call after an external optimizer updated the parameters in place."""
+        self.tower.mark_stale()

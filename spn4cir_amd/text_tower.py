@@ -135,3 +135,27 @@ class TextTower:
         check(lib().spn_text_bwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(dfeats),
                                  _p(self.grads), _p(self._ws), self._ws.numel(), _stream()), "text_bwd")
         return self.grads
+
+    def backward_phased(self, dfeats, on_span_ready):
+        """Same as backward(), but calls on_span_ready(start, end) right after the launches that
+        finish the flat-gradient range [start, end) have been enqueued (tail+head params first, then
+        each block from the last to the first, then the embeddings): the DDP bucket hook."""
+        ids = self._last
+        if ids is None:
+            raise RuntimeError("backward_phased() without a preceding forward()")
+        B, L = ids.shape
+        cfg = self._buffers(B, L, True)
+        dfeats = dfeats.contiguous()
+        ws, n = _p(self._ws), self._ws.numel()
+        spans = self.layer_spans()
+        check(lib().spn_text_bwd_head(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats),
+                                      _p(self.grads), ws, n, _stream()), "text_bwd_head")
+        on_span_ready(*spans[0])
+        for i, l in enumerate(reversed(range(self.layers))):
+            check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),
+                                           _p(self.grads), l, ws, n, _stream()), "text_bwd_layer")
+            on_span_ready(*spans[1 + i])
+        check(lib().spn_text_bwd_tail(C.byref(cfg), _p(ids), _p(self._acts), _p(self.grads), ws, n, _stream()),
+              "text_bwd_tail")
+        on_span_ready(*spans[-1])
+        return self.grads

@@ -1,0 +1,70 @@
+"""Fast-path stage-2 trainer: one `step()` = the loop body of clip4cir/train_negplus.py:107-123.
+
+tokens-on-device -> text tower fwd -> combiner + L2-normalise -> bank InfoNCE -> backward ->
+(gradient all-reduce) -> AdamW -> bf16 weight refresh, with no host synchronisation inside a step
+(the reference syncs on loss.item() every step, train_negplus.py:114; here the loss stays on
+the device and is read by the caller when it wants it).  bf16 needs no loss scaling, so the
+GradScaler of the reference (train_negplus.py:84) degenerates to scale = 1; the inv_scale /
+found_inf plumbing of spn_adamw_step is still exercised by the autograd path in models.py.
+"""
+import torch
+
+from . import ops
+from .distributed import BankLossDP, GradBucketReducer, _world, shard_range
+
+
+class Stage2Trainer:
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
+                 bank_mode="replicated", check_finite=False):
+        self.model, self.tower = model, model.tower
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.loss_dp = BankLossDP(ops, group, bank_mode if self.world > 1 else "replicated")
+        self.m = torch.zeros_like(self.tower.params)
+        self.v = torch.zeros_like(self.tower.params)
+        self.step_count = 0
+        self.check_finite = check_finite
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.tower.device)
+        self.reducer = GradBucketReducer(self.tower.grads, group)
+        self._bank = None
+        self._m_begin, self._M_total = 0, 0
+        self._refer = None
+
+    def set_banks(self, refer_bank, target_bank):
+        """refer_bank fp32 [N, D] raw features; target_bank fp32 [M, D] L2-normalised rows.
+        In "sharded" mode only this rank's contiguous row range is kept on the device."""
+        dev = self.tower.device
+        self._refer = refer_bank.to(dev, torch.float32).contiguous()
+        M = target_bank.shape[0]
+        self._M_total = M
+        if self.loss_dp.mode == "sharded" and self.world > 1:
+            b, e = shard_range(M, self.world, self.rank)
+            self._m_begin = b
+            self._bank = ops.prepare_bank(target_bank[b:e].to(dev, torch.float32))
+        else:
+            self._m_begin = 0
+            self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32))
+
+    def step(self, ids, refer_idx, labels):
+        """ids int32 [B_local, L], refer_idx / labels int64 [B_local] (device). Returns the global mean
+        loss as a 1-element device tensor."""
+        t = self.tower
+        feats = t.forward(ids)
+        q, qb, inv = ops.combine_l2norm_fwd(self._refer, refer_idx, feats)
+        ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / self.model.tau,
+                                   self.model.label_smoothing)
+        dq = self.loss_dp.backward(ctx)
+        dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :t.embed_dim].contiguous())
+        t.backward_phased(dtext, self.reducer.on_span_ready)
+        self.reducer.finish()
+        self.step_count += 1
+        found = None
+        if self.check_finite:
+            self.found_inf.zero_()
+            ops.grad_check_finite(t.grads, self.found_inf)
+            found = self.found_inf
+        ops.adamw_step(t.params, t.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd,
+                       1.0, found)
+        t.refresh()
+        return ctx["loss"]
