@@ -51,9 +51,10 @@ int spn_gemm_nt_resid(const void* A, const void* B, int M, int N, int K, int lda
 int spn_gemm_nt_dact(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const void* pre_act_bf16,
                      int act, void* out_bf16, int ldc, void* stream);
 /* C[N1,N2] (fp32) = alpha * A[Kr,N1]^T . B[Kr,N2] (+ C): weight gradients dW = dY^T X (autograd of
- * F.linear).  N1, N2 % 8 == 0.  ws: spn_gemm_tn_workspace_bytes() bytes of scratch. */
+ * F.linear).  colsum_out (optional, [N1]) receives sum_k A[k][:], i.e. the bias gradient when A = dY.
+ * N1, N2 % 8 == 0.  ws: spn_gemm_tn_workspace_bytes() bytes of scratch. */
 int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
-                float alpha, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                float alpha, int accumulate, float* colsum_out, void* ws, size_t ws_bytes, void* stream);
 size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2);
 
 /* ---------------------------------------------------------------- elementwise / reductions */

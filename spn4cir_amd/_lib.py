@@ -32,7 +32,7 @@ _SIGS = {
     "spn_gemm_nt": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp]),
     "spn_gemm_nt_resid": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
     "spn_gemm_nt_dact": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
-    "spn_gemm_tn": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, i32, vp, sz, vp]),
+    "spn_gemm_tn": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i32, f32, i32, vp, vp, sz, vp]),
     "spn_gemm_tn_workspace_bytes": (sz, [i32, i32, i32]),
     "spn_cast_f32_bf16": (i32, [vp, vp, sz, vp]),
     "spn_cast_transpose_f32_bf16": (i32, [vp, vp, vp, i32, i32, vp]),

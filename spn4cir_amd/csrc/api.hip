@@ -48,8 +48,9 @@ int spn_gemm_nt_dact(const void* A, const void* B, int M, int N, int K, int lda,
 }
 
 int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
-                float alpha, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    return gemm_tn(CBF(A), CBF(B), Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, (float*)ws, ws_bytes, ST(stream));
+                float alpha, int accumulate, float* colsum_out, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_tn(CBF(A), CBF(B), Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, colsum_out, (float*)ws, ws_bytes,
+                   ST(stream));
 }
 
 size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2) { return gemm_tn_workspace_bytes(Kr, N1, N2); }

@@ -137,8 +137,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
     }
 }
 
+bool gemm_use_v1() {
+    // v1 (128x128 tile, 2 blocks/CU) measures faster than gemm2.hip on the K=768..3072 tower
+    // shapes; SPN_GEMM_V2=1 selects the 256x128 / 3-stage kernels (better at K >= 8192).
+    static const bool v1 = [] {
+        const char* e = getenv("SPN_GEMM_V2");
+        return !(e && e[0] == '1');
+    }();
+    return v1;
+}
+
 int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
             const GemmEpilogue& ep, hipStream_t st) {
+    if (!gemm_use_v1()) return gemm_nt2(A, B, M, N, K, lda, ldb, mode, ep, st);
     if (M <= 0 || N <= 0 || K <= 0) return SPN_ERR_ARG;
     if (K % BK || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
@@ -205,7 +216,8 @@ __device__ __forceinline__ bf16x8 tn_frag(const char* sT, int cb, int ks, int la
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ B, int Kr, int N1, int N2,
                                                               int lda, int ldb, float* __restrict__ C, int ldc,
-                                                              size_t split_stride, int k_chunk) {
+                                                              size_t split_stride, int k_chunk,
+                                                              float* __restrict__ colsum_out) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -214,6 +226,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __re
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const int kb = blockIdx.y * k_chunk;
     const int ke = min(Kr, kb + k_chunk);
+    // bias gradient for free: an all-ones B operand makes every output row the column sum of A
+    const bool do_colsum = colsum_out != nullptr && n0 == 0 && wc == 0;
+    f32x4 accs[4];
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)Kr * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)Kr * (uint32_t)ldb * 2u);
@@ -252,6 +272,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __re
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accs[i] = mfma16(ones, a[i], accs[i]);
+            }
         }
     }
     float* Cz = C + (size_t)blockIdx.y * split_stride;
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __re
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wr * 64 + i * 16 + (lane & 15);
         if (m >= N1) continue;
+        if (do_colsum && lane < 16) colsum_out[(size_t)blockIdx.y * N1 + m] = accs[i][0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
@@ -297,32 +322,36 @@ int gemm_tn_splits(int Kr, int N1, int N2) {
 
 size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2) {
     const int s = gemm_tn_splits(Kr, N1, N2);
-    return s > 1 ? (size_t)s * N1 * N2 * sizeof(float) : 0;
+    const size_t v1 = ((size_t)s * N1 * N2 + (size_t)s * N1) * sizeof(float);
+    const size_t v2 = gemm_tn2_workspace_bytes(Kr, N1, N2);
+    return v1 > v2 ? v1 : v2;
 }
 
 int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
-            float alpha, int accumulate, float* ws, size_t ws_bytes, hipStream_t st) {
+            float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (!gemm_use_v1())
+        return gemm_tn2(A, B, Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, colsum_out, ws, ws_bytes, st);
     if (Kr <= 0 || N1 <= 0 || N2 <= 0) return SPN_ERR_ARG;
     if (N1 % 8 || N2 % 8 || lda % 8 || ldb % 8 || ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)Kr * lda * 2 >= (1ull << 32) || (uint64_t)Kr * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
     int splits = gemm_tn_splits(Kr, N1, N2);
-    const bool direct = (splits == 1 && !accumulate && alpha == 1.0f);
-    if (!direct && ws_bytes < (size_t)splits * N1 * N2 * sizeof(float)) return SPN_ERR_WORKSPACE;
+    if (ws_bytes < ((size_t)splits * N1 * N2 + (size_t)splits * N1) * sizeof(float)) return SPN_ERR_WORKSPACE;
     const int ktiles = (Kr + BK - 1) / BK;
     const int k_chunk = ((ktiles + splits - 1) / splits) * BK;
     splits = (Kr + k_chunk - 1) / k_chunk;
-    if (direct) {
+    float* cs_ws = colsum_out ? ws + (size_t)splits * N1 * N2 : nullptr;
+    if (splits == 1 && !accumulate && alpha == 1.0f) {   // single split: straight into C
         ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, 1), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, C, ldc,
-                           (size_t)0, k_chunk);
+                           (size_t)0, k_chunk, colsum_out);
         SPN_CHECK_LAUNCH();
         return SPN_OK;
     }
     {
         ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(NTHREADS), 0, st, A, B, Kr, N1, N2, lda, ldb, ws,
-                           N2, (size_t)N1 * N2, k_chunk);
+                           N2, (size_t)N1 * N2, k_chunk, cs_ws);
     }
     SPN_CHECK_LAUNCH();
     const size_t total = (size_t)N1 * (N2 / 4);
@@ -330,6 +359,7 @@ int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, i
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha,
                        accumulate);
     SPN_CHECK_LAUNCH();
+    if (colsum_out) return fold_rows(cs_ws, (size_t)N1, splits, (size_t)N1, colsum_out, 1.0f, 0, st);
     return SPN_OK;
 }
 

@@ -24,9 +24,17 @@ struct GemmEpilogue {
 // gemm.hip
 int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
             const GemmEpilogue& ep, hipStream_t st);
+// colsum_out (optional, [N1]) receives the column sums of A (the bias gradient when A = dY)
 int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
-            float alpha, int accumulate, float* ws, size_t ws_bytes, hipStream_t st);
+            float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2);
+// gemm2.hip (second generation; gemm_nt / gemm_tn dispatch to these unless SPN_GEMM_V1=1)
+int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
+             const GemmEpilogue& ep, hipStream_t st);
+int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
+             float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
+bool gemm_use_v1();
 
 // elementwise.hip
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);

@@ -184,30 +184,27 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
 
     // MLP
-    SPN_TRY(colsum_bf16(dx_bf16, T, W, W, G.b_proj, 0, ws, ws_bytes, st));
     {
         GemmEpilogue e;
         e.aux_in = A.pre; e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
         SPN_TRY(gemm_nt(dx_bf16, P.w_proj_t, T, 4 * W, W, W, W, GEMM_DACT, e, st));
     }
-    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, ws, ws_bytes, st));
-    SPN_TRY(colsum_bf16(dpre, T, 4 * W, 4 * W, G.b_fc, 0, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, ws, ws_bytes, st));
     {
         GemmEpilogue e;
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dpre, P.w_fc_t, T, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, ws, ws_bytes, st));
     SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dx_bf16, G.ln2_g, G.ln2_b, 0, T, W, ws,
                           ws_bytes, st));
     // attention
-    SPN_TRY(colsum_bf16(dx_bf16, T, W, W, G.b_o, 0, ws, ws_bytes, st));
     {
         GemmEpilogue e;
         e.out_bf16 = dattn; e.ldc = W;
         SPN_TRY(gemm_nt(dx_bf16, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dx_bf16, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dx_bf16, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, ws, ws_bytes, st));
     {
         AttnBwdArgs g;
         AttnArgs& a = g.f;
@@ -222,13 +219,12 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         g.delta = delta;
         SPN_TRY(attention_bwd(g, st));
     }
-    SPN_TRY(colsum_bf16(dqkv, T, 3 * W, 3 * W, G.b_qkv, 0, ws, ws_bytes, st));
     {
         GemmEpilogue e;
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dqkv, P.w_qkv_t, T, W, 3 * W, 3 * W, 3 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, ws, ws_bytes, st));
     SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, dx_bf16, G.ln1_g, G.ln1_b, 0, T, W, ws,
                           ws_bytes, st));
     return SPN_OK;
@@ -396,7 +392,7 @@ int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char*
     text_layout(c, &t);
     TextActs A = text_acts_at(acts, c);
     SPN_TRY(cast_f32_bf16(dfeats, w.dfb, (size_t)c.B * c.D, st));
-    SPN_TRY(gemm_tn(A.ln_e, w.dfb, c.B, c.W, c.D, c.W, c.D, grads + t.text_proj, c.D, 1.0f, 0, w.opws, w.opws_bytes, st));
+    SPN_TRY(gemm_tn(A.ln_e, w.dfb, c.B, c.W, c.D, c.W, c.D, grads + t.text_proj, c.D, 1.0f, 0, nullptr, w.opws, w.opws_bytes, st));
     {
         GemmEpilogue e;
         e.out_f32 = w.dln; e.ldc = c.W;

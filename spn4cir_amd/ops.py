@@ -76,19 +76,19 @@ def gemm_nt_dact(a, b, pre, act):
     return out
 
 
-def gemm_tn(a, b, alpha=1.0, out=None, accumulate=False):
-    """a [Kr,N1] bf16, b [Kr,N2] bf16 -> a.T @ b  (fp32 [N1,N2])."""
+def gemm_tn(a, b, alpha=1.0, out=None, accumulate=False, want_colsum=False):
+    """a [Kr,N1] bf16, b [Kr,N2] bf16 -> a.T @ b  (fp32 [N1,N2]) [, column sums of a]."""
     _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
     Kr, N1 = a.shape
     N2 = b.shape[1]
     if out is None:
         out = torch.empty(N1, N2, dtype=torch.float32, device=a.device)
     nb = lib().spn_gemm_tn_workspace_bytes(Kr, N1, N2)
-    nb = max(nb, N1 * N2 * 4)   # the accumulate / alpha path always goes through the workspace
     ws = workspace(nb, a.device)
-    check(lib().spn_gemm_tn(_p(a), _p(b), Kr, N1, N2, N1, N2, _p(out), N2, float(alpha), int(accumulate), _p(ws),
-                            ws.numel(), _stream()), "gemm_tn")
-    return out
+    cs = torch.empty(N1, dtype=torch.float32, device=a.device) if want_colsum else None
+    check(lib().spn_gemm_tn(_p(a), _p(b), Kr, N1, N2, N1, N2, _p(out), N2, float(alpha), int(accumulate), _p(cs),
+                            _p(ws), ws.numel(), _stream()), "gemm_tn")
+    return (out, cs) if want_colsum else out
 
 
 # ------------------------------------------------------------------------- elementwise

@@ -97,8 +97,9 @@ def test_gemm_tn(ops, Kr, N1, N2):
     g = torch.Generator().manual_seed(Kr + N1)
     a, b = bf(torch.randn(Kr, N1, generator=g)), bf(torch.randn(Kr, N2, generator=g))
     ref = a.double().t() @ b.double()
-    out = ops.gemm_tn(dev(a), dev(b))
+    out, cs = ops.gemm_tn(dev(a), dev(b), want_colsum=True)
     assert rel_err(out, ref) < 3e-5
+    assert rel_err(cs, a.double().sum(0)) < 3e-5      # fused bias gradient (column sums of A)
     # alpha + accumulate path
     base = torch.randn(N1, N2, generator=g)
     acc = dev(base.clone())
