@@ -1,0 +1,114 @@
+"""World-size-2 gloo tests of the data-parallel logic (spn4cir_amd/distributed.py).
+
+The collectives and the shard / LSE-combination math run for real over gloo; the three bank ops
+are injected as a CPU implementation built on the oracle (allowed in tests only), so the test
+checks that the multi-rank result equals the single-process oracle loss and gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class CpuBankOps:
+    """bank_stats_fwd / bank_loss_finalize / bank_grad_q with the semantics of include/spn4cir_hip.h."""
+
+    @staticmethod
+    def bank_stats_fwd(q, bank, labels, inv_tau, m_begin=0):
+        logits = (q.double() @ bank.double().t()) * inv_tau
+        m = logits.max(dim=1).values
+        l = torch.exp(logits - m[:, None]).sum(1)
+        sl = logits.sum(1)
+        local = labels.long() - m_begin
+        inside = (local >= 0) & (local < bank.shape[0])
+        lab = torch.full_like(m, float("-inf"))
+        rows = torch.arange(q.shape[0])[inside]
+        lab[inside] = logits[rows, local[inside]]
+        return torch.stack([m, l, sl, lab], dim=1).float()
+
+    @staticmethod
+    def bank_loss_finalize(stats, M_total, label_smoothing=0.0):
+        if stats.dim() == 2:
+            stats = stats.unsqueeze(0)
+        s = stats.double()
+        m = s[..., 0].max(dim=0).values
+        l = (s[..., 1] * torch.exp(s[..., 0] - m)).sum(0)
+        lse = m + torch.log(l)
+        lab = s[..., 3].max(dim=0).values
+        row = lse - (1 - label_smoothing) * lab - label_smoothing * s[..., 2].sum(0) / M_total
+        return lse.float(), row.float(), row.mean().reshape(1).float()
+
+    @staticmethod
+    def bank_grad_q(q, bank, labels, inv_tau, row_lse, grad_scale, M_total=None, label_smoothing=0.0, m_begin=0):
+        logits = (q.double() @ bank.double().t()) * inv_tau
+        g = torch.exp(logits - row_lse.double()[:, None]) - label_smoothing / (M_total or bank.shape[0])
+        local = labels.long() - m_begin
+        inside = (local >= 0) & (local < bank.shape[0])
+        rows = torch.arange(q.shape[0])[inside]
+        g[rows, local[inside]] -= 1 - label_smoothing
+        return ((g @ bank.double()) * (grad_scale * inv_tau)).float()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd.distributed import BankLossDP, GradBucketReducer, shard_range
+        g = torch.Generator().manual_seed(0)
+        B, M, D, tau, eps = 12, 301, 32, 0.05, 0.1
+        q = torch.nn.functional.normalize(torch.randn(B, D, generator=g))
+        bank = torch.nn.functional.normalize(torch.randn(M, D, generator=g))
+        labels = torch.randint(0, M, (B,), generator=g)
+        bl = B // world
+        ql, ll = q[rank * bl:(rank + 1) * bl].clone(), labels[rank * bl:(rank + 1) * bl].clone()
+        dp = BankLossDP(CpuBankOps, None, mode)
+        if mode == "sharded":
+            b, e = shard_range(M, world, rank)
+            ctx = dp.forward(ql, ll, bank[b:e].contiguous(), b, M, 1.0 / tau, eps)
+        else:
+            ctx = dp.forward(ql, ll, bank, 0, M, 1.0 / tau, eps)
+        dq = dp.backward(ctx)
+        # single-process reference
+        qd = q.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy((qd @ bank.double().t()) / tau, labels, label_smoothing=eps)
+        ref.backward()
+        ok_loss = abs(ctx["loss"].item() - ref.item()) < 1e-5
+        ok_grad = torch.allclose(dq.double(), qd.grad[rank * bl:(rank + 1) * bl], atol=1e-6, rtol=1e-4)
+        # bucketed gradient all-reduce
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        red = GradBucketReducer(flat, None, bucket_elems=300)
+        for s, e in [(900, 1000), (600, 900), (250, 600), (0, 250)]:
+            red.on_span_ready(s, e)
+        red.finish()
+        ok_red = torch.equal(flat, torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1)))
+        out.put((rank, ok_loss, ok_grad, ok_red, ctx["loss"].item(), ref.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+def test_bank_loss_data_parallel_world2(mode):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_loss, ok_grad, ok_red, loss, ref in res:
+        assert ok_loss, (mode, rank, loss, ref)
+        assert ok_grad, (mode, rank)
+        assert ok_red, (mode, rank)

@@ -1,0 +1,149 @@
+"""GPU tests of the host protocol: CIRPlus (reference-style autograd loop), the fused trainer
+against the CPU oracle, and the Recall@K surface against metrics captured from the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _tiny_sd(golden_dir):
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    return z, {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+
+
+def test_cirplus_reference_style_loop(golden_dir):
+    """forward -> {'bank_loss'} with grad; loss.backward(); torch.optim.AdamW(model.parameters()).step()
+    exactly as clip4cir/train_negplus.py:77-123 drives the model."""
+    _need_gpu()
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    s = np.load(os.path.join(golden_dir, "cirplus_step.npz"))
+    model = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=True)
+    keys = set(model.state_dict().keys())
+    assert "clip.transformer.resblocks.1.attn.in_proj_weight" in keys and "clip.text_projection" in keys
+    assert "clip.visual.conv1.weight" in keys and "clip.logit_scale" in keys
+    assert not model.clip.visual.conv1.weight.requires_grad            # frozen image tower
+    model.refer_bank = torch.from_numpy(s["refer_bank"])
+    model.target_bank = torch.from_numpy(s["target_bank"])
+    ids = torch.from_numpy(z["ids"])
+    B = ids.shape[0]
+    opt = torch.optim.AdamW([{"params": [p for p in model.parameters() if p.requires_grad], "lr": 1e-3,
+                              "betas": (0.9, 0.999), "eps": 1e-7}])
+    opt.zero_grad()
+    out = model.forward(ids, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]), torch.from_numpy(s["ref_img_ids"]))
+    loss = out["bank_loss"]
+    assert loss.dim() == 0 and loss.requires_grad
+    "{:05.3f}".format(loss)                                            # train_negplus.py:116-117
+    assert abs(loss.item() - float(s["loss_plus"])) < 1e-2 * max(1.0, abs(float(s["loss_plus"])))
+    (loss * 128.0).backward()                                          # GradScaler-style scaled loss
+    g = model.clip.text_projection.grad
+    ref = torch.from_numpy(s["grad_plus::text_projection"]) * 128.0
+    assert ((g.cpu() - ref).norm() / ref.norm()).item() < 5e-2
+    assert model.clip.logit_scale.grad is None and model.clip.visual.proj.grad is None
+    before = model.clip.text_projection.detach().clone()
+    for p in model.parameters():                                       # scaler.unscale_
+        if p.grad is not None:
+            p.grad = p.grad / 128.0
+    opt.step()
+    model.parameters_changed()
+    assert (model.clip.text_projection.detach() - before).abs().max() > 1e-5
+    loss2 = model.forward(ids, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]),
+                          torch.from_numpy(s["ref_img_ids"]))["bank_loss"]
+    assert loss2.item() < loss.item()                                  # one step on the same batch lowers the loss
+    # per-triplet reference rows (plus=False, models_negplus.py:135)
+    model2 = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=False)
+    model2.refer_bank = torch.from_numpy(s["trip_bank"])
+    model2.target_bank = torch.from_numpy(s["target_bank"])
+    l3 = model2.forward(ids, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]), torch.from_numpy(s["ref_img_ids"]))
+    assert abs(l3["bank_loss"].item() - float(s["loss_trip"])) < 1e-2 * max(1.0, abs(float(s["loss_trip"])))
+
+
+def test_checkpoint_roundtrip(golden_dir, tmp_path):
+    _need_gpu()
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    model = CIRPlus(sd, device=torch.device("cuda"))
+    ids = torch.from_numpy(z["ids"]).cuda()
+    f0 = model.encode_text(ids).clone()
+    path = str(tmp_path / "best.pt")
+    torch.save({"epoch": 0, "state_dict": model.state_dict()}, path)   # utils.save_model format (utils.py:53-67)
+    with torch.no_grad():
+        model.clip.text_projection.mul_(0.5)
+    model.parameters_changed()
+    assert (model.encode_text(ids) - f0).abs().max() > 1e-3
+    model.load_ckpt(path, is_origin=False)
+    assert torch.allclose(model.encode_text(ids), f0, atol=1e-6)
+    torch.save({"CLIP": sd}, str(tmp_path / "stage1.pt"))             # stage-1 format (models_negplus.py:54-55)
+    model.load_ckpt(str(tmp_path / "stage1.pt"), is_origin=True)
+    assert torch.allclose(model.encode_text(ids), f0, atol=1e-6)
+
+
+def test_trainer_steps_match_oracle():
+    """Three fused steps (fwd, bank loss, bwd, AdamW, bf16 refresh) vs the CPU oracle + torch AdamW."""
+    _need_gpu()
+    from oracle import bank_loss, clip_text
+    from spn4cir_amd import synthetic
+    from spn4cir_amd.models import CIRPlus
+    from spn4cir_amd.trainer import Stage2Trainer
+    W, layers, D, vocab, B, M, tau, lr = 128, 2, 128, 600, 16, 900, 0.03, 1e-3
+    sd = synthetic.text_state_dict(W, layers, D, vocab=vocab, seed=0)
+    target, refer = synthetic.banks(M, D)
+    ids = synthetic.token_ids(B, vocab=vocab, seed=1)
+    ridx, labels = synthetic.triplet_indices(B, M)
+    model = CIRPlus({k: v.clone() for k, v in sd.items()}, tau=tau, device=torch.device("cuda"), plus=True)
+    tr = Stage2Trainer(model, lr=lr)
+    tr.set_banks(refer, target)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW([{"params": list(params.values()), "lr": lr, "betas": (0.9, 0.999), "eps": 1e-7}])
+    for step in range(3):
+        loss = tr.step(ids.cuda(), ridx.cuda(), labels.cuda())
+        opt.zero_grad()
+        ref = bank_loss.bank_large_step(refer, ridx, clip_text.encode_text(params, ids), target, labels, tau)
+        ref.backward()
+        opt.step()
+        assert abs(loss.item() - ref.item()) < 2e-2 * max(1.0, abs(ref.item())), (step, loss.item(), ref.item())
+    views = model.tower.named_views()
+    for k in ("text_projection", "transformer.resblocks.0.mlp.c_fc.weight", "positional_embedding", "ln_final.weight"):
+        d = (views[k].cpu() - params[k].detach())
+        moved = (params[k].detach() - sd[k]).norm()
+        assert d.norm() < 0.15 * moved, (k, d.norm().item(), moved.item())    # same trajectory as the oracle
+
+
+class _StubModel:
+    """encode_text returns pre-made features in call order (the metric code only needs the protocol)."""
+
+    def __init__(self, feats, dim):
+        self.feats, self.output_dim, self.pos = feats, dim, 0
+
+    def encode_text(self, captions):
+        out = self.feats[self.pos:self.pos + len(captions)]
+        self.pos += len(captions)
+        return out
+
+
+def test_recall_metrics_match_reference(golden_dir):
+    _need_gpu()
+    from spn4cir_amd import validate
+    z = np.load(os.path.join(golden_dir, "recall.npz"))
+    names = json.loads(str(z["names"]))
+    members = json.loads(str(z["members"]))
+    gallery = torch.from_numpy(z["gallery"]).cuda()
+    text = torch.from_numpy(z["text_feats"]).cuda()
+    ref_idx, tgt_idx = z["ref_idx"], z["tgt_idx"]
+    fiq_rows = [(names[r], names[t], [f"cap a {i}.", f"cap b {i}?"]) for i, (r, t) in enumerate(zip(ref_idx, tgt_idx))]
+    r10, r50 = validate.compute_fiq_val_metrics(fiq_rows, _StubModel(text, 64), gallery, names)
+    assert (r10, r50) == pytest.approx(tuple(z["fiq"]), abs=1e-9)
+    cirr_rows = [(names[r], names[t], f"cap {i}", members[i]) for i, (r, t) in enumerate(zip(ref_idx, tgt_idx))]
+    cirr = validate.compute_cirr_val_metrics(cirr_rows, _StubModel(text, 64), gallery, names)
+    assert cirr == pytest.approx(tuple(z["cirr"]), abs=1e-4)
+    pred, _, _ = validate.generate_fiq_val_predictions(_StubModel(text, 64), fiq_rows, names, gallery)
+    assert np.allclose(pred.cpu().numpy(), z["pred"], atol=1e-6)
