@@ -166,9 +166,22 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         a.lse[((size_t)b * a.H + h) * a.Lq + qrow] = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
 }
 
+// SPN_ATTN_FLASH=1 forces the tiled (flash-style) kernels even where the whole-head ones apply
+static bool attn_force_flash() {
+    static const bool f = [] {
+        const char* e = getenv("SPN_ATTN_FLASH");
+        return e && e[0] == '1';
+    }();
+    return f;
+}
+
 int attention_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return SPN_ERR_ARG;
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return SPN_ERR_SHAPE;
+    if (attention_small_ok(a) && !attn_force_flash()) {
+        ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
+        return attention_small_fwd(a, st);
+    }
     {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         hipLaunchKernelGGL(attention_fwd_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, a);
@@ -384,6 +397,7 @@ int attention_bwd(const AttnBwdArgs& g, hipStream_t st) {
         return SPN_ERR_SHAPE;
     const int n = a.B * a.Lq * a.H;
     ProfScope prof(PK_ATTN_BWD, 10.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
+    if (attention_small_ok(a) && !attn_force_flash()) return attention_small_bwd(g, st);
     hipLaunchKernelGGL(attention_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)a.o, a.ldo, g.d_o,
                        g.lddo, g.delta, a.B, a.H, a.Lq);
     SPN_CHECK_LAUNCH();

@@ -138,13 +138,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
 }
 
 bool gemm_use_v1() {
-    // v1 (128x128 tile, 2 blocks/CU) measures faster than gemm2.hip on the K=768..3072 tower
-    // shapes; SPN_GEMM_V2=1 selects the 256x128 / 3-stage kernels (better at K >= 8192).
-    static const bool v1 = [] {
-        const char* e = getenv("SPN_GEMM_V2");
-        return !(e && e[0] == '1');
+    return gemm_cfg() == 0;
+}
+
+// SPN_GEMM_CFG: 0 = v1 kernels of this file (128x128, 2 blocks/CU); 1/2/3 = gemm2.hip tile configs
+int gemm_cfg() {
+    static const int cfg = [] {
+        const char* e = getenv("SPN_GEMM_CFG");
+        return e ? atoi(e) : 0;
     }();
-    return v1;
+    return cfg;
 }
 
 int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,

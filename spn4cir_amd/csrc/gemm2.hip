@@ -1,22 +1,23 @@
-// Second-generation bf16 MFMA GEMMs (gfx950): 256x128 output tile, 8 waves (4x2), wave tile
-// 64x64 = 2x2 v_mfma_f32_32x32x16_bf16, 64-deep K step, THREE LDS stages filled by
-// buffer_load...lds with a COUNTED s_waitcnt vmcnt so that one whole tile stays in flight across
-// the (raw) s_barrier: the prefetch distance is two K-steps, which covers HBM latency; the v1
-// kernels (gemm.hip) drain vmcnt(0) every step and are kept for A/B runs (SPN_GEMM_V1=1).
+// Tile-templated bf16 MFMA GEMMs (gfx950), second generation.
 //
 //   gemm_nt2 : C[M,N]  = epilogue(A[M,K] . B[N,K]^T)
-//   gemm_tn2 : C[N1,N2] = A[Kr,N1]^T . B[Kr,N2]  (+ optional column sums of A = bias gradient,
-//              obtained for free with an all-ones MFMA operand)
+//   gemm_tn2 : C[N1,N2] = A[Kr,N1]^T . B[Kr,N2]  (+ column sums of A = bias gradient from an
+//              all-ones MFMA operand)
+//
+// Template <BM, BN, WM, WN, STAGES>: BM x BN output tile per workgroup of WM x WN waves, each wave
+// a (BM/WM) x (BN/WN) sub-tile built from v_mfma_f32_32x32x16_bf16, 64-deep K step, STAGES LDS
+// buffers filled by buffer_load...lds.  With STAGES = 3 the wait is a COUNTED s_waitcnt vmcnt so one
+// whole tile stays in flight across the (raw) s_barrier.  Why bigger tiles: a 128x128x64 step moves
+// 32 KB of operands per 512 MFMA cycles per CU, which is about the L2->LDS bandwidth; 256x256x64
+// moves 64 KB per 2048 MFMA cycles.
+// The v1 kernels (gemm.hip: 128x128, 16x16x32 MFMA, 2 blocks/CU) remain selectable: SPN_GEMM_CFG=0.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
 
 namespace spn {
 
-static constexpr int BM2 = 256, BN2 = 128, BK2 = 64, NT2 = 512;
-static constexpr int A2_BYTES = 256 * 64 * 2, B2_BYTES = 128 * 64 * 2, STAGE2 = A2_BYTES + B2_BYTES;   // 48 KiB
-static constexpr int LDS2 = 3 * STAGE2;                                                                 // 144 KiB
-static constexpr int GLDS_PER_STAGE = 6;   // per wave: 4 (A) + 2 (B)
+static constexpr int BK2 = 64;
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -27,6 +28,11 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
     for (int e = 0; e < 16; ++e) z[e] = 0.f;
     return z;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // ----------------------------------------------------------------------------------- NT
@@ -50,71 +56,78 @@ __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * 128 + (nt2_swz(r, c) << 4));
 }
 
-template <int MODE, int ACT>
-__global__ __launch_bounds__(NT2, 2) void gemm_nt2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         int M, int N, int K, int lda, int ldb, GemmEpilogue ep) {
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
+                                                                            const bf16_t* __restrict__ B, int M,
+                                                                            int N, int K, int lda, int ldb,
+                                                                            GemmEpilogue ep) {
+    constexpr int NW = WM * WN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;      // DMA instructions per wave per stage
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    const int tiles_n = (N + BN2 - 1) / BN2;
+    const int wr = wid / WN, wc = wid % WN;
+    const int tiles_n = (N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM2, n0 = (bid % tiles_n) * BN2;
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+        for (int j = 0; j < NJ; ++j) acc[i][j] = zero16();
 
     const int nk = K / BK2;
     auto stage = [&](int kt, int buf) {
-        char* s = smem + buf * STAGE2;
-        nt2_stage<4>(rsA, s, m0, lda, kt * BK2, wid, lane);
-        nt2_stage<2>(rsB, s + A2_BYTES, n0, ldb, kt * BK2, wid, lane);
+        char* s = smem + buf * STAGE;
+        nt2_stage<GA>(rsA, s, m0, lda, kt * BK2, wid, lane);
+        nt2_stage<GB>(rsB, s + A_BYTES, n0, ldb, kt * BK2, wid, lane);
     };
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int cur = 0, nxt2 = 2;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage(s, s);
+    int cur = 0, fill = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the newest stage (6 DMA per wave) is still outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile kt has landed once at most the (STAGES-2) newer stages are still outstanding
+        if (STAGES >= 3 && kt + 1 < nk) wait_vmcnt<(STAGES - 2) * (GA + GB)>();
+        else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done with tile kt-1
-        if (kt + 2 < nk) stage(kt + 2, nxt2);
-        const char* sA = smem + cur * STAGE2;
-        const char* sB = sA + A2_BYTES;
+        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, fill);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int c = kk * 2 + (lane >> 5);
-            bf16x8 a[2], b[2];
+            bf16x8 a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = nt2_frag(sA, wr * 64 + i * 32 + (lane & 31), c);
-                b[i] = nt2_frag(sB, wc * 64 + i * 32 + (lane & 31), c);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = nt2_frag(sA, wr * TM + i * 32 + (lane & 31), c);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag(sB, wc * TN + j * 32 + (lane & 31), c);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
         }
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+        fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
 
     // (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3, the 4
     // consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wr * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wr * TM + i * 32 + (lane & 31);
         if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = n0 + wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
                 if (n >= N) continue;
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 v *= ep.alpha;
@@ -149,19 +162,44 @@ __global__ __launch_bounds__(NT2, 2) void gemm_nt2_kernel(const bf16_t* __restri
     }
 }
 
-template <int MODE, int ACT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT>
 static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
-                      int tiles, hipStream_t st) {
-    auto kern = gemm_nt2_kernel<MODE, ACT>;
+                      hipStream_t st) {
+    constexpr int LDS = STAGES * (BM + BN) * 128;
+    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT2), LDS2, st, A, B, M, N, K, lda, ldb, ep);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, st, A, B, M, N, K, lda, ldb, ep);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
+                        const GemmEpilogue& ep, hipStream_t st) {
+#define SPN_NT2(MODE_, ACT_) launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_>(A, B, M, N, K, lda, ldb, ep, st)
+    if (mode == GEMM_STORE) {
+        if (ep.act == ACT_NONE) return SPN_NT2(GEMM_STORE, ACT_NONE);
+        if (ep.act == ACT_QUICKGELU) return SPN_NT2(GEMM_STORE, ACT_QUICKGELU);
+        if (ep.act == ACT_GELU_ERF) return SPN_NT2(GEMM_STORE, ACT_GELU_ERF);
+        return SPN_ERR_ARG;
+    }
+    if (mode == GEMM_RESID) {
+        if (!ep.resid || !ep.out_f32) return SPN_ERR_ARG;
+        return SPN_NT2(GEMM_RESID, ACT_NONE);
+    }
+    if (mode == GEMM_DACT) {
+        if (!ep.aux_in) return SPN_ERR_ARG;
+        if (ep.act == ACT_QUICKGELU) return SPN_NT2(GEMM_DACT, ACT_QUICKGELU);
+        if (ep.act == ACT_GELU_ERF) return SPN_NT2(GEMM_DACT, ACT_GELU_ERF);
+    }
+#undef SPN_NT2
+    return SPN_ERR_ARG;
 }
 
 int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode, const GemmEpilogue& ep,
@@ -170,36 +208,23 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     if (K % BK2 || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
-    const int tiles = ((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
-    if (mode == GEMM_STORE) {
-        if (ep.act == ACT_NONE) return launch_nt2<GEMM_STORE, ACT_NONE>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-        if (ep.act == ACT_QUICKGELU) return launch_nt2<GEMM_STORE, ACT_QUICKGELU>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-        if (ep.act == ACT_GELU_ERF) return launch_nt2<GEMM_STORE, ACT_GELU_ERF>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-        return SPN_ERR_ARG;
+    switch (gemm_cfg()) {
+        case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, ep, st);
+        case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, ep, st);
+        default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, ep, st);
     }
-    if (mode == GEMM_RESID) {
-        if (!ep.resid || !ep.out_f32) return SPN_ERR_ARG;
-        return launch_nt2<GEMM_RESID, ACT_NONE>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-    }
-    if (mode == GEMM_DACT) {
-        if (!ep.aux_in) return SPN_ERR_ARG;
-        if (ep.act == ACT_QUICKGELU) return launch_nt2<GEMM_DACT, ACT_QUICKGELU>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-        if (ep.act == ACT_GELU_ERF) return launch_nt2<GEMM_DACT, ACT_GELU_ERF>(A, B, M, N, K, lda, ldb, ep, tiles, st);
-    }
-    return SPN_ERR_ARG;
 }
 
 // ----------------------------------------------------------------------------------- TN
-// LDS image of a [64 k][COLS] bf16 tile (COLS = 256 for A, 128 for B): row k at byte k*2*COLS;
-// the 32-byte chunk holding logical columns 16c..16c+15 sits at chunk position c ^ ((k&3)<<1):
-// the two 16-lane groups of a half-wave read chunks c, c+1 of rows k0..k0+3 -> 8 distinct
-// 32-byte bank groups.
+// LDS image of a [64 k][COLS] bf16 tile: row k at byte k*2*COLS; the 32-byte chunk holding logical
+// columns 16c..16c+15 sits at chunk position c ^ ((k&3)<<1): the two 16-lane groups of a half-wave
+// read chunks c, c+1 of rows k0..k0+3 -> 8 distinct 32-byte bank groups.
 template <int COLS, int PER_WAVE>
 __device__ __forceinline__ void tn2_stage(__amdgpu_buffer_rsrc_t rs, char* sT, int kbase, int ld, int col0, int wid,
                                           int lane) {
     constexpr int ROWB = COLS * 2;
-    constexpr int ROWS_PER_INSTR = 1024 / ROWB;        // 2 (A) or 4 (B)
+    constexpr int ROWS_PER_INSTR = 1024 / ROWB;        // 2 (256 cols) or 4 (128 cols)
     constexpr int LANES_PER_ROW = 64 / ROWS_PER_INSTR;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
@@ -229,28 +254,35 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* sT, int cb, int kk, int l
     return u.v;
 }
 
-__global__ __launch_bounds__(NT2, 2) void gemm_tn2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         int Kr, int N1, int N2, int lda, int ldb,
-                                                         float* __restrict__ C, int ldc, size_t split_stride,
-                                                         int k_chunk, float* __restrict__ colsum_out) {
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A,
+                                                                            const bf16_t* __restrict__ B, int Kr,
+                                                                            int N1, int N2, int lda, int ldb,
+                                                                            float* __restrict__ C, int ldc,
+                                                                            size_t split_stride, int k_chunk,
+                                                                            float* __restrict__ colsum_out) {
+    constexpr int NW = WM * WN;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
-    const int tiles_n = (N2 + BN2 - 1) / BN2;
+    const int wr = wid / WN, wc = wid % WN;
+    const int tiles_n = (N2 + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM2, n0 = (bid % tiles_n) * BN2;
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const int kb = blockIdx.y * k_chunk;
     const int ke = min(Kr, kb + k_chunk);
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)Kr * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)Kr * (uint32_t)ldb * 2u);
     const bool do_colsum = colsum_out != nullptr && n0 == 0 && wc == 0;
 
-    f32x16 acc[2][2], accs[2];
+    f32x16 acc[MI][NJ], accs[MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
         accs[i] = zero16();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+        for (int j = 0; j < NJ; ++j) acc[i][j] = zero16();
     }
     bf16x8 ones;
 #pragma unroll
@@ -258,51 +290,51 @@ __global__ __launch_bounds__(NT2, 2) void gemm_tn2_kernel(const bf16_t* __restri
 
     const int nk = (ke - kb + BK2 - 1) / BK2;
     auto stage = [&](int kt, int buf) {
-        char* s = smem + buf * STAGE2;
-        tn2_stage<256, 4>(rsA, s, kb + kt * BK2, lda, m0, wid, lane);
-        tn2_stage<128, 2>(rsB, s + A2_BYTES, kb + kt * BK2, ldb, n0, wid, lane);
+        char* s = smem + buf * STAGE;
+        tn2_stage<BM, GA>(rsA, s, kb + kt * BK2, lda, m0, wid, lane);
+        tn2_stage<BN, GB>(rsB, s + A_BYTES, kb + kt * BK2, ldb, n0, wid, lane);
     };
-    if (nk > 0) stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int cur = 0, nxt2 = 2;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage(s, s);
+    int cur = 0, fill = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAGES >= 3 && kt + 1 < nk) wait_vmcnt<(STAGES - 2) * (GA + GB)>();
+        else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage(kt + 2, nxt2);
-        const char* sA = smem + cur * STAGE2;
-        const char* sB = sA + A2_BYTES;
+        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, fill);
+        const char* sA = smem + cur * STAGE;
+        const char* sB = sA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = tn2_frag<256>(sA, wr * 64 + i * 32, kk, lane);
-                b[i] = tn2_frag<128>(sB, wc * 64 + i * 32, kk, lane);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = tn2_frag<BM>(sA, wr * TM + i * 32, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NJ; ++j) b[j] = tn2_frag<BN>(sB, wc * TN + j * 32, kk, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
             if (do_colsum) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accs[i] = mfma32(ones, a[i], accs[i]);
+                for (int i = 0; i < MI; ++i) accs[i] = mfma32(ones, a[i], accs[i]);
             }
         }
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        cur = cur == STAGES - 1 ? 0 : cur + 1;
+        fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
     float* Cz = C + (size_t)blockIdx.y * split_stride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wr * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wr * TM + i * 32 + (lane & 31);
         if (m >= N1) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = n0 + wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
                 if (n >= N2) continue;
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 *(f32x4*)(Cz + (size_t)m * ldc + n) = v;
@@ -327,19 +359,44 @@ __global__ void splitk_reduce2_kernel(const float* __restrict__ ws, int splits, 
     }
 }
 
-static int tn2_splits(int Kr, int N1, int N2) {
-    const int tiles = ((N1 + BM2 - 1) / BM2) * ((N2 + BN2 - 1) / BN2);
+static int tn2_splits(int Kr, int N1, int N2, int BM, int BN) {
+    const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
     const int ktiles = (Kr + BK2 - 1) / BK2;
     int s = 256 / tiles;
     if (s < 1) s = 1;
-    const int max_s = (ktiles + 5) / 6;   // >= ~6 k-tiles per split keeps the 3-stage pipe busy
+    const int max_s = (ktiles + 5) / 6;   // >= ~6 k-tiles per split keeps the pipe busy
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
 }
 
+static void tn2_tile(int* BM, int* BN) {
+    if (gemm_cfg() == 1) { *BM = 256; *BN = 128; }
+    else { *BM = 256; *BN = 256; }
+}
+
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2) {
-    const int s = tn2_splits(Kr, N1, N2);
+    // the largest split count over the configurations (bigger tiles -> fewer tiles -> more splits)
+    const int s1 = tn2_splits(Kr, N1, N2, 256, 128), s2 = tn2_splits(Kr, N1, N2, 256, 256);
+    const int s = s1 > s2 ? s1 : s2;
     return ((size_t)s * N1 * N2 + (size_t)s * N1) * sizeof(float);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* ws, int splits,
+                      int k_chunk, float* cs_ws, hipStream_t st) {
+    constexpr int LDS = STAGES * (BM + BN) * 128;
+    auto kern = gemm_tn2_kernel<BM, BN, WM, WN, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(WM * WN * 64), LDS, st, A, B, Kr, N1, N2, lda, ldb, ws, N2,
+                       (size_t)N1 * N2, k_chunk, cs_ws);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
 }
 
 // colsum_out (optional, [N1]): column sums of A over all Kr rows (overwritten)
@@ -349,24 +406,23 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
     if (N1 % 8 || N2 % 8 || lda % 8 || ldb % 8 || ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)Kr * lda * 2 >= (1ull << 32) || (uint64_t)Kr * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (ws_bytes < gemm_tn2_workspace_bytes(Kr, N1, N2)) return SPN_ERR_WORKSPACE;
-    const int tiles = ((N1 + BM2 - 1) / BM2) * ((N2 + BN2 - 1) / BN2);
-    int splits = tn2_splits(Kr, N1, N2);
+    int BM, BN;
+    tn2_tile(&BM, &BN);
+    int splits = tn2_splits(Kr, N1, N2, BM, BN);
     const int ktiles = (Kr + BK2 - 1) / BK2;
     const int k_chunk = ((ktiles + splits - 1) / splits) * BK2;
     splits = (Kr + k_chunk - 1) / k_chunk;
     float* cs_ws = colsum_out ? ws + (size_t)splits * N1 * N2 : nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    int rc;
     {
         ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
-        hipLaunchKernelGGL(gemm_tn2_kernel, dim3(tiles, splits), dim3(NT2), LDS2, st, A, B, Kr, N1, N2, lda, ldb, ws, N2,
-                           (size_t)N1 * N2, k_chunk, cs_ws);
+        switch (gemm_cfg()) {
+            case 1: rc = launch_tn2<256, 128, 4, 2, 3>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
+            case 3: rc = launch_tn2<256, 256, 2, 4, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
+            default: rc = launch_tn2<256, 256, 4, 2, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
+        }
     }
-    SPN_CHECK_LAUNCH();
+    if (rc) return rc;
     const size_t total = (size_t)N1 * (N2 / 4);
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha, accumulate);

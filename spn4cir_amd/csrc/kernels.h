@@ -35,6 +35,7 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
              float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
 bool gemm_use_v1();
+int gemm_cfg();
 
 // elementwise.hip
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
@@ -82,6 +83,10 @@ struct AttnBwdArgs {
 };
 int attention_fwd(const AttnArgs& a, hipStream_t st);
 int attention_bwd(const AttnBwdArgs& a, hipStream_t st);
+// attention_small.hip: whole-head kernels for Lq == Lk <= 128 (attention_fwd/bwd dispatch to them)
+bool attention_small_ok(const AttnArgs& a);
+int attention_small_fwd(const AttnArgs& a, hipStream_t st);
+int attention_small_bwd(const AttnBwdArgs& a, hipStream_t st);
 
 // bank.hip
 int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
