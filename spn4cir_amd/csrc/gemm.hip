@@ -141,11 +141,11 @@ bool gemm_use_v1() {
     return gemm_cfg() == 0;
 }
 
-// SPN_GEMM_CFG: 0 = v1 kernels of this file (128x128, 2 blocks/CU); 1/2/3 = gemm2.hip tile configs
+// SPN_GEMM_CFG: 0 = v1 kernels of this file (128x128, 2 blocks/CU); 1/2/3 = gemm2.hip tile configs (default 3)
 int gemm_cfg() {
     static const int cfg = [] {
         const char* e = getenv("SPN_GEMM_CFG");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 3;   // measured best on the tower shapes: 256x256 tile, staged epilogue
     }();
     return cfg;
 }
@@ -332,7 +332,8 @@ size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2) {
 
 int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
             float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st) {
-    if (!gemm_use_v1())
+    // small outputs (e.g. 768x768) give the 256x256 tiling too few workgroups: v1 (128x128) is faster there
+    if (!gemm_use_v1() && (size_t)N1 * N2 >= (size_t)768 * 2304)
         return gemm_tn2(A, B, Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, colsum_out, ws, ws_bytes, st);
     if (Kr <= 0 || N1 <= 0 || N2 <= 0) return SPN_ERR_ARG;
     if (N1 % 8 || N2 % 8 || lda % 8 || ldb % 8 || ldc % 4) return SPN_ERR_SHAPE;

@@ -52,11 +52,21 @@ __device__ __forceinline__ void nt2_stage(__amdgpu_buffer_rsrc_t rs, char* sT, i
     }
 }
 
+// DMA instruction i (of PER_WAVE) of this wave only: lets the main loop spread a stage over its k steps
+template <int PER_WAVE>
+__device__ __forceinline__ void nt2_stage_one(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0, int wid,
+                                              int lane, int i) {
+    const int R0 = (wid * PER_WAVE + i) * 8;
+    const int r = R0 + (lane >> 3);
+    const int c = nt2_swz(r, lane & 7);
+    glds16(rs, sT + R0 * 128, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
+}
+
 __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * 128 + (nt2_swz(r, c) << 4));
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M,
                                                                             int N, int K, int lda, int ldb,
@@ -97,7 +107,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done with tile kt-1
-        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, fill);
+        // The DMA of tile kt+STAGES-1 is spread over the four k16 steps (after each step's LDS reads,
+        // before its MFMAs) instead of being issued as one burst behind the barrier, where both waves
+        // of a SIMD would stall the matrix pipe together.
+        const bool do_stage = kt + STAGES - 1 < nk;
+        char* sF = smem + fill * STAGE;
+        const int kf = (kt + STAGES - 1) * BK2;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_BYTES;
 #pragma unroll
@@ -108,17 +123,96 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             for (int i = 0; i < MI; ++i) a[i] = nt2_frag(sA, wr * TM + i * 32 + (lane & 31), c);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) b[j] = nt2_frag(sB, wc * TN + j * 32 + (lane & 31), c);
+            if (SPREAD) {
+                if (do_stage) {
+#pragma unroll
+                    for (int q = kk * ((GA + 3) / 4); q < (kk + 1) * ((GA + 3) / 4) && q < GA; ++q)
+                        nt2_stage_one<GA>(rsA, sF, m0, lda, kf, wid, lane, q);
+#pragma unroll
+                    for (int q = kk * ((GB + 3) / 4); q < (kk + 1) * ((GB + 3) / 4) && q < GB; ++q)
+                        nt2_stage_one<GB>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (kk == 0 && do_stage) {
+                stage(kt + STAGES - 1, fill);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
+            if (SPREAD) __builtin_amdgcn_sched_barrier(0);
         }
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
 
-    // (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3, the 4
+    // Epilogue.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3, the 4
     // consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
+    // Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
+    // first staged through LDS (fp32, 16-B units XOR-swizzled by row) and the epilogue math + all
+    // global traffic run row-major: one wave instruction = one or two whole rows, fully coalesced.
+    if (!ep.direct_store) {
+        constexpr int LDS_BYTES = STAGES * STAGE;
+        constexpr int CR0 = LDS_BYTES / (BN * 4);
+        constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;     // rows per staging pass
+        constexpr int NCH = (BM + CHUNK - 1) / CHUNK;
+        constexpr int LPR = BN / 4, RPI = 64 / LPR;                 // lanes per row, rows per wave instruction
+        static_assert(LPR <= 64 && 64 % LPR == 0, "row mapping");
+        float* sC = (float*)smem;
+        const int u = lane % LPR, n = n0 + u * 4;
+        f32x4 bias4 = {0, 0, 0, 0};
+        if (ep.bias && n < N) bias4 = *(const f32x4*)(ep.bias + n);
+        for (int ch = 0; ch < NCH; ++ch) {
+            __syncthreads();   // operand tiles (or the previous chunk) are no longer read
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int rl = wr * TM + i * 32 + (lane & 31);
+                if (rl / CHUNK != ch) continue;
+                const int r = rl - ch * CHUNK;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *(f32x4*)(sC + r * BN + ((unit ^ (r & 15)) << 2)) = v;
+                    }
+            }
+            __syncthreads();
+            for (int rr = wid * RPI + lane / LPR; rr < CHUNK; rr += NW * RPI) {
+                const int m = m0 + ch * CHUNK + rr;
+                if (m >= M || n >= N) continue;
+                f32x4 v = *(const f32x4*)(sC + rr * BN + ((u ^ (rr & 15)) << 2));
+                v = v * ep.alpha + bias4;
+                const size_t o = (size_t)m * ep.ldc + n;
+                if constexpr (MODE == GEMM_STORE) {
+                    if constexpr (ACT != ACT_NONE) {
+                        if (ep.aux_out) {
+                            bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                            *(bf16x4*)(ep.aux_out + o) = p;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                    }
+                } else if constexpr (MODE == GEMM_RESID) {
+                    v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
+                } else if constexpr (MODE == GEMM_DACT) {
+                    const bf16x4 p = *(const bf16x4*)(ep.aux_in + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = bf2f(p[e]);
+                        v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                    }
+                }
+                if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
+                if (ep.out_bf16) {
+                    bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *(bf16x4*)(ep.out_bf16 + o) = p;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wr * TM + i * 32 + (lane & 31);
@@ -162,11 +256,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD>
 static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
                       hipStream_t st) {
     constexpr int LDS = STAGES * (BM + BN) * 128;
-    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT>;
+    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT, SPREAD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -179,10 +273,20 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     return SPN_OK;
 }
 
+static bool gemm_spread() {
+    static const bool v = [] {
+        const char* e = getenv("SPN_GEMM_SPREAD");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES>
 static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
                         const GemmEpilogue& ep, hipStream_t st) {
-#define SPN_NT2(MODE_, ACT_) launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_>(A, B, M, N, K, lda, ldb, ep, st)
+#define SPN_NT2(MODE_, ACT_)                                                                       \
+    (gemm_spread() ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, true>(A, B, M, N, K, lda, ldb, ep, st) \
+                   : launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, false>(A, B, M, N, K, lda, ldb, ep, st))
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) return SPN_NT2(GEMM_STORE, ACT_NONE);
         if (ep.act == ACT_QUICKGELU) return SPN_NT2(GEMM_STORE, ACT_QUICKGELU);
@@ -208,11 +312,17 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     if (K % BK2 || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
+    static const int direct = [] {
+        const char* e = getenv("SPN_GEMM_EPI_DIRECT");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    GemmEpilogue e2 = ep;
+    e2.direct_store = direct;
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
     switch (gemm_cfg()) {
-        case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, ep, st);
-        case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, ep, st);
-        default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, ep, st);
+        case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
     }
 }
 

@@ -19,6 +19,7 @@ struct GemmEpilogue {
     int ldr = 0;
     int act = ACT_NONE;
     float alpha = 1.0f;
+    int direct_store = 0;            // gemm2 only: 1 = store from the MFMA layout (no LDS staging)
 };
 
 // gemm.hip
