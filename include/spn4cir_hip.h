@@ -167,6 +167,27 @@ int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void*
 int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- CLIP vision tower (inference)
+ * VisionTransformer.forward (clip/model.py:223-242): frozen in stage 2, used by the bank builders
+ * (models_negplus.py:59-125) and extract_index_features (utils.py:24-50).  image: fp32 [B,3,res,res]
+ * (already preprocessed); feats: fp32 [B, D] un-normalised.  Flat fp32 parameters per
+ * spn_vision_layout(); bf16 mirrors written by spn_vision_refresh_bf16() (once: the tower is frozen). */
+typedef struct {
+    int B, res, patch, W, H, layers, D;
+} spn_vision_cfg;
+
+typedef struct {
+    int64_t conv1, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, n_params;
+    int64_t block_off[13];
+    int64_t bf16_conv1, bf16_blocks, bf16_block_size, bf16_proj_t, n_bf16, kp, seq;
+} spn_vision_layout_t;
+
+int spn_vision_layout(const spn_vision_cfg* cfg, spn_vision_layout_t* out);
+size_t spn_vision_ws_bytes(const spn_vision_cfg* cfg);
+int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void* weights_bf16, void* stream);
+int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
+                   void* ws, size_t ws_bytes, float* feats, void* stream);
+
 /* ---------------------------------------------------------------- opt-in kernel timing
  * HIP events recorded on the launch stream around the main kernels (bench.py's live roofline).
  * The only process-global state in the library; off unless spn_prof_enable() is called.

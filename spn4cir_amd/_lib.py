@@ -26,6 +26,18 @@ class TextLayout(C.Structure):
                [(n, C.c_int64) for n in ("bf16_block_size", "bf16_text_proj", "bf16_text_proj_t", "n_bf16")]
 
 
+class VisionCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "res", "patch", "W", "H", "layers", "D")]
+
+
+class VisionLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("conv1", "cls", "pos", "ln_pre_g", "ln_pre_b", "blocks", "block_size",
+                                         "ln_post_g", "ln_post_b", "proj", "n_params")] + \
+               [("block_off", C.c_int64 * 13)] + \
+               [(n, C.c_int64) for n in ("bf16_conv1", "bf16_blocks", "bf16_block_size", "bf16_proj_t", "n_bf16", "kp",
+                                         "seq")]
+
+
 _SIGS = {
     "spn_abi_version": (i32, []),
     "spn_error_string": (C.c_char_p, [i32]),
@@ -65,6 +77,10 @@ _SIGS = {
     "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
     "spn_text_bwd_tail": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),
+    "spn_vision_layout": (i32, [C.POINTER(VisionCfg), C.POINTER(VisionLayout)]),
+    "spn_vision_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
+    "spn_vision_refresh_bf16": (i32, [C.POINTER(VisionCfg), vp, vp, vp]),
+    "spn_vision_fwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, sz, vp, vp]),
     "spn_prof_enable": (i32, [i32]),
     "spn_prof_disable": (i32, []),
     "spn_prof_reset": (i32, []),

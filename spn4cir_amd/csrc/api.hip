@@ -219,6 +219,34 @@ int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weigh
                     ST(stream));
 }
 
+static_assert(sizeof(spn_vision_cfg) == sizeof(VisionCfg), "spn_vision_cfg layout");
+static_assert(sizeof(spn_vision_layout_t) == sizeof(VisionLayout), "spn_vision_layout_t layout");
+
+static VisionCfg vc(const spn_vision_cfg* c) {
+    VisionCfg v;
+    v.B = c->B; v.res = c->res; v.patch = c->patch; v.W = c->W; v.H = c->H; v.layers = c->layers; v.D = c->D;
+    return v;
+}
+
+int spn_vision_layout(const spn_vision_cfg* cfg, spn_vision_layout_t* out) {
+    if (!cfg || !out) return SPN_ERR_ARG;
+    vision_layout(vc(cfg), reinterpret_cast<VisionLayout*>(out));
+    return SPN_OK;
+}
+
+size_t spn_vision_ws_bytes(const spn_vision_cfg* cfg) { return cfg ? vision_ws_bytes(vc(cfg)) : 0; }
+
+int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void* weights_bf16, void* stream) {
+    if (!cfg || !params || !weights_bf16) return SPN_ERR_ARG;
+    return vision_refresh_bf16(vc(cfg), params, BF(weights_bf16), ST(stream));
+}
+
+int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
+                   void* ws, size_t ws_bytes, float* feats, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !image || !ws || !feats) return SPN_ERR_ARG;
+    return vision_fwd(vc(cfg), params, CBF(weights_bf16), image, (char*)ws, ws_bytes, feats, ST(stream));
+}
+
 int spn_text_bwd_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
                       const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream) {
     if (!cfg || !params || !weights_bf16 || !acts || !dfeats || !grads || !ws) return SPN_ERR_ARG;

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import ops
 from .text_tower import TextTower, text_cfg_from_state_dict
+from .vision_tower import VisionTower, vision_cfg_from_state_dict
 
 
 class _BankStep(torch.autograd.Function):
@@ -77,9 +78,20 @@ class CIRPlus(nn.Module):
             self._params[key] = p
         self.clip.register_parameter("logit_scale", nn.Parameter(
             sd.get("logit_scale", torch.tensor(2.6592)).to(self.device, torch.float32).reshape(())))
-        self._visual_sd = {k: v.to(self.device) for k, v in sd.items() if k.startswith("visual.")}
-        for k, v in self._visual_sd.items():       # frozen image tower (models_negplus.py:27-28)
-            _attach(self.clip, k, nn.Parameter(v.float(), requires_grad=False))
+        # frozen image tower (models_negplus.py:27-28): ViT towers run on the HIP kernels; a ModifiedResNet
+        # tower (RN50x4, the argparse default) keeps its weights in the state-dict but cannot encode images
+        self.vision = None
+        if "visual.proj" in sd and "visual.conv1.weight" in sd:
+            vcfg = vision_cfg_from_state_dict(sd)
+            self.vision = VisionTower(vcfg["width"], vcfg["layers"], vcfg["heads"], vcfg["patch"], vcfg["res"],
+                                      vcfg["embed_dim"], self.device)
+            self.vision.load_clip_state_dict(sd)
+            for key, view in self.vision.named_views().items():
+                _attach(self.clip, "visual." + key, nn.Parameter(view, requires_grad=False))
+        else:
+            for k, v in sd.items():
+                if k.startswith("visual."):
+                    _attach(self.clip, k, nn.Parameter(v.to(self.device).float(), requires_grad=False))
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.combining_function = self.element_wise_sum
         self.tau = tau
@@ -148,6 +160,72 @@ class CIRPlus(nn.Module):
     def load_refer_bank(self, bank_path):
         self.refer_bank = torch.load(bank_path)
 
+    # Bank builders (models_negplus.py:59-125).  `dataset` is duck-typed like the reference's CIRDataset in
+    # 'relative' train mode: len(), `.image_id` (number of unique images) and items
+    # (reference_image, caption, target_image, index, target_index, reference_index_all, target_index_all)
+    # with images already preprocessed to fp32 [3, res, res]; 'unlabeled' mode yields single images.
+    @staticmethod
+    def _image_batches(dataset, bs=32):
+        n = len(dataset)
+        for s in range(0, n, bs):
+            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
+            if items:
+                yield items
+
+    def extract_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """models_negplus.py:59-80: per-triplet raw reference features + normalised unique-image target bank."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            self.refer_bank, self.target_bank = torch.load(bank_path)
+            return
+        refer = torch.zeros(len(cirDataset), self.output_dim)
+        target = torch.zeros(cirDataset.image_id, self.output_dim)
+        for items in self._image_batches(cirDataset):
+            ref = self.encode_image(torch.stack([it[0] for it in items]))
+            tgt = self.encode_image(torch.stack([it[2] for it in items]))
+            index = torch.tensor([int(it[3]) for it in items])
+            ref_all = torch.tensor([int(it[5]) for it in items])
+            tgt_all = torch.tensor([int(it[6]) for it in items])
+            refer[index] = ref.cpu()
+            target[ref_all] = ops.combine_l2norm_fwd(None, None, ref)[0].cpu()
+            target[tgt_all] = ops.combine_l2norm_fwd(None, None, tgt)[0].cpu()
+        self.refer_bank, self.target_bank = refer, target
+        if bank_path:
+            torch.save([refer, target], bank_path)
+
+    def extract_refer_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """models_negplus.py:82-98: raw features per unique image id, kept on the device."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            return
+        refer = torch.zeros(cirDataset.image_id, self.output_dim, device=self.device)
+        for items in self._image_batches(cirDataset):
+            ref_all = torch.tensor([int(it[5]) for it in items], device=self.device)
+            tgt_all = torch.tensor([int(it[6]) for it in items], device=self.device)
+            refer[ref_all] = self.encode_image(torch.stack([it[0] for it in items]))
+            refer[tgt_all] = self.encode_image(torch.stack([it[2] for it in items]))
+        self.refer_bank = refer
+        if bank_path:
+            torch.save(refer, bank_path)
+
+    def extract_unlabeled_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """models_negplus.py:100-125: normalised features of images outside every triplet, appended after the
+        labelled rows (self.M = number of labelled rows); neg_num > 0 keeps the first neg_num of them."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            unl = torch.load(bank_path)[0]
+        else:
+            feats = []
+            for items in self._image_batches(cirDataset):
+                f = self.encode_image(torch.stack(list(items)))
+                feats.append(ops.combine_l2norm_fwd(None, None, f)[0].cpu())
+            unl = torch.cat(feats) if feats else torch.zeros(0, self.output_dim)
+            if bank_path:
+                torch.save([unl], bank_path)
+        if self.neg_num > 0:
+            unl = unl[:self.neg_num, :]
+        self.unlabeled_target_bank = unl
+        self.M = self.target_bank.shape[0]
+        self.target_bank = torch.cat([self.target_bank, unl])
+
     # -------------------------------------------------------------------------- encoders
     def tokenize(self, text):
         if torch.is_tensor(text):
@@ -155,6 +233,13 @@ class CIRPlus(nn.Module):
         if self.tokenizer is None:
             raise RuntimeError("no tokenizer configured: pass pre-tokenised int32 ids or CIRPlus(tokenizer=...)")
         return self.tokenizer(text).to(self.device, torch.int32).contiguous()
+
+    def encode_image(self, image):
+        """fp32 [B, 3, res, res] -> un-normalised image features [B, D] (models_negplus.py:39-41)."""
+        if self.vision is None:
+            raise RuntimeError("this checkpoint has no ViT image tower (ModifiedResNet towers are not implemented)")
+        with torch.no_grad():
+            return self.vision.forward(image)
 
     def encode_text(self, text):
         """list[str] (or pre-tokenised ids) -> un-normalised text features [B, D] (models_negplus.py:43-46)."""

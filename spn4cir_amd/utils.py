@@ -1,0 +1,39 @@
+"""Helpers the reference's scripts import from clip4cir/utils.py."""
+from pathlib import Path
+
+import torch
+
+
+def extract_index_features(dataset, model, device=torch.device("cuda")):
+    """utils.py:24-50: (names, images) items of a 'classic' dataset -> (features [N, D], names)."""
+    feats, names = [], []
+    n = len(dataset)
+    for s in range(0, n, 32):
+        items = [dataset[i] for i in range(s, min(n, s + 32))]
+        items = [it for it in items if it is not None]
+        if not items:
+            continue
+        names.extend(it[0] for it in items)
+        feats.append(model.encode_image(torch.stack([it[1] for it in items])))
+    return torch.vstack(feats), names
+
+
+def save_model(name, cur_epoch, model_to_save, training_path):
+    """utils.py:53-67: {'epoch', 'state_dict'} at <training_path>/<name>.pt"""
+    path = Path(training_path)
+    path.mkdir(exist_ok=True, parents=True)
+    torch.save({"epoch": cur_epoch, "state_dict": model_to_save.state_dict()}, str(path / f"{name}.pt"))
+
+
+class RunningAverage:
+    """utils.py:70-91."""
+
+    def __init__(self):
+        self.steps, self.total = 0, 0
+
+    def update(self, val):
+        self.total += val
+        self.steps += 1
+
+    def __call__(self):
+        return self.total / float(self.steps)

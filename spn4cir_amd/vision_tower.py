@@ -1,0 +1,87 @@
+"""Host side of the frozen CLIP image tower (VisionTransformer, clip4cir/clip/model.py:206-242).
+
+Inference only: stage 2 never trains it (models_negplus.py:27-28).  Parameters live in one flat fp32
+buffer (layout spn_vision_layout); the bf16 GEMM operands are derived once."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .ops import _p, _stream
+from .text_tower import _BLOCK_KEYS
+
+
+def vision_cfg_from_state_dict(sd, prefix="visual."):
+    """clip4cir/clip/model.py:404-411."""
+    width = sd[prefix + "conv1.weight"].shape[0]
+    patch = sd[prefix + "conv1.weight"].shape[-1]
+    grid = round((sd[prefix + "positional_embedding"].shape[0] - 1) ** 0.5)
+    layers = len([k for k in sd if k.startswith(prefix) and k.endswith(".attn.in_proj_weight")])
+    return dict(width=width, patch=patch, res=patch * grid, layers=layers, heads=width // 64,
+                embed_dim=sd[prefix + "proj"].shape[1])
+
+
+class VisionTower:
+    def __init__(self, width, layers, heads, patch, res, embed_dim, device="cuda"):
+        if heads * 64 != width:
+            raise ValueError("CLIP ViT towers use head_dim 64 (clip/model.py:262)")
+        self.width, self.layers, self.heads = width, layers, heads
+        self.patch, self.res, self.embed_dim = patch, res, embed_dim
+        self.device = torch.device(device)
+        self._lay = _lib.VisionLayout()
+        check(lib().spn_vision_layout(C.byref(self._cfg(1)), C.byref(self._lay)), "vision_layout")
+        self.params = torch.zeros(int(self._lay.n_params), dtype=torch.float32, device=self.device)
+        self.wbf16 = torch.zeros(int(self._lay.n_bf16), dtype=torch.bfloat16, device=self.device)
+        self._ws = None
+        self._stale = True
+
+    def _cfg(self, B):
+        return _lib.VisionCfg(B, self.res, self.patch, self.width, self.heads, self.layers, self.embed_dim)
+
+    def spans(self):
+        lay, W, D, p = self._lay, self.width, self.embed_dim, self.patch
+        out = [("conv1.weight", lay.conv1, (W, 3, p, p)), ("class_embedding", lay.cls, (W,)),
+               ("positional_embedding", lay.pos, (int(lay.seq), W)), ("ln_pre.weight", lay.ln_pre_g, (W,)),
+               ("ln_pre.bias", lay.ln_pre_b, (W,))]
+        shapes = [(W,), (W,), (3 * W, W), (3 * W,), (W, W), (W,), (W,), (W,), (4 * W, W), (4 * W,), (W, 4 * W), (W,)]
+        for l in range(self.layers):
+            base = lay.blocks + lay.block_size * l
+            for j, key in enumerate(_BLOCK_KEYS):
+                out.append((f"transformer.resblocks.{l}.{key}", base + lay.block_off[j], shapes[j]))
+        out += [("ln_post.weight", lay.ln_post_g, (W,)), ("ln_post.bias", lay.ln_post_b, (W,)), ("proj", lay.proj, (W, D))]
+        return [(k, int(o), s) for k, o, s in out]
+
+    def named_views(self):
+        views = {}
+        for key, off, shape in self.spans():
+            n = 1
+            for s in shape:
+                n *= s
+            views[key] = self.params[off:off + n].view(shape)
+        return views
+
+    def load_clip_state_dict(self, sd, prefix="visual."):
+        with torch.no_grad():
+            for key, v in self.named_views().items():
+                v.copy_(sd[prefix + key].to(device=self.device, dtype=torch.float32))
+        self._stale = True
+
+    def forward(self, image):
+        """fp32 [B, 3, res, res] (device) -> un-normalised features fp32 [B, D]."""
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.res or image.shape[3] != self.res:
+            raise ValueError(f"expected [B,3,{self.res},{self.res}], got {tuple(image.shape)}")
+        image = image.to(self.device, torch.float32).contiguous()
+        B = image.shape[0]
+        cfg = self._cfg(B)
+        if self._stale:
+            check(lib().spn_vision_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()),
+                  "vision_refresh_bf16")
+            self._stale = False
+        need = lib().spn_vision_ws_bytes(C.byref(cfg))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        check(lib().spn_vision_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(image), _p(self._ws),
+                                   self._ws.numel(), _p(feats), _stream()), "vision_fwd")
+        return feats

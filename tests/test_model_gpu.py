@@ -147,3 +147,84 @@ def test_recall_metrics_match_reference(golden_dir):
     assert cirr == pytest.approx(tuple(z["cirr"]), abs=1e-4)
     pred, _, _ = validate.generate_fiq_val_predictions(_StubModel(text, 64), fiq_rows, names, gallery)
     assert np.allclose(pred.cpu().numpy(), z["pred"], atol=1e-6)
+
+
+def test_vision_tower_matches_reference(golden_dir):
+    """CLIP.encode_image through the HIP kernels vs the reference's fp32 CPU output (tiny ViT, patch 16)."""
+    _need_gpu()
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    model = CIRPlus(sd, device=torch.device("cuda"))
+    assert model.input_dim == 32 and model.vision is not None
+    feats = model.encode_image(torch.from_numpy(z["image"]).cuda()).cpu()
+    ref = torch.from_numpy(z["image_feats"])
+    cos = torch.nn.functional.cosine_similarity(feats.double(), ref.double(), dim=-1)
+    assert (1 - cos).max() < 1e-3
+    assert (feats - ref).norm() / ref.norm() < 2e-2
+    # a larger, ViT-L/14-shaped geometry (patch 14 -> K = 588 padded to 640, 257 tokens) against the oracle
+    from oracle import clip_vision
+    g = torch.Generator().manual_seed(3)
+    W, layers, D, p, res = 128, 1, 64, 14, 224
+    big = {k: v for k, v in sd.items() if not k.startswith("visual.")}
+    big["visual.conv1.weight"] = torch.randn(W, 3, p, p, generator=g) * 0.03
+    big["visual.class_embedding"] = torch.randn(W, generator=g) * 0.1
+    big["visual.positional_embedding"] = torch.randn((res // p) ** 2 + 1, W, generator=g) * 0.1
+    for k in ("ln_pre", "ln_post"):
+        big[f"visual.{k}.weight"] = 1 + 0.1 * torch.randn(W, generator=g)
+        big[f"visual.{k}.bias"] = 0.1 * torch.randn(W, generator=g)
+    for k, v in sd.items():
+        if k.startswith("visual.transformer.resblocks.0."):
+            big[k] = v
+    big["visual.proj"] = torch.randn(W, D, generator=g) * 0.1
+    m2 = CIRPlus(big, device=torch.device("cuda"))
+    img = torch.randn(3, 3, res, res, generator=g)
+    got = m2.encode_image(img.cuda()).cpu()
+    want = clip_vision.encode_image(big, img)
+    cos = torch.nn.functional.cosine_similarity(got.double(), want.double(), dim=-1)
+    assert (1 - cos).max() < 1e-3
+
+
+class _FakeTrainSet:
+    """7-tuples of the reference's relative/train CIRDataset with random 'images' (data_utils_negplus.py:265)."""
+
+    def __init__(self, n_trip, n_img, res, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.images = torch.randn(n_img, 3, res, res, generator=g)
+        self.ref = torch.randint(0, n_img, (n_trip,), generator=g)
+        self.tgt = torch.randint(0, n_img, (n_trip,), generator=g)
+        self.image_id = n_img
+
+    def __len__(self):
+        return len(self.ref)
+
+    def __getitem__(self, i):
+        r, t = int(self.ref[i]), int(self.tgt[i])
+        return self.images[r], f"cap {i}", self.images[t], i, i, r, t
+
+
+def test_bank_builders(golden_dir, tmp_path):
+    _need_gpu()
+    from oracle import clip_vision
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    model = CIRPlus(sd, device=torch.device("cuda"), plus=True, neg_num=3)
+    ds = _FakeTrainSet(40, 11, 32, 5)
+    path = str(tmp_path / "fiq_bank.pth")
+    model.extract_bank_features(ds, bank_path=path)
+    refer, target = torch.load(path)                                   # the reference's file format
+    assert refer.shape == (40, 64) and target.shape == (11, 64)
+    want = clip_vision.encode_image(sd, ds.images)
+    used = torch.unique(torch.cat([ds.ref, ds.tgt]))
+    cos = torch.nn.functional.cosine_similarity(target[used].double(), want[used].double(), dim=-1)
+    assert (1 - cos).min() > -1e-6 and (1 - cos).max() < 1e-3
+    assert torch.allclose(target[used].norm(dim=1), torch.ones(len(used)), atol=1e-4)
+    assert torch.allclose(refer, want[ds.ref], atol=0.05, rtol=0.05)
+    model.extract_refer_bank_features(ds, bank_path=str(tmp_path / "fiq_refer_bank.pth"))
+    assert model.refer_bank.shape == (11, 64) and model.refer_bank.is_cuda
+    unl = [torch.randn(3, 32, 32) for _ in range(5)]
+    model.extract_unlabeled_bank_features(unl, bank_path=str(tmp_path / "fiq_bank_unlabeled.pth"))
+    assert model.M == 11 and model.target_bank.shape == (14, 64)       # neg_num = 3 of the 5 unlabeled rows kept
+    # and the step runs on banks built this way
+    ids = torch.from_numpy(z["ids"])
+    out = model.forward(ids, torch.arange(6), ds.tgt[:6], ds.ref[:6])
+    assert torch.isfinite(out["bank_loss"])
