@@ -231,8 +231,12 @@ class CIRPlus(nn.Module):
         if torch.is_tensor(text):
             return text.to(self.device, torch.int32).contiguous()
         if self.tokenizer is None:
-            raise RuntimeError("no tokenizer configured: pass pre-tokenised int32 ids or CIRPlus(tokenizer=...)")
-        return self.tokenizer(text).to(self.device, torch.int32).contiguous()
+            from .tokenizer import tokenize as clip_tokenize      # clip.tokenize (clip/clip.py:206-247)
+            self.tokenizer = clip_tokenize
+        ids = self.tokenizer(text)
+        if int(ids.max()) >= self.tower.vocab:
+            raise RuntimeError(f"token id {int(ids.max())} outside the model's vocabulary ({self.tower.vocab})")
+        return ids.to(self.device, torch.int32).contiguous()
 
     def encode_image(self, image):
         """fp32 [B, 3, res, res] -> un-normalised image features [B, D] (models_negplus.py:39-41)."""
