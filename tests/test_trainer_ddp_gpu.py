@@ -1,0 +1,84 @@
+"""Two ranks sharing the one GPU of the test box (gloo carries the collectives; RCCL refuses two
+ranks per device): the full fused step - tower, sharded/replicated bank loss, bucketed gradient
+all-reduce, AdamW - must reproduce the single-process step on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+W, LAYERS, D, VOCAB, B, M, TAU, LR = 128, 2, 128, 600, 16, 901, 0.03, 1e-3
+
+
+def _setup():
+    from spn4cir_amd import synthetic
+    sd = synthetic.text_state_dict(W, LAYERS, D, vocab=VOCAB, seed=0)
+    target, refer = synthetic.banks(M, D)
+    ids = synthetic.token_ids(B, vocab=VOCAB, seed=1)
+    ridx, labels = synthetic.triplet_indices(B, M)
+    return sd, target, refer, ids, ridx, labels
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd.models import CIRPlus
+        from spn4cir_amd.trainer import Stage2Trainer
+        sd, target, refer, ids, ridx, labels = _setup()
+        dev = torch.device("cuda", 0)
+        model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode)
+        tr.set_banks(refer, target)
+        bl = B // world
+        sl = slice(rank * bl, (rank + 1) * bl)
+        losses = []
+        for _ in range(2):
+            losses.append(tr.step(ids[sl].to(dev), ridx[sl].to(dev), labels[sl].to(dev)).item())
+        out.put((rank, losses, model.tower.params.cpu().numpy()))   # by value: the worker exits right after
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+def test_two_ranks_match_single_process(mode):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd.models import CIRPlus
+    from spn4cir_amd.trainer import Stage2Trainer
+    sd, target, refer, ids, ridx, labels = _setup()
+    dev = torch.device("cuda", 0)
+    model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+    tr = Stage2Trainer(model, lr=LR)
+    tr.set_banks(refer, target)
+    ref_losses = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    ref_params = model.tower.params.cpu()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = [(r, l, torch.from_numpy(p)) for r, l, p in res]
+    for rank, losses, params in res:
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (mode, rank, losses, ref_losses)
+        # same update as the single-process run: differences only from bf16 rounding of partial sums
+        assert (params - ref_params).abs().max() < 2e-3, (mode, rank, (params - ref_params).abs().max().item())
+    assert (res[0][2] - res[1][2]).abs().max() == 0.0       # replicas stay bit-identical
