@@ -454,10 +454,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
     }
 }
 
+// also folds the per-split column sums (bias gradient) when cs_ws != nullptr
 __global__ void splitk_reduce2_kernel(const float* __restrict__ ws, int splits, int rows, int cols,
-                                      float* __restrict__ out, int ldo, float alpha, int accumulate) {
+                                      float* __restrict__ out, int ldo, float alpha, int accumulate,
+                                      const float* __restrict__ cs_ws, float* __restrict__ cs_out) {
     const int c4 = cols >> 2;
     const size_t total = (size_t)rows * c4;
+    if (cs_ws) {
+        const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < (size_t)rows) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += cs_ws[(size_t)z * rows + t];
+            cs_out[t] = s;
+        }
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / c4), c = (int)(i % c4) * 4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -535,9 +545,10 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
     if (rc) return rc;
     const size_t total = (size_t)N1 * (N2 / 4);
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha, accumulate);
+    if ((size_t)blocks * 256 < (size_t)N1) return SPN_ERR_SHAPE;   // the fused colsum fold needs >= N1 threads
+    hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha, accumulate,
+                       (const float*)cs_ws, colsum_out);
     SPN_CHECK_LAUNCH();
-    if (colsum_out) return fold_rows(cs_ws, (size_t)N1, splits, (size_t)N1, colsum_out, 1.0f, 0, st);
     return SPN_OK;
 }
 

@@ -206,7 +206,8 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
 #undef SPN_LN_BWD
     SPN_CHECK_LAUNCH();
     if (want_param) {
-        SPN_CHECK_LAUNCH();
+        if (dbeta == dgamma + W)   // adjacent in the flat gradient buffer: one fold over [dgamma | dbeta]
+            return fold_rows(ws, (size_t)2 * W, blocks, (size_t)2 * W, dgamma, 1.0f, accumulate_dparam, st);
         int rc = fold_rows(ws, (size_t)2 * W, blocks, (size_t)W, dgamma, 1.0f, accumulate_dparam, st);
         if (rc) return rc;
         rc = fold_rows(ws + W, (size_t)2 * W, blocks, (size_t)W, dbeta, 1.0f, accumulate_dparam, st);
