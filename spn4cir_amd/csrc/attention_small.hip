@@ -47,11 +47,14 @@ __device__ __forceinline__ bf16x8 rfrag(const bf16_t* s, int ld, int row_base, i
 
 // transposed fragment: index (lane&15) walks the contiguous dim (columns cb..cb+15), the 8 k-values
 // walk LDS rows kbase + (lane>>4)*8 + 0..7
-__device__ __forceinline__ bf16x8 tfrag(const bf16_t* s, int ld, int kbase, int cb, int lane) {
+// Rows >= zrow are redirected to row zrow, which holds zeros (keeps the tiles at NT*16+1 rows instead
+// of padding them to a multiple of 32).
+__device__ __forceinline__ bf16x8 tfrag(const bf16_t* s, int ld, int kbase, int cb, int lane, int zrow) {
     union { s16x4 h[2]; bf16x8 v; } u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int row = kbase + (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+        int row = kbase + (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+        row = row < zrow ? row : zrow;
         u.h[h] = lds_tr16_b64(s + row * ld + cb + (lane & 3) * 4);
     }
     return u.v;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
         if (ks < nks) {
             const bf16x8 pf = rfrag(Ps, PLD, 0, ks * 32, lane);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = mfma16s(tfrag(Vs, SLD, ks * 32, d * 16, lane), pf, o[d]);
+            for (int d = 0; d < 4; ++d) o[d] = mfma16s(tfrag(Vs, SLD, ks * 32, d * 16, lane, KP), pf, o[d]);
         }
     }
     if (qrow >= L) return;
@@ -159,15 +162,17 @@ template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArgs g) {
     const AttnArgs& a = g.f;
     constexpr int KS = (NT + 1) / 2, KP = KS * 32;
-    constexpr int PLD = KP + 8;
-    // Q, K, V, dO tiles [KP][SLD] + P, dS matrices [KP][PLD] (rows = queries, zero padded)
+    constexpr int PLD = KP;              // P / dS row stride: key columns 0..KP-1
+    constexpr int ZR = NT * 16;          // index of the all-zero row; tiles have ZR + 1 rows
+    constexpr int TR_ = ZR + 1;
+    // Q, K, V, dO tiles [TR_][SLD] + P, dS matrices [TR_][PLD] (rows = queries)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* Qs = smem;
-    bf16_t* Ks = Qs + KP * SLD;
-    bf16_t* Vs = Ks + KP * SLD;
-    bf16_t* Os = Vs + KP * SLD;
-    bf16_t* Pm = Os + KP * SLD;
-    bf16_t* Dm = Pm + KP * PLD;
+    bf16_t* Ks = Qs + TR_ * SLD;
+    bf16_t* Vs = Ks + TR_ * SLD;
+    bf16_t* Os = Vs + TR_ * SLD;
+    bf16_t* Pm = Os + TR_ * SLD;
+    bf16_t* Dm = Pm + TR_ * PLD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int L = a.Lq;
@@ -176,14 +181,13 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     const bf16_t* vb = a.v + (size_t)b * L * a.ldv + h * SHD;
     const bf16_t* dob = g.d_o + (size_t)b * L * g.lddo + h * SHD;
     const float* kbias = a.key_bias ? a.key_bias + (size_t)b * L : nullptr;
-    load_rows<KP>(qb, a.ldq, L, tid, NT * 64, Qs);
-    load_rows<KP>(kb, a.ldk, L, tid, NT * 64, Ks);
-    load_rows<KP>(vb, a.ldv, L, tid, NT * 64, Vs);
-    load_rows<KP>(dob, g.lddo, L, tid, NT * 64, Os);
-    // rows of P / dS beyond the last wave's tile (KP > NT*16) must read as zero in phase 2
-    for (int i = tid; i < (KP - NT * 16) * PLD; i += NT * 64) {
-        Pm[NT * 16 * PLD + i] = (bf16_t)0.0f;
-        Dm[NT * 16 * PLD + i] = (bf16_t)0.0f;
+    load_rows<TR_>(qb, a.ldq, L, tid, NT * 64, Qs);
+    load_rows<TR_>(kb, a.ldk, L, tid, NT * 64, Ks);
+    load_rows<TR_>(vb, a.ldv, L, tid, NT * 64, Vs);
+    load_rows<TR_>(dob, g.lddo, L, tid, NT * 64, Os);
+    for (int i = tid; i < PLD; i += NT * 64) {           // the zero row of P / dS
+        Pm[ZR * PLD + i] = (bf16_t)0.0f;
+        Dm[ZR * PLD + i] = (bf16_t)0.0f;
     }
     __syncthreads();
 
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
             if (ks < nks) {
                 const bf16x8 df = rfrag(Dm, PLD, q0, ks * 32, lane);
 #pragma unroll
-                for (int d = 0; d < 4; ++d) dq[d] = mfma16s(tfrag(Ks, SLD, ks * 32, d * 16, lane), df, dq[d]);
+                for (int d = 0; d < 4; ++d) dq[d] = mfma16s(tfrag(Ks, SLD, ks * 32, d * 16, lane, ZR), df, dq[d]);
             }
         }
         if (row_ok) {
@@ -294,12 +298,12 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
         for (int qs = 0; qs < KS; ++qs) {
             if (qs >= qs0) {
                 // B operands: P^T / dS^T [k = query][j = key]  (transposed reads of the [q][key] matrices)
-                const bf16x8 pf = tfrag(Pm, PLD, qs * 32, k0, lane);
-                const bf16x8 df = tfrag(Dm, PLD, qs * 32, k0, lane);
+                const bf16x8 pf = tfrag(Pm, PLD, qs * 32, k0, lane, ZR);
+                const bf16x8 df = tfrag(Dm, PLD, qs * 32, k0, lane, ZR);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    dv[d] = mfma16s(tfrag(Os, SLD, qs * 32, d * 16, lane), pf, dv[d]);   // dO^T [d][q]
-                    dk[d] = mfma16s(tfrag(Qs, SLD, qs * 32, d * 16, lane), df, dk[d]);   // Q^T  [d][q]
+                    dv[d] = mfma16s(tfrag(Os, SLD, qs * 32, d * 16, lane, ZR), pf, dv[d]);   // dO^T [d][q]
+                    dk[d] = mfma16s(tfrag(Qs, SLD, qs * 32, d * 16, lane, ZR), df, dk[d]);   // Q^T  [d][q]
                 }
             }
         }
@@ -332,8 +336,8 @@ static int launch_small_fwd(const AttnArgs& a, hipStream_t st) {
 
 template <int NT>
 static int launch_small_bwd(const AttnBwdArgs& g, hipStream_t st) {
-    constexpr int KS = (NT + 1) / 2, KP = KS * 32, PLD = KP + 8;
-    constexpr int LDS = (4 * KP * SLD + 2 * KP * PLD) * 2;
+    constexpr int KS = (NT + 1) / 2, KP = KS * 32, PLD = KP, TR_ = NT * 16 + 1;
+    constexpr int LDS = (4 * TR_ * SLD + 2 * TR_ * PLD) * 2;
     auto kern = attention_small_bwd_kernel<NT>;
     static bool attr_set = false;
     if (!attr_set) {
