@@ -188,6 +188,35 @@ int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void
 int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
                    void* ws, size_t ws_bytes, float* feats, void* stream);
 
+/* ---------------------------------------------------------------- BLIP fusion encoder
+ * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of
+ * blip4cir/models.py:95-105.  ids [B,L] int32 (ids[:,0] = [ENC]), mask [B,L] int32 {0,1} (may be NULL),
+ * enc [B,S,E] fp32 reference-image tokens (constants: no gradient).  proj_out [B,Dp] fp32 = text_proj of
+ * the [ENC] position; L2-normalise it with spn_combine_l2norm_fwd(NULL, NULL, proj_out, ...), and feed
+ * spn_fusion_bwd the gradient w.r.t. proj_out (spn_combine_l2norm_bwd).  W, E, I, Dp multiples of 64.
+ * Per-layer parameter order (layer_off): sa_wqkv[3W,W] (query,key,value rows) sa_bqkv sa_wo sa_bo sa_ln_g
+ * sa_ln_b ca_wq ca_bq ca_wkv[2W,E] (key,value rows) ca_bkv ca_wo ca_bo ca_ln_g ca_ln_b ff_w1[I,W] ff_b1
+ * ff_w2[W,I] ff_b2 ff_ln_g ff_ln_b, [20] = layer size. */
+typedef struct {
+    int B, L, S, W, H, layers, I, E, Dp, vocab, max_pos;
+} spn_fusion_cfg;
+
+typedef struct {
+    int64_t word, pos, emb_ln_g, emb_ln_b, layers, layer_size, proj_w, proj_b, n_params;
+    int64_t layer_off[21];
+    int64_t bf16_layer_size, bf16_proj, bf16_proj_t, n_bf16;
+    int64_t bf16_off[15];
+} spn_fusion_layout_t;
+
+int spn_fusion_layout(const spn_fusion_cfg* cfg, spn_fusion_layout_t* out);
+size_t spn_fusion_act_bytes(const spn_fusion_cfg* cfg);
+size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg);
+int spn_fusion_refresh_bf16(const spn_fusion_cfg* cfg, const float* params, void* weights_bf16, void* stream);
+int spn_fusion_fwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                   const int32_t* mask, const float* enc, void* acts, float* proj_out, void* stream);
+int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                   void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- opt-in kernel timing
  * HIP events recorded on the launch stream around the main kernels (bench.py's live roofline).
  * The only process-global state in the library; off unless spn_prof_enable() is called.

@@ -16,4 +16,4 @@ are the only pin available.
 Each function cites the reference file:line it restates (paths relative to the reference
 repository root).
 """
-from . import clip_text, clip_vision, bank_loss, recall, optim  # noqa: F401
+from . import clip_text, clip_vision, bank_loss, recall, optim, bert_fusion  # noqa: F401

@@ -38,6 +38,17 @@ class VisionLayout(C.Structure):
                                          "seq")]
 
 
+class FusionCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "S", "W", "H", "layers", "I", "E", "Dp", "vocab", "max_pos")]
+
+
+class FusionLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("word", "pos", "emb_ln_g", "emb_ln_b", "layers", "layer_size", "proj_w",
+                                         "proj_b", "n_params")] + [("layer_off", C.c_int64 * 21)] + \
+               [(n, C.c_int64) for n in ("bf16_layer_size", "bf16_proj", "bf16_proj_t", "n_bf16")] + \
+               [("bf16_off", C.c_int64 * 15)]
+
+
 _SIGS = {
     "spn_abi_version": (i32, []),
     "spn_error_string": (C.c_char_p, [i32]),
@@ -81,6 +92,12 @@ _SIGS = {
     "spn_vision_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
     "spn_vision_refresh_bf16": (i32, [C.POINTER(VisionCfg), vp, vp, vp]),
     "spn_vision_fwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, sz, vp, vp]),
+    "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
+    "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),
+    "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),
+    "spn_fusion_refresh_bf16": (i32, [C.POINTER(FusionCfg), vp, vp, vp]),
+    "spn_fusion_fwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "spn_fusion_bwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_prof_enable": (i32, [i32]),
     "spn_prof_disable": (i32, []),
     "spn_prof_reset": (i32, []),

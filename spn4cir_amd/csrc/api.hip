@@ -247,6 +247,42 @@ int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* w
     return vision_fwd(vc(cfg), params, CBF(weights_bf16), image, (char*)ws, ws_bytes, feats, ST(stream));
 }
 
+static_assert(sizeof(spn_fusion_cfg) == sizeof(FusionCfg), "spn_fusion_cfg layout");
+static_assert(sizeof(spn_fusion_layout_t) == sizeof(FusionLayout), "spn_fusion_layout_t layout");
+
+static FusionCfg fc(const spn_fusion_cfg* c) {
+    FusionCfg f;
+    f.B = c->B; f.L = c->L; f.S = c->S; f.W = c->W; f.H = c->H; f.layers = c->layers; f.I = c->I; f.E = c->E;
+    f.Dp = c->Dp; f.vocab = c->vocab; f.max_pos = c->max_pos;
+    return f;
+}
+
+int spn_fusion_layout(const spn_fusion_cfg* cfg, spn_fusion_layout_t* out) {
+    if (!cfg || !out) return SPN_ERR_ARG;
+    fusion_layout(fc(cfg), reinterpret_cast<FusionLayout*>(out));
+    return SPN_OK;
+}
+
+size_t spn_fusion_act_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_act_bytes(fc(cfg)) : 0; }
+size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_ws_bytes(fc(cfg)) : 0; }
+
+int spn_fusion_refresh_bf16(const spn_fusion_cfg* cfg, const float* params, void* weights_bf16, void* stream) {
+    if (!cfg || !params || !weights_bf16) return SPN_ERR_ARG;
+    return fusion_refresh_bf16(fc(cfg), params, BF(weights_bf16), ST(stream));
+}
+
+int spn_fusion_fwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                   const int32_t* mask, const float* enc, void* acts, float* proj_out, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !enc || !acts || !proj_out) return SPN_ERR_ARG;
+    return fusion_fwd(fc(cfg), params, CBF(weights_bf16), ids, mask, enc, (char*)acts, proj_out, ST(stream));
+}
+
+int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                   void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !dproj || !grads || !ws) return SPN_ERR_ARG;
+    return fusion_bwd(fc(cfg), params, CBF(weights_bf16), ids, (char*)acts, dproj, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
 int spn_text_bwd_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
                       const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream) {
     if (!cfg || !params || !weights_bf16 || !acts || !dfeats || !grads || !ws) return SPN_ERR_ARG;

@@ -1,0 +1,384 @@
+// BLIP multimodal text encoder (blip4cir/med.py BertModel, mode='multimodal') forward + backward and the
+// text_proj / normalise head of blip_cir.py:98 - the query producer of blip4cir's bank step
+// (blip4cir/models.py:95-105).  Post-LN BERT layers: self-attention (padding bias), cross-attention over
+// the reference image's tokens (K/V = Linear(enc_width -> W) of the image tokens, per layer), exact-GELU
+// FFN.  Pure launch sequencing over the library's kernels; the q/k/v Linears of a block are packed into
+// one GEMM (rows ordered query, key, value).  The image tokens are constants (frozen ViT, detached bank):
+// no gradient flows into them.
+#include "tower.h"
+
+namespace spn {
+
+#define SPN_TRYF(x)                       \
+    do {                                  \
+        int rc__ = (x);                   \
+        if (rc__ != SPN_OK) return rc__;  \
+    } while (0)
+
+static inline size_t fa(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// per-layer parameter order (fp32 flat); LO_* index FusionLayout::layer_off
+enum {
+    LO_SA_WQKV = 0, LO_SA_BQKV, LO_SA_WO, LO_SA_BO, LO_SA_LNG, LO_SA_LNB,
+    LO_CA_WQ, LO_CA_BQ, LO_CA_WKV, LO_CA_BKV, LO_CA_WO, LO_CA_BO, LO_CA_LNG, LO_CA_LNB,
+    LO_FF_W1, LO_FF_B1, LO_FF_W2, LO_FF_B2, LO_FF_LNG, LO_FF_LNB, LO_SIZE
+};
+// per-layer bf16 mirror order (each weight followed by its transpose); BO_* index FusionLayout::bf16_off
+enum { BO_SA_WQKV = 0, BO_SA_WQKV_T, BO_SA_WO, BO_SA_WO_T, BO_CA_WQ, BO_CA_WQ_T, BO_CA_WKV, BO_CA_WKV_T, BO_CA_WO,
+       BO_CA_WO_T, BO_FF_W1, BO_FF_W1_T, BO_FF_W2, BO_FF_W2_T, BO_SIZE };
+
+void fusion_layout(const FusionCfg& c, FusionLayout* t) {
+    const int64_t W = c.W, E = c.E, I = c.I;
+    int64_t o = 0;
+    t->word = o; o += (int64_t)c.vocab * W;
+    t->pos = o; o += (int64_t)c.max_pos * W;
+    t->emb_ln_g = o; o += W;
+    t->emb_ln_b = o; o += W;
+    t->layers = o;
+    const int64_t sz[LO_SIZE] = {3 * W * W, 3 * W, W * W, W, W, W, W * W, W, 2 * W * E, 2 * W, W * W, W, W, W,
+                                 I * W, I, W * I, W, W, W};
+    int64_t lo = 0;
+    for (int i = 0; i < LO_SIZE; ++i) { t->layer_off[i] = lo; lo += sz[i]; }
+    t->layer_off[LO_SIZE] = lo;
+    t->layer_size = lo;
+    o += lo * c.layers;
+    t->proj_w = o; o += (int64_t)c.Dp * W;
+    t->proj_b = o; o += c.Dp;
+    t->n_params = o;
+    const int64_t bs[BO_SIZE / 2] = {3 * W * W, W * W, W * W, 2 * W * E, W * W, I * W, W * I};
+    int64_t bo = 0;
+    for (int i = 0; i < BO_SIZE / 2; ++i) {
+        t->bf16_off[2 * i] = bo; bo += bs[i];
+        t->bf16_off[2 * i + 1] = bo; bo += bs[i];
+    }
+    t->bf16_off[BO_SIZE] = bo;
+    t->bf16_layer_size = bo;
+    t->bf16_proj = bo * c.layers;
+    t->bf16_proj_t = t->bf16_proj + (int64_t)c.Dp * W;
+    t->n_bf16 = t->bf16_proj_t + (int64_t)c.Dp * W;
+}
+
+static int fusion_check(const FusionCfg& c) {
+    if (c.B <= 0 || c.L <= 0 || c.S <= 0 || c.layers <= 0 || c.L > c.max_pos) return SPN_ERR_ARG;
+    if (c.W % 64 || c.H * 64 != c.W || c.E % 64 || c.I % 64 || c.Dp % 64) return SPN_ERR_SHAPE;
+    return SPN_OK;
+}
+
+int fusion_refresh_bf16(const FusionCfg& c, const float* params, bf16_t* wb, hipStream_t st) {
+    SPN_TRYF(fusion_check(c));
+    FusionLayout t;
+    fusion_layout(c, &t);
+    const int W = c.W, E = c.E, I = c.I;
+    const int src[BO_SIZE / 2] = {LO_SA_WQKV, LO_SA_WO, LO_CA_WQ, LO_CA_WKV, LO_CA_WO, LO_FF_W1, LO_FF_W2};
+    const int rows[BO_SIZE / 2] = {3 * W, W, W, 2 * W, W, I, W};
+    const int cols[BO_SIZE / 2] = {W, W, W, E, W, W, I};
+    for (int l = 0; l < c.layers; ++l) {
+        const float* p = params + t.layers + t.layer_size * l;
+        bf16_t* b = wb + t.bf16_layer_size * l;
+        for (int i = 0; i < BO_SIZE / 2; ++i)
+            SPN_TRYF(cast_transpose_f32_bf16(p + t.layer_off[src[i]], b + t.bf16_off[2 * i], b + t.bf16_off[2 * i + 1],
+                                             rows[i], cols[i], st));
+    }
+    SPN_TRYF(cast_transpose_f32_bf16(params + t.proj_w, wb + t.bf16_proj, wb + t.bf16_proj_t, c.Dp, c.W, st));
+    return SPN_OK;
+}
+
+// ------------------------------------------------------------------------------ activations
+struct FusionLayerActs {
+    float* x_in; bf16_t* xb_in;                 // layer input (previous LN output), fp32 + bf16
+    bf16_t* qkv; float* lse1; bf16_t* ctx1; float* y1; float *mean1, *rstd1; float* x1; bf16_t* x1b;
+    bf16_t* q2; bf16_t* kv2; float* lse2; bf16_t* ctx2; float* y2; float *mean2, *rstd2; float* x2; bf16_t* x2b;
+    bf16_t* pre; bf16_t* u; float* y3; float *mean3, *rstd3;
+};
+
+struct FusionActs {
+    float* key_bias;        // [B, L]   (1 - mask) * -10000
+    int32_t* last;          // [B]      index of the last unmasked token (embedding backward)
+    int32_t* zero_idx;      // [B]      zeros: row of the [ENC] token
+    bf16_t* enc_b;          // [B*S, E] bf16 copy of the image tokens
+    float* emb;             // [T, W]   word + position (LN input)
+    float *emb_mean, *emb_rstd;
+    char* layers; size_t layer_bytes;
+    float* x_final; bf16_t* xb_final;           // output of the last layer
+    float* h0; bf16_t* h0b;                     // [B, W] the [ENC] rows
+    float* proj;                                // [B, Dp] text_proj output (pre-normalise)
+};
+
+static size_t fusion_layer_act_bytes(const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    size_t b = 0;
+    b += fa(T * W * 4) + fa(T * W * 2);                                        // x_in, xb_in
+    b += fa(T * 3 * W * 2) + fa((size_t)c.B * c.H * c.L * 4) + fa(T * W * 2);   // qkv, lse1, ctx1
+    b += fa(T * W * 4) + 2 * fa(T * 4) + fa(T * W * 4) + fa(T * W * 2);         // y1, mean1, rstd1, x1, x1b
+    b += fa(T * W * 2) + fa(TS * 2 * W * 2) + fa((size_t)c.B * c.H * c.L * 4) + fa(T * W * 2);   // q2, kv2, lse2, ctx2
+    b += fa(T * W * 4) + 2 * fa(T * 4) + fa(T * W * 4) + fa(T * W * 2);         // y2, mean2, rstd2, x2, x2b
+    b += 2 * fa(T * I * 2) + fa(T * W * 4) + 2 * fa(T * 4);                     // pre, u, y3, mean3, rstd3
+    return b;
+}
+
+static FusionLayerActs fusion_layer_acts_at(char* base, const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    char* p = base;
+    auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
+    FusionLayerActs A;
+    A.x_in = (float*)take(T * W * 4); A.xb_in = (bf16_t*)take(T * W * 2);
+    A.qkv = (bf16_t*)take(T * 3 * W * 2); A.lse1 = (float*)take((size_t)c.B * c.H * c.L * 4); A.ctx1 = (bf16_t*)take(T * W * 2);
+    A.y1 = (float*)take(T * W * 4); A.mean1 = (float*)take(T * 4); A.rstd1 = (float*)take(T * 4);
+    A.x1 = (float*)take(T * W * 4); A.x1b = (bf16_t*)take(T * W * 2);
+    A.q2 = (bf16_t*)take(T * W * 2); A.kv2 = (bf16_t*)take(TS * 2 * W * 2); A.lse2 = (float*)take((size_t)c.B * c.H * c.L * 4);
+    A.ctx2 = (bf16_t*)take(T * W * 2);
+    A.y2 = (float*)take(T * W * 4); A.mean2 = (float*)take(T * 4); A.rstd2 = (float*)take(T * 4);
+    A.x2 = (float*)take(T * W * 4); A.x2b = (bf16_t*)take(T * W * 2);
+    A.pre = (bf16_t*)take(T * I * 2); A.u = (bf16_t*)take(T * I * 2);
+    A.y3 = (float*)take(T * W * 4); A.mean3 = (float*)take(T * 4); A.rstd3 = (float*)take(T * 4);
+    return A;
+}
+
+size_t fusion_act_bytes(const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W;
+    size_t b = fa(T * 4) + 2 * fa((size_t)c.B * 4) + fa(TS * c.E * 2) + fa(T * W * 4) + 2 * fa(T * 4);
+    b += fusion_layer_act_bytes(c) * c.layers;
+    b += fa(T * W * 4) + fa(T * W * 2) + fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2) + fa((size_t)c.B * c.Dp * 4);
+    return b;
+}
+
+static FusionActs fusion_acts_at(char* base, const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W;
+    char* p = base;
+    auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
+    FusionActs A;
+    A.key_bias = (float*)take(T * 4);
+    A.last = (int32_t*)take((size_t)c.B * 4);
+    A.zero_idx = (int32_t*)take((size_t)c.B * 4);
+    A.enc_b = (bf16_t*)take(TS * c.E * 2);
+    A.emb = (float*)take(T * W * 4);
+    A.emb_mean = (float*)take(T * 4);
+    A.emb_rstd = (float*)take(T * 4);
+    A.layer_bytes = fusion_layer_act_bytes(c);
+    A.layers = p; p += A.layer_bytes * c.layers;
+    A.x_final = (float*)take(T * W * 4);
+    A.xb_final = (bf16_t*)take(T * W * 2);
+    A.h0 = (float*)take((size_t)c.B * W * 4);
+    A.h0b = (bf16_t*)take((size_t)c.B * W * 2);
+    A.proj = (float*)take((size_t)c.B * c.Dp * 4);
+    return A;
+}
+
+// key_bias[b,l] = (1 - mask) * -10000 (med.py:686); last[b] = (number of unmasked tokens) - 1; zero_idx = 0
+__global__ void fusion_mask_kernel(const int32_t* __restrict__ mask, float* __restrict__ key_bias,
+                                   int32_t* __restrict__ last, int32_t* __restrict__ zero_idx, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = 0;
+    for (int l = 0; l < L; ++l) {
+        const int m = mask ? mask[(size_t)b * L + l] : 1;
+        key_bias[(size_t)b * L + l] = m ? 0.f : -10000.0f;
+        if (m) n = l + 1;
+    }
+    last[b] = n > 0 ? n - 1 : 0;
+    zero_idx[b] = 0;
+}
+
+static int nt(const bf16_t* A, const bf16_t* Bw, int M, int N, int K, const float* bias, bf16_t* out_b, float* out_f,
+              hipStream_t st, int act = ACT_NONE, bf16_t* pre = nullptr) {
+    GemmEpilogue e;
+    e.bias = bias; e.out_bf16 = out_b; e.out_f32 = out_f; e.ldc = N; e.act = act; e.aux_out = pre;
+    return gemm_nt(A, Bw, M, N, K, K, K, GEMM_STORE, e, st);
+}
+
+static int nt_resid(const bf16_t* A, const bf16_t* Bw, int M, int N, int K, const float* bias, const float* resid,
+                    float* out_f, hipStream_t st) {
+    GemmEpilogue e;
+    e.bias = bias; e.resid = resid; e.ldr = N; e.out_f32 = out_f; e.ldc = N;
+    return gemm_nt(A, Bw, M, N, K, K, K, GEMM_RESID, e, st);
+}
+
+static AttnArgs self_attn_args(const FusionCfg& c, const FusionLayerActs& A, const float* key_bias) {
+    AttnArgs a;
+    a.q = A.qkv; a.k = A.qkv + c.W; a.v = A.qkv + 2 * c.W;
+    a.ldq = a.ldk = a.ldv = 3 * c.W;
+    a.o = A.ctx1; a.ldo = c.W; a.lse = A.lse1; a.key_bias = key_bias;
+    a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = 0; a.scale = 0.125f;
+    return a;
+}
+
+static AttnArgs cross_attn_args(const FusionCfg& c, const FusionLayerActs& A) {
+    AttnArgs a;
+    a.q = A.q2; a.k = A.kv2; a.v = A.kv2 + c.W;
+    a.ldq = c.W; a.ldk = a.ldv = 2 * c.W;
+    a.o = A.ctx2; a.ldo = c.W; a.lse = A.lse2; a.key_bias = nullptr;     // image mask is all ones (blip_cir.py:85)
+    a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.S; a.causal = 0; a.scale = 0.125f;
+    return a;
+}
+
+int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* mask,
+               const float* enc, char* acts, float* proj_out, hipStream_t st) {
+    SPN_TRYF(fusion_check(c));
+    FusionLayout t;
+    fusion_layout(c, &t);
+    FusionActs A = fusion_acts_at(acts, c);
+    const int T = c.B * c.L, TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
+    hipLaunchKernelGGL(fusion_mask_kernel, dim3((c.B + 63) / 64), dim3(64), 0, st, mask, A.key_bias, A.last, A.zero_idx, c.B,
+                       c.L);
+    SPN_CHECK_LAUNCH();
+    SPN_TRYF(cast_f32_bf16(enc, A.enc_b, (size_t)TS * E, st));
+    SPN_TRYF(embed_fwd(ids, params + t.word, params + t.pos, A.emb, c.B, c.L, W, c.vocab, st));
+    FusionLayerActs first = fusion_layer_acts_at(A.layers, c);
+    SPN_TRYF(layernorm_fwd(A.emb, params + t.emb_ln_g, params + t.emb_ln_b, first.xb_in, first.x_in, A.emb_mean, A.emb_rstd, T,
+                           W, 1e-12f, st));
+    for (int l = 0; l < c.layers; ++l) {
+        FusionLayerActs a = fusion_layer_acts_at(A.layers + A.layer_bytes * l, c);
+        float* x_out = A.x_final;
+        bf16_t* xb_out = A.xb_final;
+        if (l + 1 < c.layers) {
+            FusionLayerActs n = fusion_layer_acts_at(A.layers + A.layer_bytes * (l + 1), c);
+            x_out = n.x_in; xb_out = n.xb_in;
+        }
+        const float* p = params + t.layers + t.layer_size * l;
+        const bf16_t* b = wb + t.bf16_layer_size * l;
+        auto P = [&](int i) { return p + t.layer_off[i]; };
+        auto Bw = [&](int i) { return b + t.bf16_off[i]; };
+        // self-attention (med.py BertSelfAttention + BertSelfOutput)
+        SPN_TRYF(nt(a.xb_in, Bw(BO_SA_WQKV), T, 3 * W, W, P(LO_SA_BQKV), a.qkv, nullptr, st));
+        SPN_TRYF(attention_fwd(self_attn_args(c, a, A.key_bias), st));
+        SPN_TRYF(nt_resid(a.ctx1, Bw(BO_SA_WO), T, W, W, P(LO_SA_BO), a.x_in, a.y1, st));
+        SPN_TRYF(layernorm_fwd(a.y1, P(LO_SA_LNG), P(LO_SA_LNB), a.x1b, a.x1, a.mean1, a.rstd1, T, W, 1e-12f, st));
+        // cross-attention over the image tokens
+        SPN_TRYF(nt(a.x1b, Bw(BO_CA_WQ), T, W, W, P(LO_CA_BQ), a.q2, nullptr, st));
+        SPN_TRYF(nt(A.enc_b, Bw(BO_CA_WKV), TS, 2 * W, E, P(LO_CA_BKV), a.kv2, nullptr, st));
+        SPN_TRYF(attention_fwd(cross_attn_args(c, a), st));
+        SPN_TRYF(nt_resid(a.ctx2, Bw(BO_CA_WO), T, W, W, P(LO_CA_BO), a.x1, a.y2, st));
+        SPN_TRYF(layernorm_fwd(a.y2, P(LO_CA_LNG), P(LO_CA_LNB), a.x2b, a.x2, a.mean2, a.rstd2, T, W, 1e-12f, st));
+        // feed-forward (BertIntermediate exact GELU + BertOutput)
+        SPN_TRYF(nt(a.x2b, Bw(BO_FF_W1), T, I, W, P(LO_FF_B1), a.u, nullptr, st, ACT_GELU_ERF, a.pre));
+        SPN_TRYF(nt_resid(a.u, Bw(BO_FF_W2), T, W, I, P(LO_FF_B2), a.x2, a.y3, st));
+        SPN_TRYF(layernorm_fwd(a.y3, P(LO_FF_LNG), P(LO_FF_LNB), xb_out, x_out, a.mean3, a.rstd3, T, W, 1e-12f, st));
+    }
+    // text_proj of the [ENC] position (blip_cir.py:98); the L2-normalise is spn_combine_l2norm_fwd
+    SPN_TRYF(gather_rows_f32(A.x_final, A.zero_idx, A.h0, c.B, c.L, W, st));
+    SPN_TRYF(cast_f32_bf16(A.h0, A.h0b, (size_t)c.B * W, st));
+    SPN_TRYF(nt(A.h0b, wb + t.bf16_proj, c.B, c.Dp, W, params + t.proj_b, nullptr, proj_out, st));
+    return SPN_OK;
+}
+
+size_t fusion_ws_bytes(const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    size_t b = 0;
+    b += fa(T * W * 4) + fa(T * W * 4) + fa(T * W * 2);          // dx, dy, dyb
+    b += fa(T * I * 2);                                          // dpre
+    b += fa(T * W * 2);                                          // dctx
+    b += fa(T * 3 * W * 2);                                      // dqkv (also dq2)
+    b += fa(TS * 2 * W * 2);                                     // dkv2
+    b += fa((size_t)c.B * c.H * c.L * 4);                        // delta
+    b += fa((size_t)c.B * c.Dp * 2) + fa((size_t)c.B * W * 4);   // dproj bf16, dh0
+    size_t op = 0;
+    auto mx = [&](size_t v) { if (v > op) op = v; };
+    mx(gemm_tn_workspace_bytes((int)T, (int)W, (int)I));
+    mx(gemm_tn_workspace_bytes((int)T, (int)I, (int)W));
+    mx(gemm_tn_workspace_bytes((int)T, (int)W, (int)W));
+    mx(gemm_tn_workspace_bytes((int)T, 3 * (int)W, (int)W));
+    mx(gemm_tn_workspace_bytes((int)TS, 2 * (int)W, c.E));
+    mx(gemm_tn_workspace_bytes(c.B, c.Dp, (int)W));
+    mx(layernorm_bwd_workspace_bytes((int)T, (int)W));
+    return b + fa(op);
+}
+
+// dproj: gradient w.r.t. the text_proj output [B, Dp] (i.e. after spn_combine_l2norm_bwd)
+int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+               const float* dproj, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
+    SPN_TRYF(fusion_check(c));
+    if (ws_bytes < fusion_ws_bytes(c)) return SPN_ERR_WORKSPACE;
+    FusionLayout t;
+    fusion_layout(c, &t);
+    FusionActs A = fusion_acts_at(acts, c);
+    const int T = c.B * c.L, TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
+    const size_t Ts = (size_t)T;
+    char* p = ws;
+    auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
+    float* dx = (float*)take(Ts * W * 4);        // gradient w.r.t. the current LN output
+    float* dy = (float*)take(Ts * W * 4);        // gradient w.r.t. the current LN input
+    bf16_t* dyb = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dpre = (bf16_t*)take(Ts * I * 2);
+    bf16_t* dctx = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
+    bf16_t* dkv2 = (bf16_t*)take((size_t)TS * 2 * W * 2);
+    float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
+    bf16_t* dprojb = (bf16_t*)take((size_t)c.B * c.Dp * 2);
+    float* dh0 = (float*)take((size_t)c.B * W * 4);
+    float* opws = (float*)p;
+    const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
+
+    // head: text_proj
+    SPN_TRYF(cast_f32_bf16(dproj, dprojb, (size_t)c.B * c.Dp, st));
+    SPN_TRYF(gemm_tn(dprojb, A.h0b, c.B, c.Dp, W, c.Dp, W, grads + t.proj_w, W, 1.0f, 0, grads + t.proj_b, opws,
+                     opws_bytes, st));
+    SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, dh0, st));
+    SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
+
+    for (int l = c.layers - 1; l >= 0; --l) {
+        FusionLayerActs a = fusion_layer_acts_at(A.layers + A.layer_bytes * l, c);
+        const float* pp = params + t.layers + t.layer_size * l;
+        float* gp = grads + t.layers + t.layer_size * l;
+        const bf16_t* b = wb + t.bf16_layer_size * l;
+        auto P = [&](int i) { return pp + t.layer_off[i]; };
+        auto G = [&](int i) { return gp + t.layer_off[i]; };
+        auto Bw = [&](int i) { return b + t.bf16_off[i]; };
+        // ---- FFN: x3 = LN(y3), y3 = x2 + gelu(x2 W1^T + b1) W2^T + b2
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y3, P(LO_FF_LNG), a.mean3, a.rstd3, dy, 0, dyb, G(LO_FF_LNG), G(LO_FF_LNB), 0, T, W,
+                               opws, opws_bytes, st));
+        {
+            GemmEpilogue e;
+            e.aux_in = a.pre; e.act = ACT_GELU_ERF; e.out_bf16 = dpre; e.ldc = I;
+            SPN_TRYF(gemm_nt(dyb, Bw(BO_FF_W2_T), T, I, W, W, W, GEMM_DACT, e, st));
+        }
+        SPN_TRYF(gemm_tn(dyb, a.u, T, W, I, W, I, G(LO_FF_W2), I, 1.0f, 0, G(LO_FF_B2), opws, opws_bytes, st));
+        SPN_TRYF(gemm_tn(dpre, a.x2b, T, I, W, I, W, G(LO_FF_W1), W, 1.0f, 0, G(LO_FF_B1), opws, opws_bytes, st));
+        SPN_TRYF(nt_resid(dpre, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));          // dx = d/dx2
+        // ---- cross-attention: x2 = LN(y2), y2 = x1 + attn(q(x1), kv(enc)) Wo^T + bo
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y2, P(LO_CA_LNG), a.mean2, a.rstd2, dy, 0, dyb, G(LO_CA_LNG), G(LO_CA_LNB), 0, T, W,
+                               opws, opws_bytes, st));
+        SPN_TRYF(nt(dyb, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(gemm_tn(dyb, a.ctx2, T, W, W, W, W, G(LO_CA_WO), W, 1.0f, 0, G(LO_CA_BO), opws, opws_bytes, st));
+        {
+            AttnBwdArgs g;
+            g.f = cross_attn_args(c, a);
+            g.d_o = dctx; g.lddo = W;
+            g.dq = dqkv; g.lddq = W;
+            g.dk = dkv2; g.dv = dkv2 + W; g.lddk = g.lddv = 2 * W;
+            g.delta = delta;
+            SPN_TRYF(attention_bwd(g, st));
+        }
+        SPN_TRYF(gemm_tn(dkv2, A.enc_b, TS, 2 * W, E, 2 * W, E, G(LO_CA_WKV), E, 1.0f, 0, G(LO_CA_BKV), opws, opws_bytes, st));
+        SPN_TRYF(gemm_tn(dqkv, a.x1b, T, W, W, W, W, G(LO_CA_WQ), W, 1.0f, 0, G(LO_CA_BQ), opws, opws_bytes, st));
+        SPN_TRYF(nt_resid(dqkv, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));          // dx = d/dx1
+        // ---- self-attention: x1 = LN(y1), y1 = x_in + attn(qkv(x_in)) Wo^T + bo
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y1, P(LO_SA_LNG), a.mean1, a.rstd1, dy, 0, dyb, G(LO_SA_LNG), G(LO_SA_LNB), 0, T, W,
+                               opws, opws_bytes, st));
+        SPN_TRYF(nt(dyb, Bw(BO_SA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(gemm_tn(dyb, a.ctx1, T, W, W, W, W, G(LO_SA_WO), W, 1.0f, 0, G(LO_SA_BO), opws, opws_bytes, st));
+        {
+            AttnBwdArgs g;
+            g.f = self_attn_args(c, a, A.key_bias);
+            g.d_o = dctx; g.lddo = W;
+            g.dq = dqkv; g.dk = dqkv + W; g.dv = dqkv + 2 * W;
+            g.lddq = g.lddk = g.lddv = 3 * W;
+            g.delta = delta;
+            SPN_TRYF(attention_bwd(g, st));
+        }
+        SPN_TRYF(gemm_tn(dqkv, a.xb_in, T, 3 * W, W, 3 * W, W, G(LO_SA_WQKV), W, 1.0f, 0, G(LO_SA_BQKV), opws, opws_bytes, st));
+        SPN_TRYF(nt_resid(dqkv, Bw(BO_SA_WQKV_T), T, W, 3 * W, nullptr, dy, dx, st));     // dx = d/dx_in
+    }
+    // embeddings: x0 = LN(word[ids] + pos)
+    SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
+                           grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));
+    hipError_t he = hipMemsetAsync(grads + t.word, 0, (size_t)c.vocab * W * sizeof(float), st);
+    if (he != hipSuccess) return (int)he;
+    SPN_TRYF(embed_bwd(ids, A.last, dy, grads + t.word, grads + t.pos, c.B, c.L, W, c.vocab, st));
+    if (c.L < c.max_pos) {
+        he = hipMemsetAsync(grads + t.pos + (size_t)c.L * W, 0, (size_t)(c.max_pos - c.L) * W * sizeof(float), st);
+        if (he != hipSuccess) return (int)he;
+    }
+    return SPN_OK;
+}
+
+}  // namespace spn

@@ -60,6 +60,26 @@ int vision_refresh_bf16(const VisionCfg& c, const float* params, bf16_t* wb, hip
 int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const float* image, char* ws, size_t ws_bytes,
                float* feats, hipStream_t st);
 
+struct FusionCfg {     // == spn_fusion_cfg
+    int B, L, S, W, H, layers, I, E, Dp, vocab, max_pos;
+};
+
+struct FusionLayout {  // == spn_fusion_layout_t (element offsets)
+    int64_t word, pos, emb_ln_g, emb_ln_b, layers, layer_size, proj_w, proj_b, n_params;
+    int64_t layer_off[21];
+    int64_t bf16_layer_size, bf16_proj, bf16_proj_t, n_bf16;
+    int64_t bf16_off[15];
+};
+
+void fusion_layout(const FusionCfg& c, FusionLayout* t);
+size_t fusion_act_bytes(const FusionCfg& c);
+size_t fusion_ws_bytes(const FusionCfg& c);
+int fusion_refresh_bf16(const FusionCfg& c, const float* params, bf16_t* wb, hipStream_t st);
+int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* mask,
+               const float* enc, char* acts, float* proj_out, hipStream_t st);
+int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+               const float* dproj, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
+
 void block_param_offsets(int W, int64_t off[13]);
 int64_t block_bf16_size(int W);
 BlockParams block_params_at(const float* p, const bf16_t* wb, int W);

@@ -1,0 +1,56 @@
+"""GPU parity of the BLIP fusion encoder + bank step vs golden vectors captured from blip4cir/med.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blip_fusion_step_matches_reference(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import ops
+    from spn4cir_amd.fusion import BlipBankStep, FusionEncoder, fusion_cfg_from_state_dict
+    z = np.load(os.path.join(golden_dir, "blip_fusion.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    c = fusion_cfg_from_state_dict(sd)
+    enc = FusionEncoder(c["hidden"], c["layers"], c["heads"], c["intermediate"], c["enc_width"],
+                        sd["text_proj.weight"].shape[0], c["vocab"], c["max_pos"], "cuda")
+    enc.load_state_dict(sd)
+    ids, mask = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["mask"]).cuda()
+    tokens = torch.from_numpy(z["enc"]).cuda()
+    bank = ops.prepare_bank(torch.from_numpy(z["bank"]).cuda())
+    labels = torch.from_numpy(z["labels"]).cuda()
+    tau = float(z["tau"])
+    step = BlipBankStep(enc, tau=tau)
+    loss, grads, dtau, q = step.step(ids, mask, tokens, bank, labels)
+    qref = torch.from_numpy(z["q"])
+    cos = torch.nn.functional.cosine_similarity(q.cpu().double(), qref.double(), dim=-1)
+    assert (1 - cos).max() < 1e-3                                     # north_star gate on the embeddings
+    assert abs(loss.item() - float(z["loss"])) < 2e-2 * max(1.0, abs(float(z["loss"])))
+    views = enc.named_views(grads)
+    worst = ("", 0.0)
+    for key, g in views.items():
+        ref = torch.from_numpy(z["grad::" + key])
+        if ref.abs().max() == 0:
+            assert g.abs().max() < 1e-6, key
+            continue
+        if key.endswith("self.key.bias"):
+            # mathematically zero (a constant added to every key shifts a softmax row uniformly): the reference
+            # holds fp32 round-off here, so compare against the scale of the sibling query-bias gradient
+            scale = torch.from_numpy(z["grad::" + key.replace("key.bias", "query.bias")]).norm()
+            assert g.cpu().norm() < 3e-2 * scale, (key, g.cpu().norm().item(), scale.item())
+            continue
+        err = ((g.cpu() - ref).norm() / ref.norm()).item()
+        if err > worst[1]:
+            worst = (key, err)
+        assert err < 6e-2, (key, err)
+    print("worst relative L2 gradient error:", worst)
+    # learnable temperature (blip4cir/models.py:29): dL/dtau against autograd on the reference's q
+    qd = qref.double()
+    t = torch.tensor(tau, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.cross_entropy((qd @ torch.from_numpy(z["bank"]).double().T) / t,
+                                      torch.from_numpy(z["labels"])).backward()
+    assert abs(dtau.item() - t.grad.item()) < 5e-2 * abs(t.grad.item())

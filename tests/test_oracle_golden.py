@@ -110,3 +110,26 @@ def test_adamw_matches_torch(golden_dir):
     assert torch.allclose(p, torch.from_numpy(z["p1"]), atol=1e-7, rtol=1e-6)
     optim.adamw_step(p, torch.from_numpy(z["g2"]), m, v, 2, float(z["lr"]))
     assert torch.allclose(p, torch.from_numpy(z["p2"]), atol=1e-7, rtol=1e-6)
+
+
+def test_blip_fusion_matches_reference(golden_dir):
+    from oracle import bert_fusion
+    z = _load(golden_dir, "blip_fusion.npz")
+    sd = {k[4:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd::")}
+    ids, mask, enc = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]), torch.from_numpy(z["enc"])
+    h = bert_fusion.fusion_forward(sd, ids, mask, enc)
+    valid = mask.bool()
+    assert torch.allclose(h[valid], torch.from_numpy(z["last_hidden_state"])[valid], atol=2e-5, rtol=1e-4)
+    q = bert_fusion.fusion_query(sd, ids, mask, enc)
+    assert torch.allclose(q, torch.from_numpy(z["q"]), atol=1e-5)
+    loss = torch.nn.functional.cross_entropy((q @ torch.from_numpy(z["bank"]).T) / float(z["tau"]),
+                                             torch.from_numpy(z["labels"]))
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    n = 0
+    for k in sd:
+        if "grad::" + k in z.files:
+            ref = torch.from_numpy(z["grad::" + k])
+            assert (sd[k].grad - ref).abs().max() <= 2e-4 * ref.abs().max().clamp_min(1e-6) + 1e-7, k
+            n += 1
+    assert n >= 50
