@@ -174,10 +174,12 @@ int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, f
  * spn_vision_layout(); bf16 mirrors written by spn_vision_refresh_bf16() (once: the tower is frozen). */
 typedef struct {
     int B, res, patch, W, H, layers, D;
+    int kind; /* 0 = CLIP VisionTransformer; 1 = BLIP / timm ViT (blip4cir/vit.py:115-197: conv bias, no ln_pre,
+                 LayerNorm eps 1e-6, exact GELU, final norm over all tokens, vision_proj with bias) */
 } spn_vision_cfg;
 
 typedef struct {
-    int64_t conv1, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, n_params;
+    int64_t conv1, conv_b, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, proj_b, n_params;
     int64_t block_off[13];
     int64_t bf16_conv1, bf16_blocks, bf16_block_size, bf16_proj_t, n_bf16, kp, seq;
 } spn_vision_layout_t;
@@ -185,8 +187,10 @@ typedef struct {
 int spn_vision_layout(const spn_vision_cfg* cfg, spn_vision_layout_t* out);
 size_t spn_vision_ws_bytes(const spn_vision_cfg* cfg);
 int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void* weights_bf16, void* stream);
+/* tokens_out (optional, kind 1): the normalised token sequence fp32 [B, S, W] (BLIP_Retrieval.img_embed,
+ * blip_cir.py:54-70: the per-image reference bank of blip4cir/models.py:76); feats = proj of token 0. */
 int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
-                   void* ws, size_t ws_bytes, float* feats, void* stream);
+                   void* ws, size_t ws_bytes, float* feats, float* tokens_out, void* stream);
 
 /* ---------------------------------------------------------------- BLIP fusion encoder
  * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of

@@ -27,12 +27,12 @@ class TextLayout(C.Structure):
 
 
 class VisionCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "res", "patch", "W", "H", "layers", "D")]
+    _fields_ = [(n, C.c_int) for n in ("B", "res", "patch", "W", "H", "layers", "D", "kind")]
 
 
 class VisionLayout(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("conv1", "cls", "pos", "ln_pre_g", "ln_pre_b", "blocks", "block_size",
-                                         "ln_post_g", "ln_post_b", "proj", "n_params")] + \
+    _fields_ = [(n, C.c_int64) for n in ("conv1", "conv_b", "cls", "pos", "ln_pre_g", "ln_pre_b", "blocks",
+                                         "block_size", "ln_post_g", "ln_post_b", "proj", "proj_b", "n_params")] + \
                [("block_off", C.c_int64 * 13)] + \
                [(n, C.c_int64) for n in ("bf16_conv1", "bf16_blocks", "bf16_block_size", "bf16_proj_t", "n_bf16", "kp",
                                          "seq")]
@@ -91,7 +91,7 @@ _SIGS = {
     "spn_vision_layout": (i32, [C.POINTER(VisionCfg), C.POINTER(VisionLayout)]),
     "spn_vision_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
     "spn_vision_refresh_bf16": (i32, [C.POINTER(VisionCfg), vp, vp, vp]),
-    "spn_vision_fwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, sz, vp, vp]),
+    "spn_vision_fwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, sz, vp, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),

@@ -225,6 +225,7 @@ static_assert(sizeof(spn_vision_layout_t) == sizeof(VisionLayout), "spn_vision_l
 static VisionCfg vc(const spn_vision_cfg* c) {
     VisionCfg v;
     v.B = c->B; v.res = c->res; v.patch = c->patch; v.W = c->W; v.H = c->H; v.layers = c->layers; v.D = c->D;
+    v.kind = c->kind;
     return v;
 }
 
@@ -242,9 +243,9 @@ int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void
 }
 
 int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
-                   void* ws, size_t ws_bytes, float* feats, void* stream) {
+                   void* ws, size_t ws_bytes, float* feats, float* tokens_out, void* stream) {
     if (!cfg || !params || !weights_bf16 || !image || !ws || !feats) return SPN_ERR_ARG;
-    return vision_fwd(vc(cfg), params, CBF(weights_bf16), image, (char*)ws, ws_bytes, feats, ST(stream));
+    return vision_fwd(vc(cfg), params, CBF(weights_bf16), image, (char*)ws, ws_bytes, feats, tokens_out, ST(stream));
 }
 
 static_assert(sizeof(spn_fusion_cfg) == sizeof(FusionCfg), "spn_fusion_cfg layout");

@@ -46,10 +46,11 @@ struct TextLayout {    // == spn_text_layout_t (element offsets)
 
 struct VisionCfg {     // == spn_vision_cfg
     int B, res, patch, W, H, layers, D;
+    int kind;          // 0 = CLIP VisionTransformer, 1 = BLIP / timm ViT (blip4cir/vit.py)
 };
 
 struct VisionLayout {  // == spn_vision_layout_t (element offsets)
-    int64_t conv1, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, n_params;
+    int64_t conv1, conv_b, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, proj_b, n_params;
     int64_t block_off[13];
     int64_t bf16_conv1, bf16_blocks, bf16_block_size, bf16_proj_t, n_bf16, kp, seq;
 };
@@ -58,7 +59,7 @@ void vision_layout(const VisionCfg& c, VisionLayout* t);
 size_t vision_ws_bytes(const VisionCfg& c);
 int vision_refresh_bf16(const VisionCfg& c, const float* params, bf16_t* wb, hipStream_t st);
 int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const float* image, char* ws, size_t ws_bytes,
-               float* feats, hipStream_t st);
+               float* feats, float* tokens_out, hipStream_t st);
 
 struct FusionCfg {     // == spn_fusion_cfg
     int B, L, S, W, H, layers, I, E, Dp, vocab, max_pos;

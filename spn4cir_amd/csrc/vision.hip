@@ -55,7 +55,9 @@ static int grid1d(size_t n) {
 static BlockCfg vision_block_cfg(const VisionCfg& c) {
     BlockCfg b;
     const int g = c.res / c.patch;
-    b.B = c.B; b.L = g * g + 1; b.W = c.W; b.H = c.H; b.causal = 0; b.act = ACT_QUICKGELU; b.eps = 1e-5f;
+    b.B = c.B; b.L = g * g + 1; b.W = c.W; b.H = c.H; b.causal = 0;
+    b.act = c.kind == 1 ? ACT_GELU_ERF : ACT_QUICKGELU;
+    b.eps = c.kind == 1 ? 1e-6f : 1e-5f;
     return b;
 }
 
@@ -68,6 +70,7 @@ void vision_layout(const VisionCfg& c, VisionLayout* t) {
     const int64_t K = 3ll * c.patch * c.patch;
     int64_t o = 0;
     t->conv1 = o; o += (int64_t)c.W * K;
+    t->conv_b = o; o += c.W;          // used by kind 1 only (CLIP's conv1 has no bias)
     t->cls = o; o += c.W;
     t->pos = o; o += (int64_t)S * c.W;
     t->ln_pre_g = o; o += c.W;
@@ -76,6 +79,7 @@ void vision_layout(const VisionCfg& c, VisionLayout* t) {
     t->ln_post_g = o; o += c.W;
     t->ln_post_b = o; o += c.W;
     t->proj = o; o += (int64_t)c.W * c.D;
+    t->proj_b = o; o += c.D;          // kind 1: vision_proj bias
     t->n_params = o;
     for (int i = 0; i < 13; ++i) t->block_off[i] = bo[i];
     t->bf16_conv1 = 0;
@@ -133,7 +137,7 @@ size_t vision_ws_bytes(const VisionCfg& c) {
 }
 
 int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const float* image, char* ws, size_t ws_bytes,
-               float* feats, hipStream_t st) {
+               float* feats, float* tokens_out, hipStream_t st) {
     SPN_TRYV(vision_check(c));
     if (ws_bytes < vision_ws_bytes(c)) return SPN_ERR_WORKSPACE;
     VisionLayout t;
@@ -157,15 +161,17 @@ int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const 
     {
         GemmEpilogue e;
         e.out_f32 = emb; e.ldc = c.W;
+        if (c.kind == 1) e.bias = params + t.conv_b;       // timm PatchEmbed conv has a bias
         SPN_TRYV(gemm_nt(patches, wb + t.bf16_conv1, (int)P, c.W, Kp, Kp, Kp, GEMM_STORE, e, st));
     }
-    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(grid1d(T * (c.W / 4))), dim3(256), 0, st, emb, params + t.cls,
-                       params + t.pos, tok, c.B, S, c.W);
-    SPN_CHECK_LAUNCH();
     BlockActs A = block_acts_at(acts, bc);
-    float* xa = A.x_in;      // ln_pre output = first block input
-    SPN_TRYV(layernorm_fwd(tok, params + t.ln_pre_g, params + t.ln_pre_b, nullptr, xa, nullptr, nullptr, (int)T, c.W, 1e-5f,
-                           st));
+    float* xa = A.x_in;      // first block input: ln_pre(tokens) for CLIP, the tokens themselves for the timm ViT
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(grid1d(T * (c.W / 4))), dim3(256), 0, st, emb, params + t.cls,
+                       params + t.pos, c.kind == 1 ? xa : tok, c.B, S, c.W);
+    SPN_CHECK_LAUNCH();
+    if (c.kind != 1)
+        SPN_TRYV(layernorm_fwd(tok, params + t.ln_pre_g, params + t.ln_pre_b, nullptr, xa, nullptr, nullptr, (int)T, c.W,
+                               1e-5f, st));
     float* cur = xa;
     float* nxt = xb;
     for (int l = 0; l < c.layers; ++l) {
@@ -182,9 +188,13 @@ int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const 
     if (he != hipSuccess) return (int)he;
     SPN_TRYV(gather_rows_f32(cur, zero_idx, cls_rows, c.B, S, c.W, st));
     SPN_TRYV(layernorm_fwd(cls_rows, params + t.ln_post_g, params + t.ln_post_b, ln_cls, nullptr, nullptr, nullptr, c.B, c.W,
-                           1e-5f, st));
+                           bc.eps, st));
+    if (tokens_out)   // vit.py:195: x = self.norm(x) over every token
+        SPN_TRYV(layernorm_fwd(cur, params + t.ln_post_g, params + t.ln_post_b, nullptr, tokens_out, nullptr, nullptr, (int)T,
+                               c.W, bc.eps, st));
     GemmEpilogue e;
     e.out_f32 = feats; e.ldc = c.D;
+    if (c.kind == 1) e.bias = params + t.proj_b;
     SPN_TRYV(gemm_nt(ln_cls, wb + t.bf16_proj_t, c.B, c.D, c.W, c.W, c.W, GEMM_STORE, e, st));
     (void)g;
     return SPN_OK;

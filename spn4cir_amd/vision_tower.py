@@ -23,7 +23,8 @@ def vision_cfg_from_state_dict(sd, prefix="visual."):
 
 
 class VisionTower:
-    def __init__(self, width, layers, heads, patch, res, embed_dim, device="cuda"):
+    def __init__(self, width, layers, heads, patch, res, embed_dim, device="cuda", kind=0):
+        self.kind = kind
         if heads * 64 != width:
             raise ValueError("CLIP ViT towers use head_dim 64 (clip/model.py:262)")
         self.width, self.layers, self.heads = width, layers, heads
@@ -37,10 +38,12 @@ class VisionTower:
         self._stale = True
 
     def _cfg(self, B):
-        return _lib.VisionCfg(B, self.res, self.patch, self.width, self.heads, self.layers, self.embed_dim)
+        return _lib.VisionCfg(B, self.res, self.patch, self.width, self.heads, self.layers, self.embed_dim, self.kind)
 
     def spans(self):
         lay, W, D, p = self._lay, self.width, self.embed_dim, self.patch
+        if self.kind == 1:
+            return self._blip_spans()
         out = [("conv1.weight", lay.conv1, (W, 3, p, p)), ("class_embedding", lay.cls, (W,)),
                ("positional_embedding", lay.pos, (int(lay.seq), W)), ("ln_pre.weight", lay.ln_pre_g, (W,)),
                ("ln_pre.bias", lay.ln_pre_b, (W,))]
@@ -51,6 +54,34 @@ class VisionTower:
                 out.append((f"transformer.resblocks.{l}.{key}", base + lay.block_off[j], shapes[j]))
         out += [("ln_post.weight", lay.ln_post_g, (W,)), ("ln_post.bias", lay.ln_post_b, (W,)), ("proj", lay.proj, (W, D))]
         return [(k, int(o), s) for k, o, s in out]
+
+    def _blip_spans(self):
+        """blip4cir/vit.py state-dict keys (visual_encoder.*) + `vision_proj_t` = vision_proj.weight^T [W, D]."""
+        lay, W, D, p = self._lay, self.width, self.embed_dim, self.patch
+        out = [("patch_embed.proj.weight", lay.conv1, (W, 3, p, p)), ("patch_embed.proj.bias", lay.conv_b, (W,)),
+               ("cls_token", lay.cls, (1, 1, W)), ("pos_embed", lay.pos, (1, int(lay.seq), W))]
+        names = ["norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                 "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"]
+        shapes = [(W,), (W,), (3 * W, W), (3 * W,), (W, W), (W,), (W,), (W,), (4 * W, W), (4 * W,), (W, 4 * W), (W,)]
+        for l in range(self.layers):
+            base = lay.blocks + lay.block_size * l
+            for j, key in enumerate(names):
+                out.append((f"blocks.{l}.{key}", base + lay.block_off[j], shapes[j]))
+        out += [("norm.weight", lay.ln_post_g, (W,)), ("norm.bias", lay.ln_post_b, (W,)),
+                ("vision_proj_t", lay.proj, (W, D)), ("vision_proj.bias", lay.proj_b, (D,))]
+        return [(k, int(o), s) for k, o, s in out]
+
+    def load_blip_state_dict(self, sd, prefix="visual_encoder.", proj_prefix="vision_proj."):
+        """BLIP_Retrieval state-dict: visual_encoder.* (vit.py) + vision_proj.{weight [D,W], bias}."""
+        with torch.no_grad():
+            for key, v in self.named_views().items():
+                if key == "vision_proj_t":
+                    v.copy_(sd[proj_prefix + "weight"].t().to(self.device, torch.float32))
+                elif key == "vision_proj.bias":
+                    v.copy_(sd[proj_prefix + "bias"].to(self.device, torch.float32))
+                else:
+                    v.copy_(sd[prefix + key].to(self.device, torch.float32))
+        self._stale = True
 
     def named_views(self):
         views = {}
@@ -67,8 +98,9 @@ class VisionTower:
                 v.copy_(sd[prefix + key].to(device=self.device, dtype=torch.float32))
         self._stale = True
 
-    def forward(self, image):
-        """fp32 [B, 3, res, res] (device) -> un-normalised features fp32 [B, D]."""
+    def forward(self, image, return_tokens=False):
+        """fp32 [B, 3, res, res] (device) -> un-normalised features fp32 [B, D] (and, for the BLIP ViT, the
+        normalised token sequence [B, S, W])."""
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.res or image.shape[3] != self.res:
             raise ValueError(f"expected [B,3,{self.res},{self.res}], got {tuple(image.shape)}")
         image = image.to(self.device, torch.float32).contiguous()
@@ -82,6 +114,9 @@ class VisionTower:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        tokens = None
+        if return_tokens:
+            tokens = torch.empty(B, int(self._lay.seq), self.width, dtype=torch.float32, device=self.device)
         check(lib().spn_vision_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(image), _p(self._ws),
-                                   self._ws.numel(), _p(feats), _stream()), "vision_fwd")
-        return feats
+                                   self._ws.numel(), _p(feats), _p(tokens), _stream()), "vision_fwd")
+        return (feats, tokens) if return_tokens else feats

@@ -54,3 +54,25 @@ def test_blip_fusion_step_matches_reference(golden_dir):
     torch.nn.functional.cross_entropy((qd @ torch.from_numpy(z["bank"]).double().T) / t,
                                       torch.from_numpy(z["labels"])).backward()
     assert abs(dtau.item() - t.grad.item()) < 5e-2 * abs(t.grad.item())
+
+
+def test_blip_vit_matches_oracle():
+    """blip4cir/vit.py image side (parity UNPINNED: the reference module is not importable offline; the oracle is a
+    restatement by reading, see oracle/blip_vit.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import blip_vit
+    from spn4cir_amd import ops
+    from spn4cir_amd.vision_tower import VisionTower
+    W, layers, patch, res, proj = 128, 2, 16, 64, 64
+    sd = blip_vit.synthetic_state_dict(W, layers, patch, res, proj)
+    vt = VisionTower(W, layers, W // 64, patch, res, proj, "cuda", kind=1)
+    vt.load_blip_state_dict(sd)
+    img = torch.randn(3, 3, res, res, generator=torch.Generator().manual_seed(5))
+    pooled_raw, tokens = vt.forward(img.cuda(), return_tokens=True)
+    pooled = ops.combine_l2norm_fwd(None, None, pooled_raw)[0]
+    tok_ref, pooled_ref = blip_vit.img_embed(sd, img, W // 64)
+    cos_t = torch.nn.functional.cosine_similarity(tokens.cpu().double().flatten(0, 1), tok_ref.double().flatten(0, 1), dim=-1)
+    assert (1 - cos_t).max() < 1e-3
+    cos_p = torch.nn.functional.cosine_similarity(pooled.cpu().double(), pooled_ref.double(), dim=-1)
+    assert (1 - cos_p).max() < 1e-3
