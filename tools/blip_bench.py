@@ -1,0 +1,73 @@
+"""BLIP4CIR stage-2 step throughput (BASELINE.json config 4 shape on ONE GPU): BERT-base fusion encoder
+(12 layers, 768, 12 heads, cross-attention over 577 image tokens), B=128, 32-token captions, 30 000 x 256 bank,
+tau 0.03, AdamW; reference token bank resident on the device in fp32 (a random [N_img, 577, 768] slab).
+
+    python tools/blip_bench.py [--enc-width 768|1024] [--steps 10]
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from spn4cir_amd import ops
+from spn4cir_amd.fusion import BlipBankStep, FusionEncoder
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--len", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=577)
+    ap.add_argument("--enc-width", type=int, default=768)
+    ap.add_argument("--bank", type=int, default=30000)
+    ap.add_argument("--images", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    enc = FusionEncoder(768, 12, 12, 3072, a.enc_width, 256, 30524, 512, dev)
+    with torch.no_grad():
+        for k, v in enc.named_views().items():
+            if k.endswith("LayerNorm.weight"):
+                v.fill_(1.0)
+            elif v.dim() >= 2:
+                v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(dev))
+    enc.mark_stale()
+    B, L = a.batch, a.len
+    ids = torch.randint(1000, 30522, (B, L), generator=g, dtype=torch.int32)
+    ids[:, 0] = 30523
+    lens = torch.randint(6, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int32)
+    ids = (ids * mask).to(dev); mask = mask.to(dev)
+    ref_bank = torch.randn(a.images, a.tokens, a.enc_width, device=dev)          # per-image token bank (models.py:76)
+    ridx = torch.randint(0, a.images, (B,), generator=g).to(dev)
+    bank = ops.prepare_bank(torch.nn.functional.normalize(torch.randn(a.bank, 256, generator=g)).to(dev))
+    labels = torch.randint(0, a.bank, (B,), generator=g).to(dev)
+    step = BlipBankStep(enc, tau=0.03)
+    m, v = torch.zeros_like(enc.params), torch.zeros_like(enc.params)
+
+    def one(i):
+        tokens = ref_bank[ridx]                                                  # [B, 577, E] gather (models.py:98)
+        loss, grads, dtau, q = step.step(ids, mask, tokens, bank, labels)
+        ops.adamw_step(enc.params, grads, m, v, i + 1, 5e-6, (0.9, 0.999), 1e-7, 0.01)
+        enc.mark_stale()
+        return loss
+
+    for i in range(a.warmup):
+        loss = one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one(a.warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    T, TS, W, I, E = B * L, B * a.tokens, 768, 3072, a.enc_width
+    fwd = 12 * (2 * T * W * 3 * W + 2 * T * W * W * 2 + 2 * TS * E * 2 * W + 2 * T * W * I * 2
+                + 4 * B * 12 * L * L * 64 + 4 * B * 12 * L * a.tokens * 64)
+    print(json.dumps({"workload": f"blip4cir stage-2 step, BERT-base fusion, B={B}, L={L}, {a.tokens} image tokens, "
+                                  f"enc_width {E}, bank {a.bank}x256", "triplets_per_s": round(B / dt, 1),
+                      "ms_per_step": round(dt * 1e3, 2), "loss": round(loss.item(), 4),
+                      "model_tflops": round(3 * fwd / dt / 1e12, 1), "params_M": round(enc.n_params / 1e6, 2)}))
+
+
+if __name__ == "__main__":
+    main()
