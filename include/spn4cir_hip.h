@@ -140,6 +140,11 @@ int spn_topk_from_scores(const double* scores, int Nq, int Ng, int K, const int3
  * that spn_text_refresh_bf16() rewrites after every optimizer step. */
 typedef struct {
     int B, L, L_ctx, W, H, layers, D, vocab;
+    /* T = 0: dense, every caption occupies L rows (what clip/model.py:345-358 computes).
+     * T > 0: packed, only the T = sum_b (eot_b + 1) live rows exist.  Rows after a caption's EOT token are dead
+     * under the causal mask (clip/model.py:330-336): they feed neither x[arange, argmax] (:356) nor any gradient,
+     * so dropping them changes no output.  Use spn_text_fwd_packed(); the other calls take the same cfg. */
+    int T;
 } spn_text_cfg;
 
 typedef struct {
@@ -155,6 +160,10 @@ size_t spn_text_ws_bytes(const spn_text_cfg* cfg);
 int spn_text_refresh_bf16(const spn_text_cfg* cfg, const float* params, void* weights_bf16, void* stream);
 int spn_text_fwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                  void* acts, float* feats, void* stream);
+/* cfg->T > 0; cu_seqlens = device int32 [B+1], cu[0] = 0, cu[b+1] - cu[b] = argmax_l ids[b, l] + 1, cu[B] = T.
+ * It is copied into acts, so the backward calls below need nothing extra.  L <= 128. */
+int spn_text_fwd_packed(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        const int32_t* cu_seqlens, void* acts, float* feats, void* stream);
 int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                  void* acts, const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
 /* The same backward in three phases (head, layers-1..0, tail) so a data-parallel host can start

@@ -17,7 +17,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 
 class TextCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "L", "L_ctx", "W", "H", "layers", "D", "vocab")]
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "L_ctx", "W", "H", "layers", "D", "vocab", "T")]
 
 
 class TextLayout(C.Structure):
@@ -84,6 +84,7 @@ _SIGS = {
     "spn_text_ws_bytes": (sz, [C.POINTER(TextCfg)]),
     "spn_text_refresh_bf16": (i32, [C.POINTER(TextCfg), vp, vp, vp]),
     "spn_text_fwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp]),
+    "spn_text_fwd_packed": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp]),
     "spn_text_bwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),

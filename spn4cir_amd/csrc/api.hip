@@ -188,7 +188,7 @@ int spn_topk_from_scores(const double* scores, int Nq, int Ng, int K, const int3
 static TextCfg tc(const spn_text_cfg* c) {
     TextCfg t;
     t.B = c->B; t.L = c->L; t.L_ctx = c->L_ctx; t.W = c->W; t.H = c->H; t.layers = c->layers; t.D = c->D;
-    t.vocab = c->vocab;
+    t.vocab = c->vocab; t.T = c->T;
     return t;
 }
 
@@ -209,7 +209,14 @@ int spn_text_refresh_bf16(const spn_text_cfg* cfg, const float* params, void* we
 int spn_text_fwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                  void* acts, float* feats, void* stream) {
     if (!cfg || !params || !weights_bf16 || !ids || !acts || !feats) return SPN_ERR_ARG;
-    return text_fwd(tc(cfg), params, CBF(weights_bf16), ids, (char*)acts, feats, ST(stream));
+    if (cfg->T != 0) return SPN_ERR_ARG;
+    return text_fwd(tc(cfg), params, CBF(weights_bf16), ids, nullptr, (char*)acts, feats, ST(stream));
+}
+
+int spn_text_fwd_packed(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        const int32_t* cu_seqlens, void* acts, float* feats, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !cu_seqlens || !acts || !feats || cfg->T <= 0) return SPN_ERR_ARG;
+    return text_fwd(tc(cfg), params, CBF(weights_bf16), ids, cu_seqlens, (char*)acts, feats, ST(stream));
 }
 
 int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,

@@ -178,7 +178,8 @@ static bool attn_force_flash() {
 int attention_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return SPN_ERR_ARG;
     if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return SPN_ERR_SHAPE;
-    if (attention_small_ok(a) && !attn_force_flash()) {
+    if (a.cu && !attention_small_ok(a)) return SPN_ERR_SHAPE;   // packed rows: whole-head kernels only
+    if (attention_small_ok(a) && (a.cu || !attn_force_flash())) {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         return attention_small_fwd(a, st);
     }
@@ -397,7 +398,8 @@ int attention_bwd(const AttnBwdArgs& g, hipStream_t st) {
         return SPN_ERR_SHAPE;
     const int n = a.B * a.Lq * a.H;
     ProfScope prof(PK_ATTN_BWD, 10.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
-    if (attention_small_ok(a) && !attn_force_flash()) return attention_small_bwd(g, st);
+    if (a.cu && !attention_small_ok(a)) return SPN_ERR_SHAPE;
+    if (attention_small_ok(a) && (a.cu || !attn_force_flash())) return attention_small_bwd(g, st);
     hipLaunchKernelGGL(attention_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)a.o, a.ldo, g.d_o,
                        g.lddo, g.delta, a.B, a.H, a.Lq);
     SPN_CHECK_LAUNCH();

@@ -80,11 +80,12 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     bf16_t* Ps = smem + 2 * KP * SLD + w * 16 * PLD;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int L = a.Lq;
-    const bf16_t* qb = a.q + (size_t)b * L * a.ldq + h * SHD;
-    const bf16_t* kb = a.k + (size_t)b * L * a.ldk + h * SHD;
-    const bf16_t* vb = a.v + (size_t)b * L * a.ldv + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * L : nullptr;
+    const int L = a.cu ? a.cu[b + 1] - a.cu[b] : a.Lq;                 // this sequence's length
+    const size_t row0 = a.cu ? (size_t)a.cu[b] : (size_t)b * a.Lq;     // its first row
+    const bf16_t* qb = a.q + row0 * a.ldq + h * SHD;
+    const bf16_t* kb = a.k + row0 * a.ldk + h * SHD;
+    const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
+    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
     load_rows<KP>(kb, a.ldk, L, tid, NT * 64, Ks);
     load_rows<KP>(vb, a.ldv, L, tid, NT * 64, Vs);
     const int q0 = w * 16, qrow = q0 + (lane & 15);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
     }
     if (qrow >= L) return;
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    bf16_t* orow = a.o + (size_t)(b * L + qrow) * a.ldo + h * SHD;
+    bf16_t* orow = a.o + (row0 + qrow) * a.ldo + h * SHD;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         bf16x4 ob;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
         for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[d][r] * inv);
         *(bf16x4*)(orow + d * 16 + (lane >> 4) * 4) = ob;
     }
-    if (a.lse && (lane >> 4) == 0) a.lse[((size_t)b * a.H + h) * L + qrow] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
+    if (a.lse && (lane >> 4) == 0)
+        a.lse[((size_t)b * a.H + h) * a.Lq + qrow] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
 }
 
 template <int NT>
@@ -175,12 +177,13 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     bf16_t* Dm = Pm + TR_ * PLD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
-    const int L = a.Lq;
-    const bf16_t* qb = a.q + (size_t)b * L * a.ldq + h * SHD;
-    const bf16_t* kb = a.k + (size_t)b * L * a.ldk + h * SHD;
-    const bf16_t* vb = a.v + (size_t)b * L * a.ldv + h * SHD;
-    const bf16_t* dob = g.d_o + (size_t)b * L * g.lddo + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * L : nullptr;
+    const int L = a.cu ? a.cu[b + 1] - a.cu[b] : a.Lq;
+    const size_t row0 = a.cu ? (size_t)a.cu[b] : (size_t)b * a.Lq;
+    const bf16_t* qb = a.q + row0 * a.ldq + h * SHD;
+    const bf16_t* kb = a.k + row0 * a.ldk + h * SHD;
+    const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
+    const bf16_t* dob = g.d_o + row0 * g.lddo + h * SHD;
+    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
     load_rows<TR_>(qb, a.ldq, L, tid, NT * 64, Qs);
     load_rows<TR_>(kb, a.ldk, L, tid, NT * 64, Ks);
     load_rows<TR_>(vb, a.ldv, L, tid, NT * 64, Vs);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
             }
         }
         if (row_ok) {
-            bf16_t* drow = g.dq + (size_t)(b * L + qrow) * g.lddq + h * SHD;
+            bf16_t* drow = g.dq + (row0 + qrow) * g.lddq + h * SHD;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf16x4 ob;
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
             }
         }
         if (key < L) {
-            bf16_t* dkrow = g.dk + (size_t)(b * L + key) * g.lddk + h * SHD;
-            bf16_t* dvrow = g.dv + (size_t)(b * L + key) * g.lddv + h * SHD;
+            bf16_t* dkrow = g.dk + (row0 + key) * g.lddk + h * SHD;
+            bf16_t* dvrow = g.dv + (row0 + key) * g.lddv + h * SHD;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf16x4 ok, ov;

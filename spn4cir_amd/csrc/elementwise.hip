@@ -280,6 +280,129 @@ int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx
     return SPN_OK;
 }
 
+// ------------------------------------------------------------------------- packed sequences
+// Dead-token elimination for the causal text tower: rows after the EOT token influence neither the pooled
+// feature nor any gradient, so only the cu[B] live rows are materialised (sequence b = rows cu[b]..cu[b+1]-1).
+__global__ void build_row_map_kernel(const int32_t* __restrict__ cu, int32_t* __restrict__ row_b,
+                                     int32_t* __restrict__ row_l, int32_t* __restrict__ eot_row) {
+    const int b = blockIdx.x, r0 = cu[b], n = cu[b + 1] - r0;
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        row_b[r0 + l] = b;
+        row_l[r0 + l] = l;
+    }
+    if (threadIdx.x == 0) eot_row[b] = r0 + n - 1;
+}
+
+int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st) {
+    hipLaunchKernelGGL(build_row_map_kernel, dim3(B), dim3(64), 0, st, cu, row_b, row_l, eot_row);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void embed_fwd_packed_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ row_b,
+                                        const int32_t* __restrict__ row_l, const float* __restrict__ tok,
+                                        const float* __restrict__ pos, float* __restrict__ x, int T, int L, int W,
+                                        int vocab) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)T * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        const int l = row_l[row];
+        int id = ids[(size_t)row_b[row] * L + l];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        *(f32x4*)(x + (size_t)row * W + c) = *(const f32x4*)(tok + (size_t)id * W + c) + *(const f32x4*)(pos + (size_t)l * W + c);
+    }
+}
+
+int embed_fwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const float* tok_emb,
+                     const float* pos_emb, float* x, int T, int L, int W, int vocab, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(embed_fwd_packed_kernel, dim3(grid_for((size_t)T * (W / 4))), dim3(256), 0, st, ids, row_b, row_l,
+                       tok_emb, pos_emb, x, T, L, W, vocab);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void embed_bwd_tok_packed_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ row_b,
+                                            const int32_t* __restrict__ row_l, const float* __restrict__ dx,
+                                            float* __restrict__ dtok, int T, int L, int W, int vocab) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)T * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        int id = ids[(size_t)row_b[row] * L + row_l[row]];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 g = *(const f32x4*)(dx + (size_t)row * W + c);
+        float* d = dtok + (size_t)id * W + c;
+        atomicAdd(d + 0, g[0]); atomicAdd(d + 1, g[1]); atomicAdd(d + 2, g[2]); atomicAdd(d + 3, g[3]);
+    }
+}
+
+__global__ void embed_bwd_pos_packed_kernel(const float* __restrict__ dx, const int32_t* __restrict__ cu,
+                                            float* __restrict__ dpos, int B, int W) {
+    const int l = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
+        f32x4 s = {0, 0, 0, 0};
+        for (int b = 0; b < B; ++b) {
+            const int r0 = cu[b];
+            if (l < cu[b + 1] - r0) s += *(const f32x4*)(dx + (size_t)(r0 + l) * W + c);
+        }
+        *(f32x4*)(dpos + (size_t)l * W + c) = s;
+    }
+}
+
+int embed_bwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const int32_t* cu, const float* dx,
+                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(embed_bwd_tok_packed_kernel, dim3(grid_for((size_t)T * (W / 4))), dim3(256), 0, st, ids, row_b,
+                       row_l, dx, dtok, T, L, W, vocab);
+    SPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(embed_bwd_pos_packed_kernel, dim3(L), dim3(256), 0, st, dx, cu, dpos, B, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void gather_rows_abs_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows,
+                                       float* __restrict__ out, int W) {
+    const int b = blockIdx.x;
+    const float* src = x + (size_t)rows[b] * W;
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) *(f32x4*)(out + (size_t)b * W + c) = *(const f32x4*)(src + c);
+}
+
+int gather_rows_abs(const float* x, const int32_t* rows, float* out, int B, int W, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_rows_abs_kernel, dim3(B), dim3(256), 0, st, x, rows, out, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void scatter_rows_abs_kernel(const float* __restrict__ src, const int32_t* __restrict__ row_b,
+                                        const int32_t* __restrict__ eot_row, float* __restrict__ dx,
+                                        bf16_t* __restrict__ dxb, int T, int W) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)T * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        const int b = row_b[row];
+        f32x4 v = {0, 0, 0, 0};
+        if (row == eot_row[b]) v = *(const f32x4*)(src + (size_t)b * W + c);
+        *(f32x4*)(dx + (size_t)row * W + c) = v;
+        if (dxb) {
+            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(dxb + (size_t)row * W + c) = o;
+        }
+    }
+}
+
+int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_row, float* dx, bf16_t* dx_bf16, int T,
+                     int W, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(scatter_rows_abs_kernel, dim3(grid_for((size_t)T * (W / 4))), dim3(256), 0, st, src, row_b, eot_row,
+                       dx, dx_bf16, T, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 // ---------------------------------------------------------------------------------- AdamW
 // torch.optim.AdamW semantics (decoupled weight decay), train_negplus.py:77-83.  g is
 // multiplied by inv_scale first (GradScaler unscale); the whole step is skipped when

@@ -38,44 +38,52 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ----------------------------------------------------------------------------------- NT
 // LDS image of a [rows][64 k] bf16 tile: row r at byte r*128, logical 16-B k-chunk c at
 // position c ^ ((r>>1)&7) (conflict-free for the 32-row ds_read_b128 fragments).
-__device__ __forceinline__ int nt2_swz(int r, int c) { return c ^ ((r >> 1) & 7); }
+// (BKT = 32: rows of 64 B, 4 chunks, position c ^ ((r>>2)&3) - 4 rows share a 256-B bank row.)
+template <int BKT>
+__device__ __forceinline__ int nt2_swz(int r, int c) {
+    return BKT == 64 ? (c ^ ((r >> 1) & 7)) : (c ^ ((r >> 2) & 3));
+}
 
-template <int PER_WAVE>
+template <int PER_WAVE, int BKT>
 __device__ __forceinline__ void nt2_stage(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0, int wid,
                                           int lane) {
+    constexpr int CPR = BKT / 8, RPI = 64 / CPR, ROWB = BKT * 2;   // chunks per row, rows per DMA instruction
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-        const int R0 = (wid * PER_WAVE + i) * 8;
-        const int r = R0 + (lane >> 3);
-        const int c = nt2_swz(r, lane & 7);
-        glds16(rs, sT + R0 * 128, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
+        const int R0 = (wid * PER_WAVE + i) * RPI;
+        const int r = R0 + lane / CPR;
+        const int c = nt2_swz<BKT>(r, lane % CPR);
+        glds16(rs, sT + R0 * ROWB, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
     }
 }
 
 // DMA instruction i (of PER_WAVE) of this wave only: lets the main loop spread a stage over its k steps
-template <int PER_WAVE>
+template <int PER_WAVE, int BKT>
 __device__ __forceinline__ void nt2_stage_one(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0, int wid,
                                               int lane, int i) {
-    const int R0 = (wid * PER_WAVE + i) * 8;
-    const int r = R0 + (lane >> 3);
-    const int c = nt2_swz(r, lane & 7);
-    glds16(rs, sT + R0 * 128, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
+    constexpr int CPR = BKT / 8, RPI = 64 / CPR, ROWB = BKT * 2;
+    const int R0 = (wid * PER_WAVE + i) * RPI;
+    const int r = R0 + lane / CPR;
+    const int c = nt2_swz<BKT>(r, lane % CPR);
+    glds16(rs, sT + R0 * ROWB, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
 }
 
+template <int BKT>
 __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
-    return *(const bf16x8*)(sT + r * 128 + (nt2_swz(r, c) << 4));
+    return *(const bf16x8*)(sT + r * (BKT * 2) + (nt2_swz<BKT>(r, c) << 4));
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD, int BKT>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M,
                                                                             int N, int K, int lda, int ldb,
                                                                             GemmEpilogue ep) {
     constexpr int NW = WM * WN;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;      // DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int KSTEPS = BKT / 16;
+    constexpr int GA = A_BYTES / 1024 / NW, GB = B_BYTES / 1024 / NW;      // DMA instructions per wave per stage
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
+    static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
@@ -91,11 +99,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = zero16();
 
-    const int nk = K / BK2;
+    const int nk = K / BKT;
     auto stage = [&](int kt, int buf) {
         char* s = smem + buf * STAGE;
-        nt2_stage<GA>(rsA, s, m0, lda, kt * BK2, wid, lane);
-        nt2_stage<GB>(rsB, s + A_BYTES, n0, ldb, kt * BK2, wid, lane);
+        nt2_stage<GA, BKT>(rsA, s, m0, lda, kt * BKT, wid, lane);
+        nt2_stage<GB, BKT>(rsB, s + A_BYTES, n0, ldb, kt * BKT, wid, lane);
     };
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -112,25 +120,25 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // of a SIMD would stall the matrix pipe together.
         const bool do_stage = kt + STAGES - 1 < nk;
         char* sF = smem + fill * STAGE;
-        const int kf = (kt + STAGES - 1) * BK2;
+        const int kf = (kt + STAGES - 1) * BKT;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KSTEPS; ++kk) {
             const int c = kk * 2 + (lane >> 5);
             bf16x8 a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = nt2_frag(sA, wr * TM + i * 32 + (lane & 31), c);
+            for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag(sB, wc * TN + j * 32 + (lane & 31), c);
+            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
             if (SPREAD) {
                 if (do_stage) {
 #pragma unroll
-                    for (int q = kk * ((GA + 3) / 4); q < (kk + 1) * ((GA + 3) / 4) && q < GA; ++q)
-                        nt2_stage_one<GA>(rsA, sF, m0, lda, kf, wid, lane, q);
+                    for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
+                        nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q);
 #pragma unroll
-                    for (int q = kk * ((GB + 3) / 4); q < (kk + 1) * ((GB + 3) / 4) && q < GB; ++q)
-                        nt2_stage_one<GB>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
+                    for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
+                        nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else if (kk == 0 && do_stage) {
@@ -256,11 +264,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD, int BKT>
 static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
                       hipStream_t st) {
-    constexpr int LDS = STAGES * (BM + BN) * 128;
-    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT, SPREAD>;
+    constexpr int LDS = STAGES * (BM + BN) * BKT * 2;
+    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT, SPREAD, BKT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -281,12 +289,12 @@ static bool gemm_spread() {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int BKT = 64>
 static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
                         const GemmEpilogue& ep, hipStream_t st) {
 #define SPN_NT2(MODE_, ACT_)                                                                       \
-    (gemm_spread() ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, true>(A, B, M, N, K, lda, ldb, ep, st) \
-                   : launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, false>(A, B, M, N, K, lda, ldb, ep, st))
+    (gemm_spread() ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, true, BKT>(A, B, M, N, K, lda, ldb, ep, st) \
+                   : launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, false, BKT>(A, B, M, N, K, lda, ldb, ep, st))
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) return SPN_NT2(GEMM_STORE, ACT_NONE);
         if (ep.act == ACT_QUICKGELU) return SPN_NT2(GEMM_STORE, ACT_QUICKGELU);
@@ -322,6 +330,7 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     switch (gemm_cfg()) {
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 4: return dispatch_nt2<256, 256, 2, 4, 4, 32>(A, B, M, N, K, lda, ldb, mode, e2, st);   // measured slower
         default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
     }
 }

@@ -54,6 +54,14 @@ int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st);
 int gather_rows_f32(const float* x, const int32_t* eot, float* out, int B, int L, int W, hipStream_t st);
 int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx_bf16, int B, int L, int W,
                      hipStream_t st);
+int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st);
+int embed_fwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const float* tok_emb,
+                     const float* pos_emb, float* x, int T, int L, int W, int vocab, hipStream_t st);
+int embed_bwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const int32_t* cu, const float* dx,
+                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, hipStream_t st);
+int gather_rows_abs(const float* x, const int32_t* rows, float* out, int B, int W, hipStream_t st);
+int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_row, float* dx, bf16_t* dx_bf16, int T,
+                     int W, hipStream_t st);
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                float wd, int step, float inv_scale, const float* found_inf, hipStream_t st);
 int grad_unscale_check(float* g, size_t n, float inv_scale, float* found_inf, hipStream_t st);
@@ -75,6 +83,9 @@ struct AttnArgs {
     const float* key_bias;           // optional additive bias per key [B, Lk] (BERT padding mask), may be null
     int B, H, Lq, Lk, causal;
     float scale;
+    // packed (variable-length) self-attention: sequence b occupies rows cu[b]..cu[b+1]-1 of q/k/v/o (Lq = Lk =
+    // the maximum length, used for the kernel geometry and the lse layout); nullptr = dense b*Lq rows
+    const int32_t* cu = nullptr;
 };
 struct AttnBwdArgs {
     AttnArgs f;

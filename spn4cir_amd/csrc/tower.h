@@ -8,6 +8,11 @@ namespace spn {
 struct BlockCfg {
     int B, L, W, H, causal, act;
     float eps;
+    // packed (variable-length) rows: T live rows in total, sequence b = rows cu[b]..cu[b+1]-1 (device pointer);
+    // T == 0 means the dense B*L layout
+    int T = 0;
+    const int32_t* cu = nullptr;
+    int rows() const { return T > 0 ? T : B * L; }
 };
 
 struct BlockParams {
@@ -36,6 +41,7 @@ struct BlockActs {
 
 struct TextCfg {       // == spn_text_cfg
     int B, L, L_ctx, W, H, layers, D, vocab;
+    int T;             // packed live rows (sum of the sequence lengths), 0 = dense B*L rows
 };
 
 struct TextLayout {    // == spn_text_layout_t (element offsets)
@@ -98,8 +104,9 @@ void text_layout(const TextCfg& c, TextLayout* t);
 size_t text_act_bytes(const TextCfg& c);
 size_t text_ws_bytes(const TextCfg& c);
 int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStream_t st);
-int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
-             hipStream_t st);
+// cu_seqlens: device [B+1] prefix sums of the live lengths (EOT position + 1), required iff c.T > 0
+int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* cu_seqlens,
+             char* acts, float* feats, hipStream_t st);
 int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
              const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
 int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,

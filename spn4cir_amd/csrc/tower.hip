@@ -71,7 +71,7 @@ int block_refresh_bf16(const float* p, bf16_t* wb, int W, hipStream_t st) {
 }
 
 size_t block_act_bytes(const BlockCfg& c) {
-    const size_t T = (size_t)c.B * c.L, W = c.W;
+    const size_t T = (size_t)c.rows(), W = c.W;
     size_t b = 0;
     b += align256(T * W * 4);                 // x_in
     b += 2 * align256(T * 4);                 // mean1, rstd1
@@ -87,7 +87,7 @@ size_t block_act_bytes(const BlockCfg& c) {
 }
 
 BlockActs block_acts_at(char* base, const BlockCfg& c) {
-    const size_t T = (size_t)c.B * c.L, W = c.W;
+    const size_t T = (size_t)c.rows(), W = c.W;
     BlockActs A;
     char* p = base;
     auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
@@ -110,7 +110,7 @@ BlockActs block_acts_at(char* base, const BlockCfg& c) {
 
 // scratch for one block's backward + the op workspaces (shared, used sequentially)
 size_t block_bwd_scratch_bytes(const BlockCfg& c) {
-    const size_t T = (size_t)c.B * c.L, W = c.W;
+    const size_t T = (size_t)c.rows(), W = c.W;
     size_t b = 0;
     b += align256(T * 4 * W * 2);   // dpre
     b += align256(T * W * 2);       // dh
@@ -121,7 +121,7 @@ size_t block_bwd_scratch_bytes(const BlockCfg& c) {
 }
 
 size_t block_op_ws_bytes(const BlockCfg& c) {
-    const int T = c.B * c.L, W = c.W;
+    const int T = c.rows(), W = c.W;
     size_t m = 0;
     auto mx = [&](size_t v) { if (v > m) m = v; };
     mx(gemm_tn_workspace_bytes(T, W, 4 * W));
@@ -135,7 +135,7 @@ size_t block_op_ws_bytes(const BlockCfg& c) {
 
 // -------------------------------------------------------------------------------- block
 int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st) {
-    const int T = c.B * c.L, W = c.W;
+    const int T = c.rows(), W = c.W;
     SPN_TRY(layernorm_fwd(A.x_in, P.ln1_g, P.ln1_b, A.h1, nullptr, A.mean1, A.rstd1, T, W, c.eps, st));
     {
         GemmEpilogue e;
@@ -147,7 +147,7 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
         a.q = A.qkv; a.k = A.qkv + W; a.v = A.qkv + 2 * W;
         a.ldq = a.ldk = a.ldv = 3 * W;
         a.o = A.attn; a.ldo = W; a.lse = A.lse; a.key_bias = nullptr;
-        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal;
+        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal; a.cu = c.cu;
         a.scale = 0.125f;
         SPN_TRY(attention_fwd(a, st));
     }
@@ -173,7 +173,7 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
 // dx / dx_bf16: gradient w.r.t. the block output on entry, w.r.t. the block input on exit.
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
               bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st) {
-    const int T = c.B * c.L, W = c.W;
+    const int T = c.rows(), W = c.W;
     const size_t Ts = (size_t)T;
     char* p = scratch;
     auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
@@ -211,7 +211,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         a.q = A.qkv; a.k = A.qkv + W; a.v = A.qkv + 2 * W;
         a.ldq = a.ldk = a.ldv = 3 * W;
         a.o = A.attn; a.ldo = W; a.lse = A.lse; a.key_bias = nullptr;
-        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal;
+        a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = c.causal; a.cu = c.cu;
         a.scale = 0.125f;
         g.d_o = dattn; g.lddo = W;
         g.dq = dqkv; g.dk = dqkv + W; g.dv = dqkv + 2 * W;
@@ -234,6 +234,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
 static BlockCfg text_block_cfg(const TextCfg& c) {
     BlockCfg b;
     b.B = c.B; b.L = c.L; b.W = c.W; b.H = c.H; b.causal = 1; b.act = ACT_QUICKGELU; b.eps = 1e-5f;
+    b.T = c.T;   // b.cu is filled in by the callers from the activation arena
     return b;
 }
 
@@ -255,9 +256,12 @@ void text_layout(const TextCfg& c, TextLayout* t) {
     t->n_bf16 = t->bf16_text_proj_t + (int64_t)c.W * c.D;
 }
 
-// activation arena: [eot][per-layer block acts][x_final][e][mean_f][rstd_f][ln_e]
+// activation arena: [eot][cu][row_b][row_l][eot_row][per-layer block acts][x_final][e][mean_f][rstd_f][ln_e]
+// Packed mode (c.T > 0): rows after each caption's EOT token are dead under the causal mask (they reach neither
+// the pooled feature nor any gradient), so only the T live rows exist; cu/row_b/row_l/eot_row describe them.
 struct TextActs {
     int32_t* eot;
+    int32_t *cu, *row_b, *row_l, *eot_row;
     char* blocks;
     size_t block_bytes;
     float* x_final;
@@ -268,8 +272,8 @@ struct TextActs {
 
 size_t text_act_bytes(const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
-    const size_t T = (size_t)c.B * c.L;
-    size_t b = align256((size_t)c.B * 4);
+    const size_t T = (size_t)bc.rows();
+    size_t b = 2 * align256((size_t)c.B * 4) + align256((size_t)(c.B + 1) * 4) + 2 * align256(T * 4);
     b += block_act_bytes(bc) * c.layers;
     b += align256(T * c.W * 4);
     b += align256((size_t)c.B * c.W * 4);
@@ -280,11 +284,15 @@ size_t text_act_bytes(const TextCfg& c) {
 
 static TextActs text_acts_at(char* base, const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
-    const size_t T = (size_t)c.B * c.L;
+    const size_t T = (size_t)bc.rows();
     TextActs A;
     char* p = base;
     auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
     A.eot = (int32_t*)take((size_t)c.B * 4);
+    A.cu = (int32_t*)take((size_t)(c.B + 1) * 4);
+    A.row_b = (int32_t*)take(T * 4);
+    A.row_l = (int32_t*)take(T * 4);
+    A.eot_row = (int32_t*)take((size_t)c.B * 4);
     A.block_bytes = block_act_bytes(bc);
     A.blocks = p; p += A.block_bytes * c.layers;
     A.x_final = (float*)take(T * c.W * 4);
@@ -297,7 +305,7 @@ static TextActs text_acts_at(char* base, const TextCfg& c) {
 
 size_t text_ws_bytes(const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
-    const size_t T = (size_t)c.B * c.L;
+    const size_t T = (size_t)bc.rows();
     size_t b = block_bwd_scratch_bytes(bc);
     b += align256(T * c.W * 4);              // dx
     b += align256(T * c.W * 2);              // dx_bf16
@@ -314,6 +322,8 @@ size_t text_ws_bytes(const TextCfg& c) {
 
 static int text_check(const TextCfg& c) {
     if (c.B <= 0 || c.L <= 0 || c.L > c.L_ctx || c.layers <= 0 || c.vocab <= 0) return SPN_ERR_ARG;
+    if (c.T < 0 || (c.T > 0 && (c.T < c.B || (int64_t)c.T > (int64_t)c.B * c.L))) return SPN_ERR_ARG;
+    if (c.T > 0 && c.L > 128) return SPN_ERR_SHAPE;   // packed rows need the whole-head attention kernels
     if (c.W % 64 || c.H * 64 != c.W || c.D % 64) return SPN_ERR_SHAPE;
     return SPN_OK;
 }
@@ -328,16 +338,27 @@ int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStre
     return SPN_OK;
 }
 
-int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
-             hipStream_t st) {
+int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* cu_seqlens,
+             char* acts, float* feats, hipStream_t st) {
     SPN_TRY(text_check(c));
+    if ((c.T > 0) != (cu_seqlens != nullptr)) return SPN_ERR_ARG;
     TextLayout t;
     text_layout(c, &t);
-    const BlockCfg bc = text_block_cfg(c);
+    BlockCfg bc = text_block_cfg(c);
     TextActs A = text_acts_at(acts, c);
-    SPN_TRY(eot_argmax(ids, A.eot, c.B, c.L, st));
     BlockActs first = block_acts_at(A.blocks, bc);
-    SPN_TRY(embed_fwd(ids, params + t.tok, params + t.pos, first.x_in, c.B, c.L, c.W, c.vocab, st));
+    if (c.T > 0) {
+        // the prefix sums live in the arena from here on, so the backward phases need no extra argument
+        hipError_t he = hipMemcpyAsync(A.cu, cu_seqlens, (size_t)(c.B + 1) * 4, hipMemcpyDeviceToDevice, st);
+        if (he != hipSuccess) return (int)he;
+        bc.cu = A.cu;
+        SPN_TRY(build_row_map(A.cu, A.row_b, A.row_l, A.eot_row, c.B, st));
+        SPN_TRY(embed_fwd_packed(ids, A.row_b, A.row_l, params + t.tok, params + t.pos, first.x_in, c.T, c.L, c.W, c.vocab,
+                                 st));
+    } else {
+        SPN_TRY(eot_argmax(ids, A.eot, c.B, c.L, st));
+        SPN_TRY(embed_fwd(ids, params + t.tok, params + t.pos, first.x_in, c.B, c.L, c.W, c.vocab, st));
+    }
     for (int l = 0; l < c.layers; ++l) {
         BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
         a.x_out = (l + 1 < c.layers) ? block_acts_at(A.blocks + A.block_bytes * (l + 1), bc).x_in : A.x_final;
@@ -345,7 +366,8 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
         SPN_TRY(block_fwd(bc, P, a, st));
     }
     // ln_final is per-row, so pooling the EOT row first is identical to clip/model.py:352-356
-    SPN_TRY(gather_rows_f32(A.x_final, A.eot, A.e, c.B, c.L, c.W, st));
+    if (c.T > 0) SPN_TRY(gather_rows_abs(A.x_final, A.eot_row, A.e, c.B, c.W, st));
+    else SPN_TRY(gather_rows_f32(A.x_final, A.eot, A.e, c.B, c.L, c.W, st));
     SPN_TRY(layernorm_fwd(A.e, params + t.lnf_g, params + t.lnf_b, A.ln_e, nullptr, A.mean_f, A.rstd_f, c.B, c.W, 1e-5f,
                           st));
     GemmEpilogue e;
@@ -368,7 +390,7 @@ struct TextBwdWs {
 static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w) {
     if (ws_bytes < text_ws_bytes(c)) return SPN_ERR_WORKSPACE;
     const BlockCfg bc = text_block_cfg(c);
-    const size_t T = (size_t)c.B * c.L;
+    const size_t T = (size_t)bc.rows();
     char* p = ws;
     auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
     w->scratch = p; p += block_bwd_scratch_bytes(bc);
@@ -400,7 +422,8 @@ int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char*
     }
     SPN_TRY(layernorm_bwd(nullptr, w.dln, A.e, params + t.lnf_g, A.mean_f, A.rstd_f, w.de, 0, nullptr, grads + t.lnf_g,
                           grads + t.lnf_b, 0, c.B, c.W, w.opws, w.opws_bytes, st));
-    SPN_TRY(scatter_rows_f32(w.de, A.eot, w.dx, w.dxb, c.B, c.L, c.W, st));
+    if (c.T > 0) SPN_TRY(scatter_rows_abs(w.de, A.row_b, A.eot_row, w.dx, w.dxb, c.T, c.W, st));
+    else SPN_TRY(scatter_rows_f32(w.de, A.eot, w.dx, w.dxb, c.B, c.L, c.W, st));
     return SPN_OK;
 }
 
@@ -413,8 +436,9 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
     TextLayout t;
     text_layout(c, &t);
-    const BlockCfg bc = text_block_cfg(c);
+    BlockCfg bc = text_block_cfg(c);
     TextActs A = text_acts_at(acts, c);
+    if (c.T > 0) bc.cu = A.cu;
     BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
     const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
@@ -432,7 +456,10 @@ int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads
     TextActs A = text_acts_at(acts, c);
     hipError_t he = hipMemsetAsync(grads + t.tok, 0, (size_t)c.vocab * c.W * sizeof(float), st);
     if (he != hipSuccess) return (int)he;
-    SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
+    if (c.T > 0)
+        SPN_TRY(embed_bwd_packed(ids, A.row_b, A.row_l, A.cu, w.dx, grads + t.tok, grads + t.pos, c.T, c.B, c.L, c.W, c.vocab,
+                                 st));
+    else SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
     if (c.L < c.L_ctx) {
         he = hipMemsetAsync(grads + t.pos + (size_t)c.L * c.W, 0, (size_t)(c.L_ctx - c.L) * c.W * sizeof(float), st);
         if (he != hipSuccess) return (int)he;

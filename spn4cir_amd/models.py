@@ -57,10 +57,14 @@ def _attach(root, dotted, param):
 class CIRPlus(nn.Module):
     def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
                  device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
-                 tokenizer=None):
+                 tokenizer=None, pack_eot=False):
         """`clip_model_name`: path to a CLIP state-dict file (as clip.load accepts, clip/clip.py:120-123),
-        a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline)."""
+        a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline).
+        `pack_eot`: run the text tower on the live rows only (everything after a caption's EOT token is dead
+        under the causal mask); same loss and gradients, ~L/mean_len fewer rows."""
         super().__init__()
+        self.pack_eot = bool(pack_eot)
+        self._pack = (None, 0)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("spn4cir_amd.CIRPlus runs on an MI355X (device='cuda'); there is no CPU path")
@@ -228,7 +232,10 @@ class CIRPlus(nn.Module):
 
     # -------------------------------------------------------------------------- encoders
     def tokenize(self, text):
+        self._pack = (None, 0)
         if torch.is_tensor(text):
+            if self.pack_eot and not text.is_cuda:
+                self._set_pack(text)
             return text.to(self.device, torch.int32).contiguous()
         if self.tokenizer is None:
             from .tokenizer import tokenize as clip_tokenize      # clip.tokenize (clip/clip.py:206-247)
@@ -236,7 +243,14 @@ class CIRPlus(nn.Module):
         ids = self.tokenizer(text)
         if int(ids.max()) >= self.tower.vocab:
             raise RuntimeError(f"token id {int(ids.max())} outside the model's vocabulary ({self.tower.vocab})")
+        if self.pack_eot:
+            self._set_pack(ids)
         return ids.to(self.device, torch.int32).contiguous()
+
+    def _set_pack(self, ids_host):
+        """pack_eot: the ids are still on the host here, so the live lengths cost no device sync."""
+        cu, total = self.tower.cu_seqlens(ids_host)
+        self._pack = (cu.to(self.device), total)
 
     def encode_image(self, image):
         """fp32 [B, 3, res, res] -> un-normalised image features [B, D] (models_negplus.py:39-41)."""
@@ -247,7 +261,8 @@ class CIRPlus(nn.Module):
 
     def encode_text(self, text):
         """list[str] (or pre-tokenised ids) -> un-normalised text features [B, D] (models_negplus.py:43-46)."""
-        return self.tower.forward(self.tokenize(text))
+        ids = self.tokenize(text)
+        return self.tower.forward(ids, *self._pack)
 
     def element_wise_sum(self, refer_image_feats, text_feats):
         return refer_image_feats + text_feats        # models_negplus.py:48-50
@@ -262,7 +277,7 @@ class CIRPlus(nn.Module):
 
     def _step_forward(self, ids, refer_idx, labels):
         bank_dev = self._target_bank_dev
-        feats = self.tower.forward(ids)
+        feats = self.tower.forward(ids, *self._pack)
         q, qb, inv = ops.combine_l2norm_fwd(self._refer_f32, refer_idx, feats)
         M = bank_dev.shape[0]
         stats = ops.bank_stats_fwd(qb, bank_dev, labels, 1.0 / self.tau)

@@ -44,11 +44,12 @@ class TextTower:
         self._acts_key = None
         self._ws = None
         self._last = None
+        self._last_T = 0
         self._stale = True
 
     # ------------------------------------------------------------------ layout
-    def _cfg(self, B, L):
-        return _lib.TextCfg(B, L, self.ctx, self.width, self.heads, self.layers, self.embed_dim, self.vocab)
+    def _cfg(self, B, L, T=0):
+        return _lib.TextCfg(B, L, self.ctx, self.width, self.heads, self.layers, self.embed_dim, self.vocab, T)
 
     def spans(self):
         """[(clip state-dict key, offset, shape)] in flat-buffer order."""
@@ -99,8 +100,8 @@ class TextTower:
         self._stale = True
 
     # ------------------------------------------------------------------ compute
-    def _buffers(self, B, L, need_ws):
-        cfg = self._cfg(B, L)
+    def _buffers(self, B, L, need_ws, T=0):
+        cfg = self._cfg(B, L)      # arenas are sized for the dense layout, which bounds every packed one
         if self._acts_key != (B, L):
             self._acts = None
             self._acts = torch.empty(lib().spn_text_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
@@ -108,20 +109,41 @@ class TextTower:
             self._ws = None
         if need_ws and self._ws is None:
             self._ws = torch.empty(lib().spn_text_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-        return cfg
+        return self._cfg(B, L, T) if T else cfg
 
-    def forward(self, ids):
-        """ids int32 [B, L] on device -> fp32 [B, D]; activations are kept for backward()."""
+    @staticmethod
+    def cu_seqlens(ids_host):
+        """Host helper for the packed mode: int32 [B+1] prefix sums of the live lengths (EOT position + 1,
+        EOT = argmax of the ids as in clip/model.py:356) of a CPU id matrix, and their total."""
+        ids_host = torch.as_tensor(ids_host)
+        lens = ids_host.argmax(dim=-1).to(torch.int64) + 1
+        cu = torch.zeros(ids_host.shape[0] + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        return cu, int(cu[-1])
+
+    def forward(self, ids, cu_seqlens=None, total_rows=0):
+        """ids int32 [B, L] on device -> fp32 [B, D]; activations are kept for backward().
+
+        cu_seqlens (device int32 [B+1]) + total_rows select the packed mode: only the rows up to each caption's
+        EOT token are computed (the rest is dead under the causal mask), same features and gradients."""
         if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
             raise ValueError("ids must be a contiguous int32 device tensor")
         B, L = ids.shape
         if self._stale:
             self.refresh()
-        cfg = self._buffers(B, L, False)
+        T = int(total_rows) if cu_seqlens is not None else 0
+        cfg = self._buffers(B, L, False, T)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
-        check(lib().spn_text_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(feats),
-                                 _stream()), "text_fwd")
+        if cu_seqlens is not None:
+            if cu_seqlens.dtype != torch.int32 or not cu_seqlens.is_cuda or cu_seqlens.numel() != B + 1 or T <= 0:
+                raise ValueError("cu_seqlens must be a device int32 [B+1] tensor and total_rows its last entry")
+            check(lib().spn_text_fwd_packed(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(cu_seqlens),
+                                            _p(self._acts), _p(feats), _stream()), "text_fwd_packed")
+        else:
+            check(lib().spn_text_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(feats),
+                                     _stream()), "text_fwd")
         self._last = ids
+        self._last_T = T
         return feats
 
     def backward(self, dfeats):
@@ -130,7 +152,7 @@ class TextTower:
         if ids is None:
             raise RuntimeError("backward() without a preceding forward()")
         B, L = ids.shape
-        cfg = self._buffers(B, L, True)
+        cfg = self._buffers(B, L, True, self._last_T)
         dfeats = dfeats.contiguous()
         check(lib().spn_text_bwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(dfeats),
                                  _p(self.grads), _p(self._ws), self._ws.numel(), _stream()), "text_bwd")
@@ -144,7 +166,7 @@ class TextTower:
         if ids is None:
             raise RuntimeError("backward_phased() without a preceding forward()")
         B, L = ids.shape
-        cfg = self._buffers(B, L, True)
+        cfg = self._buffers(B, L, True, self._last_T)
         dfeats = dfeats.contiguous()
         ws, n = _p(self._ws), self._ws.numel()
         spans = self.layer_spans()

@@ -46,11 +46,12 @@ class Stage2Trainer:
             self._m_begin = 0
             self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32))
 
-    def step(self, ids, refer_idx, labels):
+    def step(self, ids, refer_idx, labels, cu_seqlens=None, total_rows=0):
         """ids int32 [B_local, L], refer_idx / labels int64 [B_local] (device). Returns the global mean
-        loss as a 1-element device tensor."""
+        loss as a 1-element device tensor.  cu_seqlens / total_rows (TextTower.cu_seqlens of the host ids,
+        uploaded) switch the text tower to its packed mode: same result, only live rows computed."""
         t = self.tower
-        feats = t.forward(ids)
+        feats = t.forward(ids, cu_seqlens, total_rows)
         q, qb, inv = ops.combine_l2norm_fwd(self._refer, refer_idx, feats)
         ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / self.model.tau,
                                    self.model.label_smoothing)

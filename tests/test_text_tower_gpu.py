@@ -91,3 +91,72 @@ def test_adamw_on_flat_buffer_and_refresh(golden_dir):
     t.mark_stale()
     f1 = t.forward(ids)
     assert (f1 - f0).abs().max() > 1e-4          # the bf16 mirrors were refreshed from the new weights
+
+
+def _packed_vs_dense(t, ids_host, dfeats):
+    ids = ids_host.cuda()
+    f_dense = t.forward(ids).clone()
+    g_dense = t.backward(dfeats).clone()
+    cu, total = t.cu_seqlens(ids_host)
+    f_pack = t.forward(ids, cu.cuda(), total).clone()
+    g_pack = t.backward(dfeats).clone()
+    return f_dense, g_dense, f_pack, g_pack, total
+
+
+def test_packed_rows_equal_dense_on_golden_ids(golden_dir):
+    """Packed mode drops the rows after each caption's EOT token; they are dead under the causal mask
+    (clip/model.py:330-336,356), so features and every parameter gradient must not move.  Per-row arithmetic is
+    unchanged (features: 1e-6 absolute); weight gradients sum over rows in a different split, hence 1e-3
+    relative L2 per parameter.  Also re-checked against the reference's golden features."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    z, sd = _tiny(golden_dir)
+    t = _tower(sd)
+    ids_host = torch.from_numpy(z["ids"])
+    torch.manual_seed(3)
+    dfeats = torch.randn(ids_host.shape[0], t.embed_dim, device="cuda")
+    f_dense, g_dense, f_pack, g_pack, total = _packed_vs_dense(t, ids_host, dfeats)
+    assert total < ids_host.numel()
+    assert (f_pack - f_dense).abs().max() < 1e-6
+    ref = torch.from_numpy(z["text_feats"])
+    assert (1 - cosine(f_pack.cpu(), ref)).max() < 1e-3
+    vd, vp = t.named_views(g_dense), t.named_views(g_pack)
+    for key in vd:
+        err = ((vp[key] - vd[key]).norm() / vd[key].norm().clamp_min(1e-12)).item()
+        assert err < 1e-3, (key, err)
+
+
+@pytest.mark.parametrize("B,L,lens", [(48, 77, "random"), (5, 77, "full"), (7, 33, "one")])
+def test_packed_rows_ragged_cases(B, L, lens):
+    """Ragged lengths incl. the extremes: every caption full-length (packing is the identity) and
+    every caption a single token (EOT at position 0)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import clip_text
+    from spn4cir_amd.text_tower import TextTower
+    W, H, layers, D, vocab = 256, 4, 2, 128, 1000
+    sd = clip_text.synthetic_text_state_dict(width=W, layers=layers, embed_dim=D, vocab=vocab, ctx=77, seed=5)
+    t = TextTower(W, layers, H, D, vocab, 77, "cuda")
+    t.load_clip_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    ids_host = torch.randint(1, vocab - 2, (B, L), generator=g, dtype=torch.int32)
+    if lens == "random":
+        eot = torch.randint(0, L, (B,), generator=g)
+    elif lens == "full":
+        eot = torch.full((B,), L - 1)
+    else:
+        eot = torch.zeros(B, dtype=torch.int64)
+    for b in range(B):
+        ids_host[b, eot[b]] = vocab - 1          # the unique maximum = EOT (clip/model.py:356)
+        ids_host[b, eot[b] + 1:] = 0
+    dfeats = torch.randn(B, D, generator=g).cuda()
+    f_dense, g_dense, f_pack, g_pack, total = _packed_vs_dense(t, ids_host, dfeats)
+    assert total == int((eot + 1).sum())
+    assert (f_pack - f_dense).abs().max() < 1e-6
+    vd, vp = t.named_views(g_dense), t.named_views(g_pack)
+    for key in vd:
+        err = ((vp[key] - vd[key]).norm() / vd[key].norm().clamp_min(1e-12)).item()
+        assert err < 1e-3, (key, err)
+    # and against the CPU oracle's features (bf16 GEMM operands vs fp32: north_star's 1e-3 cosine)
+    ref = clip_text.encode_text(sd, ids_host.long())
+    assert (1 - cosine(f_pack.cpu(), ref)).max() < 1e-3
