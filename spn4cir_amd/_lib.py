@@ -8,7 +8,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspn4cir_hip.so")
+# SPN_LIB_PATH: load an experimental build of the same C-ABI instead (kernel A/B runs, tools/build_variant.sh)
+LIB_PATH = os.environ.get("SPN_LIB_PATH") or os.path.join(_HERE, "libspn4cir_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "spn4cir_hip.h")
 
 _lib = None

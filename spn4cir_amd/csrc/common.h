@@ -59,8 +59,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 }
 
 // 16-byte async global->LDS copy: LDS destination = lds_base (wave-uniform) + lane*16.
+#ifndef SPN_GLDS_AUX
+#define SPN_GLDS_AUX 0   // cache-policy bits of the DMA (1 = sc0, 2 = nt, 16 = sc1)
+#endif
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, uint32_t voffset_bytes) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset_bytes, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset_bytes, 0, 0, SPN_GLDS_AUX);
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -18,6 +18,15 @@
 namespace spn {
 
 static constexpr int BK2 = 64;
+#ifndef SPN_NT2_ROLE
+#define SPN_NT2_ROLE 0
+#endif
+#ifndef SPN_NT2_PIPE
+#define SPN_NT2_PIPE 0
+#endif
+#ifndef SPN_NT2_REGSTAGE
+#define SPN_NT2_REGSTAGE 0
+#endif
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -60,12 +69,28 @@ __device__ __forceinline__ void nt2_stage(__amdgpu_buffer_rsrc_t rs, char* sT, i
 // DMA instruction i (of PER_WAVE) of this wave only: lets the main loop spread a stage over its k steps
 template <int PER_WAVE, int BKT>
 __device__ __forceinline__ void nt2_stage_one(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0, int wid,
-                                              int lane, int i) {
+                                              int lane, int i, int noswz = 0) {
     constexpr int CPR = BKT / 8, RPI = 64 / CPR, ROWB = BKT * 2;
     const int R0 = (wid * PER_WAVE + i) * RPI;
     const int r = R0 + lane / CPR;
-    const int c = nt2_swz<BKT>(r, lane % CPR);
+    const int c = noswz ? lane % CPR : nt2_swz<BKT>(r, lane % CPR);
     glds16(rs, sT + R0 * ROWB, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
+}
+
+// register-staged variant of one DMA piece: the same 16 B per lane, but global -> VGPR now and VGPR -> LDS later
+template <int PER_WAVE, int BKT>
+__device__ __forceinline__ u32x4 nt2_gload(__amdgpu_buffer_rsrc_t rs, int row0, int ld, int k0, int wid, int lane, int i) {
+    constexpr int CPR = BKT / 8, RPI = 64 / CPR;
+    const int R0 = (wid * PER_WAVE + i) * RPI;
+    const int r = R0 + lane / CPR;
+    const int c = nt2_swz<BKT>(r, lane % CPR);
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u, 0, 0);
+}
+template <int PER_WAVE, int BKT>
+__device__ __forceinline__ void nt2_lstore(char* sT, int wid, int lane, int i, u32x4 v) {
+    constexpr int CPR = BKT / 8, RPI = 64 / CPR, ROWB = BKT * 2;
+    const int R0 = (wid * PER_WAVE + i) * RPI;
+    *(u32x4*)(sT + R0 * ROWB + lane * 16) = v;
 }
 
 template <int BKT>
@@ -105,6 +130,64 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         nt2_stage<GA, BKT>(rsA, s, m0, lda, kt * BKT, wid, lane);
         nt2_stage<GB, BKT>(rsB, s + A_BYTES, n0, ldb, kt * BKT, wid, lane);
     };
+    if constexpr (SPN_NT2_REGSTAGE && STAGES == 2) {
+    // Register-staged operand pipeline (needs STAGES == 2): piece q of tile kt+2 is loaded global -> VGPR right
+    // after piece q of tile kt+1 has been written VGPR -> LDS, so every piece has one whole k step to land and
+    // the wait before its ds_write is a counted vmcnt on the oldest load only.
+    u32x4 g[GA + GB];
+    if (nk > 0) {
+#pragma unroll
+        for (int q = 0; q < GA; ++q) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, 0, wid, lane, q);
+#pragma unroll
+        for (int q = 0; q < GB; ++q) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, 0, wid, lane, q);
+#pragma unroll
+        for (int q = 0; q < GA; ++q) nt2_lstore<GA, BKT>(smem, wid, lane, q, g[q]);
+#pragma unroll
+        for (int q = 0; q < GB; ++q) nt2_lstore<GB, BKT>(smem + A_BYTES, wid, lane, q, g[GA + q]);
+    }
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < GA; ++q) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, BKT, wid, lane, q);
+#pragma unroll
+        for (int q = 0; q < GB; ++q) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, BKT, wid, lane, q);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile kt is visible in slot kt&1; nobody reads slot (kt+1)&1 any more
+        const char* sA = smem + (kt & 1) * STAGE;
+        const char* sB = sA + A_BYTES;
+        char* sF = smem + ((kt + 1) & 1) * STAGE;
+        const bool do_wr = kt + 1 < nk, ld2 = kt + 2 < nk;
+        const int kf = (kt + 2) * BKT;
+        bf16x8 a[MI], b[NJ];
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int c = kk * 2 + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
+            if (do_wr) {
+#pragma unroll
+                for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q) {
+                    nt2_lstore<GA, BKT>(sF, wid, lane, q, g[q]);
+                    if (ld2) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, kf, wid, lane, q);
+                }
+#pragma unroll
+                for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q) {
+                    nt2_lstore<GB, BKT>(sF + A_BYTES, wid, lane, q, g[GA + q]);
+                    if (ld2) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, kf, wid, lane, q);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) stage(s, s);
@@ -118,28 +201,97 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // The DMA of tile kt+STAGES-1 is spread over the four k16 steps (after each step's LDS reads,
         // before its MFMAs) instead of being issued as one burst behind the barrier, where both waves
         // of a SIMD would stall the matrix pipe together.
-        const bool do_stage = kt + STAGES - 1 < nk;
+        const bool do_stage = kt + STAGES - 1 < nk && !(ep.dbg & 2);
         char* sF = smem + fill * STAGE;
-        const int kf = (kt + STAGES - 1) * BKT;
+        const int kf = (ep.dbg & 1) ? 0 : (kt + STAGES - 1) * BKT;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_BYTES;
+#if SPN_NT2_PIPE
+        // Software-pipelined fragments: the LDS reads of k16 step kk+1 (and this step's share of the next tile's
+        // DMA) are issued BEFORE the MFMAs of step kk, whose operands were read one step earlier.
+        bf16x8 a[2][MI], b[2][NJ];
+        {
+            const int c = lane >> 5;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[0][i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[0][j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk + 1 < KSTEPS) {
+                const int c = (kk + 1) * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[nb][i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[nb][j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
+            }
+            if (do_stage) {
+#pragma unroll
+                for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
+                    nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q);
+#pragma unroll
+                for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
+                    nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
+            }
+#if SPN_NT2_PIPE == 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[cb][j], a[cb][i], acc[i][j]);
+#if SPN_NT2_PIPE == 1
+            __builtin_amdgcn_sched_barrier(0);
+#elif SPN_NT2_PIPE == 2
+            // interleave: one memory instruction in the shadow of each MFMA
+#pragma unroll
+            for (int t = 0; t < MI + NJ; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+#endif
+        }
+#else
+        bf16x8 a[MI], b[NJ];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int c = kk * 2 + (lane >> 5);
-            bf16x8 a[MI], b[NJ];
+            if (!(ep.dbg & 4) || kk == 0) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
+                for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
+                for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
+            }
             if (SPREAD) {
+#if SPN_NT2_ROLE
+                // role split: in k step kt only the waves of one half (wid>>2 == kt&1; waves w and w+4 share a
+                // SIMD) issue the DMA of the next tile, all of it; their SIMD partners issue none, so the matrix
+                // pipe never has both of its waves parked in VMEM issue at once.
+                if (do_stage && ((wid >> 2) == (kt & 1))) {
+                    constexpr int GA2 = GA * 2, GB2 = GB * 2;
+#pragma unroll
+                    for (int q = kk * ((GA2 + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA2 + KSTEPS - 1) / KSTEPS) && q < GA2; ++q)
+                        nt2_stage_one<GA2, BKT>(rsA, sF, m0, lda, kf, wid & 3, lane, q);
+#pragma unroll
+                    for (int q = kk * ((GB2 + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB2 + KSTEPS - 1) / KSTEPS) && q < GB2; ++q)
+                        nt2_stage_one<GB2, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid & 3, lane, q);
+                }
+#else
                 if (do_stage) {
 #pragma unroll
                     for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
-                        nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q);
+                        nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q, ep.dbg & 16);
 #pragma unroll
                     for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
-                        nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
+                        nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q, ep.dbg & 16);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             } else if (kk == 0 && do_stage) {
                 stage(kt + STAGES - 1, fill);
@@ -150,26 +302,44 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
             if (SPREAD) __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
 
+    }
     // Epilogue.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3, the 4
     // consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
     // Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
     // first staged through LDS (fp32, 16-B units XOR-swizzled by row) and the epilogue math + all
     // global traffic run row-major: one wave instruction = one or two whole rows, fully coalesced.
+    if (ep.dbg & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 12345.678f && ep.out_f32) ep.out_f32[0] = t;
+        return;
+    }
     if (!ep.direct_store) {
         constexpr int LDS_BYTES = STAGES * STAGE;
         constexpr int CR0 = LDS_BYTES / (BN * 4);
         constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;     // rows per staging pass
         constexpr int NCH = (BM + CHUNK - 1) / CHUNK;
-        constexpr int LPR = BN / 4, RPI = 64 / LPR;                 // lanes per row, rows per wave instruction
+        // a lane owns 8 consecutive columns of a row: bf16 traffic moves 16 B per lane (the store path is
+        // issue-bound, so half as many, twice as wide instructions), fp32 traffic as two 16-B accesses
+        constexpr int LPR = BN / 8, RPI = 64 / LPR;                 // lanes per row, rows per wave instruction
         static_assert(LPR <= 64 && 64 % LPR == 0, "row mapping");
         float* sC = (float*)smem;
-        const int u = lane % LPR, n = n0 + u * 4;
-        f32x4 bias4 = {0, 0, 0, 0};
-        if (ep.bias && n < N) bias4 = *(const f32x4*)(ep.bias + n);
+        const int u = lane % LPR, n = n0 + u * 8;
+        const bool hi = n + 4 < N;                                  // N % 4 == 0: each half is all in or all out
+        const bool wide = hi && (ep.ldc % 8 == 0);
+        f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
+        if (ep.bias && n < N) bias_lo = *(const f32x4*)(ep.bias + n);
+        if (ep.bias && hi) bias_hi = *(const f32x4*)(ep.bias + n + 4);
         for (int ch = 0; ch < NCH; ++ch) {
             __syncthreads();   // operand tiles (or the previous chunk) are no longer read
 #pragma unroll
@@ -190,33 +360,63 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             for (int rr = wid * RPI + lane / LPR; rr < CHUNK; rr += NW * RPI) {
                 const int m = m0 + ch * CHUNK + rr;
                 if (m >= M || n >= N) continue;
-                f32x4 v = *(const f32x4*)(sC + rr * BN + ((u ^ (rr & 15)) << 2));
-                v = v * ep.alpha + bias4;
+                f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
+                f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
+                v0 = v0 * ep.alpha + bias_lo;
+                v1 = v1 * ep.alpha + bias_hi;
                 const size_t o = (size_t)m * ep.ldc + n;
+                auto pack8 = [](f32x4 x, f32x4 y) {
+                    bf16x8 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+                    return p;
+                };
+                auto store_bf16 = [&](bf16_t* dst, f32x4 x, f32x4 y) {
+                    if (wide) {
+                        *(bf16x8*)(dst + o) = pack8(x, y);
+                    } else {
+                        bf16x4 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+                        *(bf16x4*)(dst + o) = p;
+                        if (hi) {
+                            bf16x4 q = {f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+                            *(bf16x4*)(dst + o + 4) = q;
+                        }
+                    }
+                };
                 if constexpr (MODE == GEMM_STORE) {
                     if constexpr (ACT != ACT_NONE) {
-                        if (ep.aux_out) {
-                            bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                            *(bf16x4*)(ep.aux_out + o) = p;
-                        }
+                        if (ep.aux_out) store_bf16(ep.aux_out, v0, v1);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                        }
                     }
                 } else if constexpr (MODE == GEMM_RESID) {
-                    v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
+                    const float* rp = ep.resid + (size_t)m * ep.ldr + n;
+                    v0 += *(const f32x4*)rp;
+                    if (hi) v1 += *(const f32x4*)(rp + 4);
                 } else if constexpr (MODE == GEMM_DACT) {
-                    const bf16x4 p = *(const bf16x4*)(ep.aux_in + o);
+                    bf16x8 p;
+                    if (wide) {
+                        p = *(const bf16x8*)(ep.aux_in + o);
+                    } else {
+                        const bf16x4 p0 = *(const bf16x4*)(ep.aux_in + o);
+                        bf16x4 p1 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                        if (hi) p1 = *(const bf16x4*)(ep.aux_in + o + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { p[e] = p0[e]; p[4 + e] = p1[e]; }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = bf2f(p[e]);
-                        v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                        const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
+                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
+                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
                     }
                 }
-                if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
-                if (ep.out_bf16) {
-                    bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *(bf16x4*)(ep.out_bf16 + o) = p;
+                if (ep.out_f32) {
+                    *(f32x4*)(ep.out_f32 + o) = v0;
+                    if (hi) *(f32x4*)(ep.out_f32 + o + 4) = v1;
                 }
+                if (ep.out_bf16) store_bf16(ep.out_bf16, v0, v1);
             }
         }
         return;
@@ -324,13 +524,19 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
         const char* e = getenv("SPN_GEMM_EPI_DIRECT");
         return (e && e[0] == '1') ? 1 : 0;
     }();
+    static const int dbg = [] {
+        const char* e = getenv("SPN_GEMM_DBG");
+        return e ? atoi(e) : 0;
+    }();
     GemmEpilogue e2 = ep;
     e2.direct_store = direct;
+    e2.dbg = dbg;
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
     switch (gemm_cfg()) {
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 4: return dispatch_nt2<256, 256, 2, 4, 4, 32>(A, B, M, N, K, lda, ldb, mode, e2, st);   // measured slower
+        case 5: return dispatch_nt2<256, 256, 2, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);       // 4 waves x 128x128
         default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
     }
 }

@@ -20,6 +20,9 @@ struct GemmEpilogue {
     int act = ACT_NONE;
     float alpha = 1.0f;
     int direct_store = 0;            // gemm2 only: 1 = store from the MFMA layout (no LDS staging)
+    int dbg = 0;                     // gemm2 only, SPN_GEMM_DBG bottleneck-elimination bits (wrong results): 1 = every k tile
+                                     // re-reads k0 = 0, 2 = no DMA after the prologue, 4 = LDS fragments read once per
+                                     // k step, 8 = no epilogue
 };
 
 // gemm.hip

@@ -1,0 +1,21 @@
+"""Bottleneck elimination on the NT GEMM: time shapes under SPN_GEMM_DBG bit masks (results are wrong by design)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = [(19712, 3072, 768), (19712, 768, 3072), (19712, 768, 768), (8192, 8192, 8192)]
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    from spn4cir_amd import ops
+    for M, N, K in SHAPES:
+        a = torch.randn(M, K, device="cuda").bfloat16(); b = torch.randn(N, K, device="cuda").bfloat16()
+        for _ in range(3): ops.gemm_nt(a, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): ops.gemm_nt(a, b)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        print(f"  {M}x{N}x{K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
+else:
+    for dbg in (sys.argv[1:] or ["0", "1", "2", "4", "6", "8", "14"]):
+        print(f"== SPN_GEMM_DBG={dbg} CFG={os.environ.get('SPN_GEMM_CFG', 'default')}", flush=True)
+        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, SPN_GEMM_DBG=dbg))
