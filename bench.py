@@ -197,8 +197,18 @@ def main():
         if per_kernel:
             dom = max((k for k in per_kernel.values() if k["bound"] == "mfma"), key=lambda k: k["total_ms"])
             ach = dom["work"] / (dom["total_ms"] * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if dom["kernel"] == "gemm_nt_kernel" and os.path.exists(tpath) and args.batch_per_gpu == 256 \
+                    and args.model == "ViT-L/14":
+                # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
+                # (bench.py cannot profile itself); FETCH_SIZE already doubled per the gfx950 correction
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": dom["kernel"],
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": dom["kernel"],
                     "launches": dom["launches"], "avg_us": round(dom["avg_us"], 1),
                     "share_of_step": round(dom["total_ms"] / (dt * 1e3), 3)}
             ks = []
