@@ -15,8 +15,18 @@ the MI355X-native multi-GPU design of SURVEY.md section 8(e):
 The math is backend-agnostic: `ops` is any object with bank_stats_fwd / bank_loss_finalize /
 bank_grad_q (the HIP ops in production; tests inject a CPU implementation over gloo).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# SPN_DP_FORCE_COLLECTIVES=1: issue every collective even in a 1-rank group, so the RCCL call pattern of the
+# N-GPU path (dtypes, in-place bucket slices, async handles, stream ordering) can be exercised on a 1-GPU box.
+_FORCE = os.environ.get("SPN_DP_FORCE_COLLECTIVES") == "1"
+
+
+def _skip(world):
+    return world == 1 and not (_FORCE and dist.is_available() and dist.is_initialized())
 
 
 def _world(group):
@@ -34,7 +44,7 @@ def shard_range(total, world, rank):
 
 def all_gather_cat(x, group=None):
     world, _ = _world(group)
-    if world == 1:
+    if _skip(world):
         return x
     out = [torch.empty_like(x) for _ in range(world)]
     dist.all_gather(out, x.contiguous(), group=group)
@@ -44,7 +54,7 @@ def all_gather_cat(x, group=None):
 def reduce_scatter_rows(x, group=None):
     """x [world * B_local, ...] summed over ranks; this rank keeps its B_local rows."""
     world, rank = _world(group)
-    if world == 1:
+    if _skip(world):
         return x
     n = x.shape[0] // world
     if dist.get_backend(group) == "gloo":        # gloo has no reduce_scatter
@@ -68,11 +78,11 @@ class BankLossDP:
         rows, `bank` = full bank (replicated) or this rank's shard starting at global row m_begin.
         Returns a ctx dict; ctx['loss'] is the GLOBAL mean loss (identical on every rank)."""
         ops = self.ops
-        if self.mode == "replicated" or self.world == 1:
+        if self.mode == "replicated" or _skip(self.world):
             stats = ops.bank_stats_fwd(qb_local, bank, labels_local, inv_tau, m_begin)
             lse, row, mean = ops.bank_loss_finalize(stats, M_total, label_smoothing)
             loss = row.sum().reshape(1)
-            if self.world > 1:
+            if not _skip(self.world):
                 dist.all_reduce(loss, group=self.group)          # reporting only
             B_global = qb_local.shape[0] * self.world
             return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss / B_global, bank=bank, m_begin=m_begin,
@@ -125,14 +135,14 @@ class GradBucketReducer:
         self._pending = []
 
     def on_span_ready(self, start, end):
-        if self.world == 1:
+        if _skip(self.world):
             return
         self._pending.append((start, end))
         if sum(e - s for s, e in self._pending) >= self.bucket_elems:
             self._flush()
 
     def finish(self):
-        if self.world == 1:
+        if _skip(self.world):
             return
         self._flush()
         for w in self._works:

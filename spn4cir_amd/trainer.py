@@ -10,6 +10,7 @@ found_inf plumbing of spn_adamw_step is still exercised by the autograd path in 
 import torch
 
 from . import ops
+from . import distributed as _dp
 from .distributed import BankLossDP, GradBucketReducer, _world, shard_range
 
 
@@ -20,7 +21,7 @@ class Stage2Trainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group = group
         self.world, self.rank = _world(group)
-        self.loss_dp = BankLossDP(ops, group, bank_mode if self.world > 1 else "replicated")
+        self.loss_dp = BankLossDP(ops, group, bank_mode if (self.world > 1 or _dp._FORCE) else "replicated")
         self.m = torch.zeros_like(self.tower.params)
         self.v = torch.zeros_like(self.tower.params)
         self.step_count = 0

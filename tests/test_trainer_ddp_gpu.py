@@ -82,3 +82,45 @@ def test_two_ranks_match_single_process(mode):
         # same update as the single-process run: differences only from bf16 rounding of partial sums
         assert (params - ref_params).abs().max() < 2e-3, (mode, rank, (params - ref_params).abs().max().item())
     assert (res[0][2] - res[1][2]).abs().max() == 0.0       # replicas stay bit-identical
+
+
+_NCCL_WORLD1 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from test_trainer_ddp_gpu import _setup, TAU, LR
+from spn4cir_amd.models import CIRPlus
+from spn4cir_amd.trainer import Stage2Trainer
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+sd, target, refer, ids, ridx, labels = _setup()
+def run(mode):
+    model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode)
+    tr.set_banks(refer, target)
+    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    return ls, model.tower.params.clone()
+ref_l, ref_p = run("replicated")                      # no process group yet: plain single-GPU step
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1])
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+for mode in ("sharded", "replicated"):
+    l, p = run(mode)                                  # every collective now goes through RCCL
+    assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5, (mode, l, ref_l)
+    assert (p - ref_p).abs().max().item() < 1e-6, mode
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("NCCL_WORLD1_OK")
+"""
+
+
+def test_rccl_call_pattern_on_one_rank():
+    """The N-GPU path's RCCL calls (bf16/int64/fp32 all-gathers, reduce_scatter_tensor, async all-reduce of
+    in-place bucket slices, barrier) issued for real on the nccl backend with a 1-rank group
+    (SPN_DP_FORCE_COLLECTIVES=1); the step must equal the plain single-GPU step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    env = dict(os.environ, SPN_DP_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_WORLD1, str(_free_port())], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
