@@ -118,6 +118,12 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
                     int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
                     float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 size_t spn_bank_workspace_bytes(int B, int M, int D);
+/* In-batch negatives, BASELINE config 1 (clip4cir/models.py:151-167, wo_bank: labels = arange(B), the target
+ * features are trainable too).  Loss and dq come from the three calls above with the normalised target
+ * features as the bank; this is the target-side gradient
+ *   dt[j,:] = grad_scale * inv_tau * sum_i (exp(q_i.t_j * inv_tau - row_lse[i]) - [i == j]) q[i,:]   fp32 [B, D] */
+int spn_inbatch_grad_t(const void* q_bf16, const void* t_bf16, int ld, const float* row_lse, int B, int D,
+                       float inv_tau, float grad_scale, float* dt, void* stream);
 
 /* ---------------------------------------------------------------- AdamW (train_negplus.py:77-83)
  * torch.optim.AdamW semantics; g is multiplied by inv_scale (GradScaler.unscale_), the step is
@@ -191,6 +197,7 @@ typedef struct {
     int64_t conv1, conv_b, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, proj_b, n_params;
     int64_t block_off[13];
     int64_t bf16_conv1, bf16_blocks, bf16_block_size, bf16_proj_t, n_bf16, kp, seq;
+    int64_t bf16_proj;
 } spn_vision_layout_t;
 
 int spn_vision_layout(const spn_vision_cfg* cfg, spn_vision_layout_t* out);
@@ -200,6 +207,15 @@ int spn_vision_refresh_bf16(const spn_vision_cfg* cfg, const float* params, void
  * blip_cir.py:54-70: the per-image reference bank of blip4cir/models.py:76); feats = proj of token 0. */
 int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
                    void* ws, size_t ws_bytes, float* feats, float* tokens_out, void* stream);
+/* Training path of the CLIP tower (kind 0), used when the visual tower is trainable (clip4cir/models.py:31-33,
+ * 156-158: wo_bank / first stage).  The reference re-computes it under torch.utils.checkpoint; here the per-layer
+ * activations stay in `acts` (spn_vision_train_act_bytes).  grads: flat fp32, spn_vision_layout() offsets, overwritten. */
+size_t spn_vision_train_act_bytes(const spn_vision_cfg* cfg);
+size_t spn_vision_bwd_ws_bytes(const spn_vision_cfg* cfg);
+int spn_vision_fwd_train(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
+                         void* acts, float* feats, void* stream);
+int spn_vision_bwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                   const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- BLIP fusion encoder
  * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of

@@ -33,6 +33,14 @@ def bank_large_step(refer_bank, refer_idx, text_feats, target_bank, labels, tau,
     return infonce(q, target_bank.detach(), labels, tau, label_smoothing)
 
 
+def inbatch_step(refer_feats, text_feats, target_feats, tau):
+    """clip4cir/models.py:151-167 with wo_bank=True (BASELINE config 1): in-batch B x B InfoNCE between
+    normalize(refer + text) and normalize(target), labels = arange(B)."""
+    q = l2_normalize(combine(refer_feats, text_feats))
+    t = l2_normalize(target_feats)
+    return infonce(q, t, torch.arange(q.shape[0]), tau)
+
+
 def infonce_stats(q, bank, labels, tau):
     """Per-row pieces used by the kernel tests: (row_lse, label_logit, row_loss)."""
     logits = (q.double() @ bank.double().t()) / tau

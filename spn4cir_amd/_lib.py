@@ -36,7 +36,7 @@ class VisionLayout(C.Structure):
                                          "block_size", "ln_post_g", "ln_post_b", "proj", "proj_b", "n_params")] + \
                [("block_off", C.c_int64 * 13)] + \
                [(n, C.c_int64) for n in ("bf16_conv1", "bf16_blocks", "bf16_block_size", "bf16_proj_t", "n_bf16", "kp",
-                                         "seq")]
+                                         "seq", "bf16_proj")]
 
 
 class FusionCfg(C.Structure):
@@ -94,6 +94,11 @@ _SIGS = {
     "spn_vision_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
     "spn_vision_refresh_bf16": (i32, [C.POINTER(VisionCfg), vp, vp, vp]),
     "spn_vision_fwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, sz, vp, vp, vp]),
+    "spn_vision_train_act_bytes": (sz, [C.POINTER(VisionCfg)]),
+    "spn_vision_bwd_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
+    "spn_vision_fwd_train": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, vp, vp]),
+    "spn_vision_bwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),

@@ -255,6 +255,27 @@ int spn_vision_fwd(const spn_vision_cfg* cfg, const float* params, const void* w
     return vision_fwd(vc(cfg), params, CBF(weights_bf16), image, (char*)ws, ws_bytes, feats, tokens_out, ST(stream));
 }
 
+size_t spn_vision_train_act_bytes(const spn_vision_cfg* cfg) { return cfg ? vision_train_act_bytes(vc(cfg)) : 0; }
+size_t spn_vision_bwd_ws_bytes(const spn_vision_cfg* cfg) { return cfg ? vision_bwd_ws_bytes(vc(cfg)) : 0; }
+
+int spn_vision_fwd_train(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, const float* image,
+                         void* acts, float* feats, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !image || !acts || !feats) return SPN_ERR_ARG;
+    return vision_fwd_train(vc(cfg), params, CBF(weights_bf16), image, (char*)acts, feats, ST(stream));
+}
+
+int spn_vision_bwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                   const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !acts || !dfeats || !grads || !ws) return SPN_ERR_ARG;
+    return vision_bwd(vc(cfg), params, CBF(weights_bf16), (char*)acts, dfeats, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
+int spn_inbatch_grad_t(const void* q_bf16, const void* t_bf16, int ld, const float* row_lse, int B, int D,
+                       float inv_tau, float grad_scale, float* dt, void* stream) {
+    if (!q_bf16 || !t_bf16 || !row_lse || !dt) return SPN_ERR_ARG;
+    return inbatch_grad_t(CBF(q_bf16), CBF(t_bf16), ld, row_lse, B, D, inv_tau, grad_scale, dt, ST(stream));
+}
+
 static_assert(sizeof(spn_fusion_cfg) == sizeof(FusionCfg), "spn_fusion_cfg layout");
 static_assert(sizeof(spn_fusion_layout_t) == sizeof(FusionLayout), "spn_fusion_layout_t layout");
 

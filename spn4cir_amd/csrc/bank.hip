@@ -463,4 +463,43 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     return fold_rows(ws, (size_t)a.B * a.D, c.nchunks, (size_t)a.B * a.D, dq, grad_scale * a.inv_tau, 0, st);
 }
 
+// -------------------------------------------------------------------- in-batch negatives
+// The B x B case of the same loss with the TARGET side trainable too (clip4cir/models.py:160-167, labels =
+// arange): the query gradient comes from bank_grad_q with the normalised targets as the bank; this is the
+// other side, dt[j] = gs/tau * sum_i (exp(l_ij - lse_i) - [i == j]) q[i].  B is a batch size (<= a few
+// thousand), so one block per target row with fp32 VALU dot products is far below every roofline that matters.
+__global__ __launch_bounds__(256) void inbatch_grad_t_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ t,
+                                                            int ldq, const float* __restrict__ row_lse, int B, int D,
+                                                            float inv_tau, float gs, float* __restrict__ dt) {
+    extern __shared__ float g[];   // [B] coefficients of this target row
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bf16_t* tj = t + (size_t)j * ldq;
+    for (int i = wid; i < B; i += 4) {
+        const bf16_t* qi = q + (size_t)i * ldq;
+        float s = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            const bf16x4 a = *(const bf16x4*)(qi + d), b = *(const bf16x4*)(tj + d);
+            s += bf2f(a[0]) * bf2f(b[0]) + bf2f(a[1]) * bf2f(b[1]) + bf2f(a[2]) * bf2f(b[2]) + bf2f(a[3]) * bf2f(b[3]);
+        }
+        s = wave_sum(s);
+        if (lane == 0) g[i] = (__expf(s * inv_tau - row_lse[i]) - (i == j ? 1.f : 0.f)) * gs * inv_tau;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < B; ++i) acc += g[i] * bf2f(q[(size_t)i * ldq + d]);
+        dt[(size_t)j * D + d] = acc;
+    }
+}
+
+int inbatch_grad_t(const bf16_t* q, const bf16_t* t, int ldq, const float* row_lse, int B, int D, float inv_tau,
+                   float grad_scale, float* dt, hipStream_t st) {
+    if (B <= 0 || D <= 0) return SPN_ERR_ARG;
+    if (D % 4 || ldq % 4 || ldq < D || (size_t)B * 4 > 64 * 1024) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(inbatch_grad_t_kernel, dim3(B), dim3(256), (size_t)B * 4, st, q, t, ldq, row_lse, B, D, inv_tau,
+                       grad_scale, dt);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 }  // namespace spn

@@ -59,6 +59,7 @@ struct VisionLayout {  // == spn_vision_layout_t (element offsets)
     int64_t conv1, conv_b, cls, pos, ln_pre_g, ln_pre_b, blocks, block_size, ln_post_g, ln_post_b, proj, proj_b, n_params;
     int64_t block_off[13];
     int64_t bf16_conv1, bf16_blocks, bf16_block_size, bf16_proj_t, n_bf16, kp, seq;
+    int64_t bf16_proj;   // proj [W, D] as stored (backward-data operand); bf16_proj_t is its transpose
 };
 
 void vision_layout(const VisionCfg& c, VisionLayout* t);
@@ -99,6 +100,14 @@ size_t block_op_ws_bytes(const BlockCfg& c);
 int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st);
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
               bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st);
+
+// training path (CLIP kind 0 only): activations kept per layer, clip4cir/models.py:156-158 (wo_bank first stage)
+size_t vision_train_act_bytes(const VisionCfg& c);
+size_t vision_bwd_ws_bytes(const VisionCfg& c);
+int vision_fwd_train(const VisionCfg& c, const float* params, const bf16_t* wb, const float* image, char* acts, float* feats,
+                     hipStream_t st);
+int vision_bwd(const VisionCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats, float* grads,
+               char* ws, size_t ws_bytes, hipStream_t st);
 
 void text_layout(const TextCfg& c, TextLayout* t);
 size_t text_act_bytes(const TextCfg& c);

@@ -40,6 +40,21 @@ class _BankStep(torch.autograd.Function):
         return torch.zeros((), device=grad_out.device), None, None, None, None
 
 
+class _InBatchStep(torch.autograd.Function):
+    """BASELINE config 1: loss = CE(normalize(vis(ref) + text(ids)) @ normalize(vis(tgt)).T / tau, arange(B))."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, ids, refer_image, target_image):
+        st = model._inbatch_forward(ids, refer_image, target_image)
+        ctx.model, ctx.st = model, st
+        return st["loss"].reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._inbatch_backward(ctx.st, grad_out)
+        return torch.zeros((), device=grad_out.device), None, None, None, None
+
+
 class _Tree(nn.Module):
     """Nested containers so that parameter names reproduce the reference's dotted keys."""
 
@@ -57,13 +72,14 @@ def _attach(root, dotted, param):
 class CIRPlus(nn.Module):
     def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
                  device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
-                 tokenizer=None, pack_eot=False):
+                 tokenizer=None, pack_eot=False, wo_bank=False):
         """`clip_model_name`: path to a CLIP state-dict file (as clip.load accepts, clip/clip.py:120-123),
         a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline).
         `pack_eot`: run the text tower on the live rows only (everything after a caption's EOT token is dead
         under the causal mask); same loss and gradients, ~L/mean_len fewer rows."""
         super().__init__()
         self.pack_eot = bool(pack_eot)
+        self.wo_bank = bool(wo_bank)   # clip4cir/models.py:23: in-batch negatives, visual tower trainable
         self._pack = (None, 0)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -91,7 +107,9 @@ class CIRPlus(nn.Module):
                                       vcfg["embed_dim"], self.device)
             self.vision.load_clip_state_dict(sd)
             for key, view in self.vision.named_views().items():
-                _attach(self.clip, "visual." + key, nn.Parameter(view, requires_grad=False))
+                p = nn.Parameter(view, requires_grad=self.wo_bank)     # models.py:31-33: frozen unless wo_bank
+                _attach(self.clip, "visual." + key, p)
+                self._params["visual." + key] = p
         else:
             for k, v in sd.items():
                 if k.startswith("visual."):
@@ -294,9 +312,47 @@ class CIRPlus(nn.Module):
             p = self._params[key]
             p.grad = view if p.grad is None else p.grad + view
 
-    def forward(self, text, indexs, target_indexs, refer_indexs):
-        """models_negplus.py:144-148 -> {'bank_loss': 0-dim tensor with grad}."""
+    # ---------------------------------------------------------------- in-batch step (config 1)
+    def _inbatch_forward(self, ids, refer_image, target_image):
+        """clip4cir/models.py:151-167 with wo_bank: both images through the (trainable) visual tower as ONE
+        batch of 2B, q = normalize(ref + text), t = normalize(tgt), CE over the B x B logits, labels = arange."""
+        if self.vision is None:
+            raise RuntimeError("wo_bank needs a ViT image tower")
+        B = ids.shape[0]
+        imgs = torch.cat([refer_image, target_image]).to(self.device, torch.float32)
+        img_feats = self.vision.forward_train(imgs)
+        text_feats = self.tower.forward(ids, *self._pack)
+        ar = torch.arange(B, device=self.device, dtype=torch.int64)
+        q, qb, inv_q = ops.combine_l2norm_fwd(img_feats[:B].contiguous(), ar, text_feats)
+        t, tb, inv_t = ops.combine_l2norm_fwd(None, None, img_feats[B:].contiguous())
+        stats = ops.bank_stats_fwd(qb, tb, ar, 1.0 / self.tau)
+        lse, row, mean = ops.bank_loss_finalize(stats, B, 0.0)
+        return dict(q=q, qb=qb, inv_q=inv_q, t=t, tb=tb, inv_t=inv_t, lse=lse, loss=mean, labels=ar, B=B)
+
+    def _inbatch_backward(self, st, grad_out):
+        scale = float(grad_out) if not torch.is_tensor(grad_out) else grad_out.item()
+        B, D = st["B"], self.output_dim
+        gs = scale / B
+        dq = ops.bank_grad_q(st["qb"], st["tb"], st["labels"], 1.0 / self.tau, st["lse"], gs, M_total=B)
+        dt = ops.inbatch_grad_t(st["qb"], st["tb"], st["lse"], 1.0 / self.tau, gs, D)
+        dsum = ops.combine_l2norm_bwd(st["q"], st["inv_q"], dq[:, :D].contiguous())      # = d ref_feats = d text_feats
+        dtgt = ops.combine_l2norm_bwd(st["t"], st["inv_t"], dt)
+        flat_t = self.tower.backward(dsum)
+        flat_v = self.vision.backward(torch.cat([dsum, dtgt]))
+        for key, view in self.tower.named_views(flat_t).items():
+            p = self._params[key]
+            p.grad = view if p.grad is None else p.grad + view
+        for key, view in self.vision.named_views(flat_v).items():
+            p = self._params["visual." + key]
+            p.grad = view if p.grad is None else p.grad + view
+
+    def forward(self, text, indexs, target_indexs, refer_indexs, refer_image=None, target_image=None):
+        """models_negplus.py:144-148 -> {'bank_loss': 0-dim tensor with grad}; with wo_bank
+        (clip4cir/models.py:151-160) -> {'bbc_loss': ...} from the two image batches."""
         ids = self.tokenize(text)
+        if self.wo_bank:
+            loss = _InBatchStep.apply(self._anchor, self, ids, refer_image, target_image)
+            return {"bbc_loss": loss}
         bank, ridx = self._refer_rows(indexs, refer_indexs)
         self._refer_f32 = bank if bank.dtype == torch.float32 else bank.float()
         labels = target_indexs.to(self.device, torch.int64)
@@ -306,3 +362,5 @@ class CIRPlus(nn.Module):
     def parameters_changed(self):
         """Call after an external optimizer updated the parameters in place."""
         self.tower.mark_stale()
+        if self.vision is not None and self.wo_bank:
+            self.vision.mark_stale()

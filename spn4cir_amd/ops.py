@@ -265,3 +265,14 @@ def topk_from_scores(scores, K, exclude=None):
     val = torch.empty(Nq, K, dtype=torch.float64, device=scores.device)
     check(lib().spn_topk_from_scores(_p(scores), Nq, Ng, K, _p(exclude), _p(idx), _p(val), _stream()), "topk")
     return idx, val
+
+
+def inbatch_grad_t(qb, tb, lse, inv_tau, grad_scale, D):
+    """In-batch negatives (clip4cir/models.py:160-167): target-side gradient fp32 [B, D] of the mean CE whose
+    query-side gradient is bank_grad_q(qb, tb, arange(B), ...)."""
+    _req(qb, torch.bfloat16, "qb"); _req(tb, torch.bfloat16, "tb"); _req(lse, torch.float32, "lse")
+    B, ld = qb.shape
+    dt = torch.empty(B, D, dtype=torch.float32, device=qb.device)
+    check(lib().spn_inbatch_grad_t(_p(qb), _p(tb), ld, _p(lse), B, D, float(inv_tau), float(grad_scale), _p(dt), _stream()),
+          "inbatch_grad_t")
+    return dt

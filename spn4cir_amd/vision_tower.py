@@ -1,7 +1,9 @@
 """Host side of the frozen CLIP image tower (VisionTransformer, clip4cir/clip/model.py:206-242).
 
-Inference only: stage 2 never trains it (models_negplus.py:27-28).  Parameters live in one flat fp32
-buffer (layout spn_vision_layout); the bf16 GEMM operands are derived once."""
+Stage 2 never trains it (models_negplus.py:27-28): forward() is the inference path of the bank builders and
+validation.  forward_train()/backward() serve BASELINE config 1 (clip4cir/models.py:151-167, wo_bank), where the
+tower is trainable.  Parameters live in one flat fp32 buffer (layout spn_vision_layout); the bf16 GEMM operands
+are derived from it."""
 import ctypes as C
 
 import torch
@@ -36,6 +38,9 @@ class VisionTower:
         self.wbf16 = torch.zeros(int(self._lay.n_bf16), dtype=torch.bfloat16, device=self.device)
         self._ws = None
         self._stale = True
+        self.grads = None          # allocated by forward_train(): flat fp32, same layout as params
+        self._acts = self._bws = None
+        self._train_B = 0
 
     def _cfg(self, B):
         return _lib.VisionCfg(B, self.res, self.patch, self.width, self.heads, self.layers, self.embed_dim, self.kind)
@@ -83,14 +88,56 @@ class VisionTower:
                     v.copy_(sd[prefix + key].to(self.device, torch.float32))
         self._stale = True
 
-    def named_views(self):
+    def named_views(self, flat=None):
+        flat = self.params if flat is None else flat
         views = {}
         for key, off, shape in self.spans():
             n = 1
             for s in shape:
                 n *= s
-            views[key] = self.params[off:off + n].view(shape)
+            views[key] = flat[off:off + n].view(shape)
         return views
+
+    def mark_stale(self):
+        self._stale = True
+
+    def _refresh(self, cfg):
+        if self._stale:
+            check(lib().spn_vision_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()),
+                  "vision_refresh_bf16")
+            self._stale = False
+
+    # ------------------------------------------------------------------ training (CLIP tower, wo_bank / first stage)
+    def forward_train(self, image):
+        """As forward(), but keeps every layer's activations for backward() (clip4cir/models.py:156-158 runs the
+        tower under torch.utils.checkpoint instead; 288 GB of HBM make the recompute unnecessary)."""
+        if self.kind != 0:
+            raise RuntimeError("only the CLIP VisionTransformer has a training path")
+        image = image.to(self.device, torch.float32).contiguous()
+        B = image.shape[0]
+        cfg = self._cfg(B)
+        self._refresh(cfg)
+        if self._train_B != B:
+            self._acts = self._bws = None
+            self._acts = torch.empty(lib().spn_vision_train_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self._bws = torch.empty(lib().spn_vision_bwd_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self._train_B = B
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        check(lib().spn_vision_fwd_train(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(image), _p(self._acts),
+                                         _p(feats), _stream()), "vision_fwd_train")
+        return feats
+
+    def backward(self, dfeats):
+        """d(loss)/d(feats) fp32 [B, D] of the preceding forward_train() -> self.grads (overwritten)."""
+        if not self._train_B or dfeats.shape[0] != self._train_B:
+            raise RuntimeError("backward() without a matching forward_train()")
+        cfg = self._cfg(self._train_B)
+        dfeats = dfeats.to(self.device, torch.float32).contiguous()
+        check(lib().spn_vision_bwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats),
+                                   _p(self.grads), _p(self._bws), self._bws.numel(), _stream()), "vision_bwd")
+        return self.grads
 
     def load_clip_state_dict(self, sd, prefix="visual."):
         with torch.no_grad():
@@ -106,10 +153,7 @@ class VisionTower:
         image = image.to(self.device, torch.float32).contiguous()
         B = image.shape[0]
         cfg = self._cfg(B)
-        if self._stale:
-            check(lib().spn_vision_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()),
-                  "vision_refresh_bf16")
-            self._stale = False
+        self._refresh(cfg)
         need = lib().spn_vision_ws_bytes(C.byref(cfg))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)

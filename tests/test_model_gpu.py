@@ -228,3 +228,39 @@ def test_bank_builders(golden_dir, tmp_path):
     ids = torch.from_numpy(z["ids"])
     out = model.forward(ids, torch.arange(6), ds.tgt[:6], ds.ref[:6])
     assert torch.isfinite(out["bank_loss"])
+
+
+def test_config1_inbatch_step_matches_reference(golden_dir):
+    """BASELINE config 1 (clip4cir/train.py --wo_bank -> models.py:151-167): in-batch negatives with the visual
+    tower trainable.  Loss and the gradient of EVERY parameter (text + visual) against vectors captured from the
+    reference (tests/golden/make_golden_inbatch.py).  Tolerances as for the stage-2 step: bf16 GEMM operands vs
+    the reference's fp32 - loss 1e-2 relative, per-parameter gradient 5e-2 relative L2."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    from spn4cir_amd.models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    s = np.load(os.path.join(golden_dir, "cirplus_inbatch.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    model = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), wo_bank=True)
+    ids = torch.from_numpy(s["ids"])
+    out = model.forward(ids, None, None, None, refer_image=torch.from_numpy(s["refer_image"]).cuda(),
+                        target_image=torch.from_numpy(s["target_image"]).cuda())
+    loss = out["bbc_loss"]
+    ref_loss = float(s["loss"])
+    assert abs(loss.item() - ref_loss) < 1e-2 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    loss.backward()
+    named = dict(model.clip.named_parameters())
+    worst, n = 0.0, 0
+    for k in s.files:
+        if not k.startswith("grad::"):
+            continue
+        g, r = named[k[6:]].grad, torch.from_numpy(s[k])
+        assert g is not None, k
+        err = ((g.cpu() - r).norm() / r.norm().clamp_min(1e-12)).item()
+        worst = max(worst, err)
+        assert err < 5e-2, (k, err)
+        n += 1
+    assert n == 61
+    print("config 1: loss", loss.item(), "ref", ref_loss, "worst per-parameter grad error", worst)

@@ -133,3 +133,29 @@ def test_blip_fusion_matches_reference(golden_dir):
             assert (sd[k].grad - ref).abs().max() <= 2e-4 * ref.abs().max().clamp_min(1e-6) + 1e-7, k
             n += 1
     assert n >= 50
+
+
+def test_inbatch_step_loss_and_grads(golden_dir):
+    """BASELINE config 1 (clip4cir/models.py:151-167, wo_bank=True): the oracle's in-batch step reproduces
+    the reference's bbc_loss and the gradient of every parameter, visual tower included."""
+    from oracle import bank_loss, clip_text, clip_vision
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    s = np.load(os.path.join(golden_dir, "cirplus_inbatch.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("sd::")
+          and z[k].dtype == np.float32}
+    ref = clip_vision.encode_image(sd, torch.from_numpy(s["refer_image"]))
+    tgt = clip_vision.encode_image(sd, torch.from_numpy(s["target_image"]))
+    assert torch.allclose(ref.detach(), torch.from_numpy(s["refer_feats"]), atol=1e-5)
+    text = clip_text.encode_text(sd, torch.from_numpy(s["ids"]))
+    loss = bank_loss.inbatch_step(ref, text, tgt, float(s["tau"]))
+    assert abs(loss.item() - float(s["loss"])) < 1e-5
+    loss.backward()
+    n = 0
+    for k in s.files:
+        if not k.startswith("grad::"):
+            continue
+        g, r = sd[k[6:]].grad, torch.from_numpy(s[k])
+        assert g is not None, k
+        assert (g - r).norm() <= 1e-4 * r.norm() + 1e-7, (k, (g - r).norm().item(), r.norm().item())
+        n += 1
+    assert n == 61
