@@ -118,6 +118,17 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
                     int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
                     float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 size_t spn_bank_workspace_bytes(int B, int M, int D);
+/* fp8 bank (BASELINE config 5): the static bank stored as OCP e4m3 bytes [M, Dp] + one fp32 scale per row
+ * (row max -> 448), halving the only HBM stream of the loss.  The kernels dequantise a tile into LDS (x scale,
+ * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /
+ * dq contract as the bf16 entry points above. */
+int spn_bank_quantize_fp8(const float* bank_f32, int M, int D, int Dp, void* bank_fp8, float* bank_scale, void* stream);
+int spn_bank_stats_fwd_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale,
+                           const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau, float* stats, void* ws,
+                           size_t ws_bytes, void* stream);
+int spn_bank_grad_q_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale, const int64_t* labels,
+                        int B, int M, int D, int m_begin, float inv_tau, const float* row_lse, float label_smoothing,
+                        int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 /* In-batch negatives, BASELINE config 1 (clip4cir/models.py:151-167, wo_bank: labels = arange(B), the target
  * features are trainable too).  Loss and dq come from the three calls above with the normalised target
  * features as the bank; this is the target-side gradient

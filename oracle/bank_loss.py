@@ -33,6 +33,22 @@ def bank_large_step(refer_bank, refer_idx, text_feats, target_bank, labels, tau,
     return infonce(q, target_bank.detach(), labels, tau, label_smoothing)
 
 
+def quantize_e4m3(bank):
+    """BASELINE config 5 storage of the static bank: per-row scale = max|x| / 448 (1 for a zero row),
+    bytes = round-to-nearest-even OCP e4m3fn of x / scale.  Returns (uint8 [M, D], fp32 scale [M]).  The
+    reference has no fp8 path; this restates the format definition (OCP 8-bit floating point, e4m3fn: bias 7,
+    max 448, no infinities) through torch's float8_e4m3fn cast."""
+    bank = bank.float()
+    mx = bank.abs().amax(dim=1)
+    scale = torch.where(mx > 0, mx / 448.0, torch.ones_like(mx))
+    q = (bank / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale
+
+
+def dequantize_e4m3(data, scale):
+    return data.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
 def inbatch_step(refer_feats, text_feats, target_feats, tau):
     """clip4cir/models.py:151-167 with wo_bank=True (BASELINE config 1): in-batch B x B InfoNCE between
     normalize(refer + text) and normalize(target), labels = arange(B)."""

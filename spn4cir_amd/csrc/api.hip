@@ -163,6 +163,28 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
 
 size_t spn_bank_workspace_bytes(int B, int M, int D) { return bank_workspace_bytes(B, M, D); }
 
+int spn_bank_quantize_fp8(const float* bank, int M, int D, int Dp, void* bank_fp8, float* scale, void* stream) {
+    return bank_quantize_fp8(bank, M, D, Dp, (uint8_t*)bank_fp8, scale, ST(stream));
+}
+
+int spn_bank_stats_fwd_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale,
+                           const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau, float* stats, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (!stats || !bank_scale) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank_fp8, labels, B, M, D, m_begin, inv_tau);
+    a.bank_scale = bank_scale;
+    return bank_stats_fwd(a, stats, (float*)ws, ws_bytes, ST(stream));
+}
+
+int spn_bank_grad_q_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale, const int64_t* labels,
+                        int B, int M, int D, int m_begin, float inv_tau, const float* row_lse, float label_smoothing,
+                        int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream) {
+    if (!bank_scale) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank_fp8, labels, B, M, D, m_begin, inv_tau);
+    a.bank_scale = bank_scale;
+    return bank_grad_q(a, row_lse, label_smoothing, M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream));
+}
+
 int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float inv_scale, const float* found_inf, void* stream) {
     if (!p || !g || !m || !v) return SPN_ERR_ARG;

@@ -127,7 +127,7 @@ static BankChunking bank_chunking(int B, int M) {
     return c;
 }
 
-template <int D, bool BWD>
+template <int D, bool BWD, bool FP8>
 __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChunking ck, const float* __restrict__ row_lse,
                                                             float label_smoothing, float inv_m_total,
                                                             float* __restrict__ ws) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     const int m_hi = min(a.M, m_lo + ck.rows);
     const int ntiles = m_hi > m_lo ? (m_hi - m_lo + TR - 1) / TR : 0;
 
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)ROWB);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)(FP8 ? D : ROWB));
 
     // query fragments of this wave's d-slice (B operand: j = query, k = d)
     bf16x8 qf[2][KSW];
@@ -187,16 +187,54 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             for (int dt = 0; dt < NDT; ++dt) dq[mt][dt] = f32x4{0, 0, 0, 0};
     }
 
+    // bf16 bank: two swizzled bf16 tiles, filled directly by the DMA.
+    // fp8 bank (FP8): ONE bf16 tile at tiles[0] + two raw e4m3 tiles behind it (same LDS total); the raw tile
+    // is a linear copy of TR contiguous rows, dequantised (x row scale) into the swizzled bf16 image by all
+    // 256 threads, so everything downstream is unchanged and HBM sees one byte per bank element.
+    constexpr int RAW_B = TR * D;
     auto stage = [&](int t, int buf) {
-        char* dst = tiles + buf * TILE_B;
+        const int mrow0 = m_lo + t * TR;
+        if constexpr (FP8) {
+            char* dst = tiles + TILE_B + buf * RAW_B;
+#pragma unroll
+            for (int i = 0; i < D / 128; ++i) {
+                const int ii = w * (D / 128) + i;
+                glds16(rs, dst + ii * 1024, (uint32_t)mrow0 * (uint32_t)D + (uint32_t)(ii * 1024 + lane * 16));
+            }
+        } else {
+            char* dst = tiles + buf * TILE_B;
+#pragma unroll
+            for (int i = 0; i < GLDS_PER_WAVE; ++i) {
+                const int ii = w * GLDS_PER_WAVE + i;
+                const int p = ii * 1024 + lane * 16;
+                const int r = p / ROWB, cp = (p % ROWB) >> 4;
+                const int c = cp ^ bank_swz(r & 15);
+                glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)c * 16u);
+            }
+        }
+    };
+    auto dequant = [&](int t, int buf) {
+        const char* raw = tiles + TILE_B + buf * RAW_B;
         const int mrow0 = m_lo + t * TR;
 #pragma unroll
-        for (int i = 0; i < GLDS_PER_WAVE; ++i) {
-            const int ii = w * GLDS_PER_WAVE + i;
-            const int p = ii * 1024 + lane * 16;
-            const int r = p / ROWB, cp = (p % ROWB) >> 4;
-            const int c = cp ^ bank_swz(r & 15);
-            glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)c * 16u);
+        for (int i = 0; i < D / 128; ++i) {
+            const int p = (i * 256 + tid) * 16;          // byte offset of this thread's 16 e4m3 values
+            const int r = p / D, cb = (p % D) >> 4;
+            const float sc = (mrow0 + r < a.M) ? a.bank_scale[mrow0 + r] : 0.f;
+            const u32x4 v = *(const u32x4*)(raw + p);
+            bf16x8 o[2];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[d], false);
+                const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[d], true);
+                o[d >> 1][(d & 1) * 4 + 0] = f2bf(lo[0] * sc);
+                o[d >> 1][(d & 1) * 4 + 1] = f2bf(lo[1] * sc);
+                o[d >> 1][(d & 1) * 4 + 2] = f2bf(hi[0] * sc);
+                o[d >> 1][(d & 1) * 4 + 3] = f2bf(hi[1] * sc);
+            }
+            const int sw = bank_swz(r & 15);
+            *(bf16x8*)(tiles + r * ROWB + (((2 * cb) ^ sw) << 4)) = o[0];
+            *(bf16x8*)(tiles + r * ROWB + (((2 * cb + 1) ^ sw) << 4)) = o[1];
         }
     };
 
@@ -206,7 +244,11 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         wait_vm0();
         __syncthreads();
         if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
-        const char* T = tiles + buf * TILE_B;
+        if constexpr (FP8) {
+            dequant(t, buf);
+            __syncthreads();
+        }
+        const char* T = tiles + (FP8 ? 0 : buf * TILE_B);
 
         // ---- logits over this wave's d-slice: D[i = key][j = query]
         f32x4 s[2][2];
@@ -391,11 +433,11 @@ size_t bank_workspace_bytes(int B, int M, int D) {
     return a > b ? a : b;
 }
 
-template <int D, bool BWD>
+template <int D, bool BWD, bool FP8>
 static int launch_bank(const BankArgs& a, const BankChunking& c, const float* row_lse, float ls, float inv_m,
                        float* ws, hipStream_t st) {
     const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2;
-    auto kern = bank_stream_kernel<D, BWD>;
+    auto kern = bank_stream_kernel<D, BWD, FP8>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -404,7 +446,8 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
     }
     {
         // "work" = algorithmic HBM bytes of one pass: the bank shard once + q in (+ dq out)
-        const double bytes = (double)a.M * D * 2 + (double)a.B * D * (BWD ? 6 : 2) + (double)a.B * 16;
+        const double bytes = (double)a.M * D * (FP8 ? 1 : 2) + (FP8 ? 4.0 * a.M : 0.0) + (double)a.B * D * (BWD ? 6 : 2) +
+                             (double)a.B * 16;
         ProfScope prof(BWD ? PK_BANK_BWD : PK_BANK_FWD, bytes, st);
         hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
     }
@@ -412,21 +455,25 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
     return SPN_OK;
 }
 
-#define SPN_BANK_DISPATCH(BWD_, ...)                                   \
-    switch (a.D) {                                                     \
-        case 128: rc = launch_bank<128, BWD_>(__VA_ARGS__); break;     \
-        case 256: rc = launch_bank<256, BWD_>(__VA_ARGS__); break;     \
-        case 512: rc = launch_bank<512, BWD_>(__VA_ARGS__); break;     \
-        case 640: rc = launch_bank<640, BWD_>(__VA_ARGS__); break;     \
-        case 768: rc = launch_bank<768, BWD_>(__VA_ARGS__); break;     \
-        case 1024: rc = launch_bank<1024, BWD_>(__VA_ARGS__); break;   \
-        default: return SPN_ERR_SHAPE;                                 \
+#define SPN_BANK_CASE(D_, BWD_, ...)                                                                  \
+    case D_:                                                                                          \
+        rc = a.bank_scale ? launch_bank<D_, BWD_, true>(__VA_ARGS__) : launch_bank<D_, BWD_, false>(__VA_ARGS__); \
+        break;
+#define SPN_BANK_DISPATCH(BWD_, ...)               \
+    switch (a.D) {                                 \
+        SPN_BANK_CASE(128, BWD_, __VA_ARGS__)      \
+        SPN_BANK_CASE(256, BWD_, __VA_ARGS__)      \
+        SPN_BANK_CASE(512, BWD_, __VA_ARGS__)      \
+        SPN_BANK_CASE(640, BWD_, __VA_ARGS__)      \
+        SPN_BANK_CASE(768, BWD_, __VA_ARGS__)      \
+        SPN_BANK_CASE(1024, BWD_, __VA_ARGS__)     \
+        default: return SPN_ERR_SHAPE;             \
     }
 
 static int bank_check(const BankArgs& a) {
     if (a.B <= 0 || a.M <= 0 || !a.q || !a.bank || !a.labels) return SPN_ERR_ARG;
     if (a.ldq % 8 || a.ldq < a.D) return SPN_ERR_SHAPE;
-    if ((uint64_t)a.M * a.D * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    if ((uint64_t)a.M * a.D * (a.bank_scale ? 1 : 2) >= (1ull << 32)) return SPN_ERR_SHAPE;
     return SPN_OK;
 }
 
@@ -461,6 +508,40 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     SPN_BANK_DISPATCH(true, a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
     if (rc) return rc;
     return fold_rows(ws, (size_t)a.B * a.D, c.nchunks, (size_t)a.B * a.D, dq, grad_scale * a.inv_tau, 0, st);
+}
+
+// ------------------------------------------------------------------------------ fp8 bank
+// One wave per row: scale = max|x| / 448 (the largest e4m3 value; 1 for an all-zero row), bytes = RNE(x / scale).
+__global__ void bank_quantize_fp8_kernel(const float* __restrict__ bank, int M, int D, int Dp, uint8_t* __restrict__ out,
+                                         float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* x = bank + (size_t)m * D;
+    float mx = 0.f;
+    for (int c = lane; c < D; c += 64) mx = fmaxf(mx, fabsf(x[c]));
+    mx = wave_max(mx);
+    const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+    if (lane == 0) scale[m] = sc;
+    for (int c = lane * 4; c < Dp; c += 256) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = c + e < D ? x[c + e] / sc : 0.f;
+            v[e] = fminf(fmaxf(t, -448.0f), 448.0f);
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        *(int*)(out + (size_t)m * Dp + c) = pk;
+    }
+}
+
+int bank_quantize_fp8(const float* bank, int M, int D, int Dp, uint8_t* out, float* scale, hipStream_t st) {
+    if (M <= 0 || D <= 0 || !bank || !out || !scale) return SPN_ERR_ARG;
+    if (Dp % 4 || Dp < D) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(bank_quantize_fp8_kernel, dim3((M + 3) / 4), dim3(256), 0, st, bank, M, D, Dp, out, scale);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
 }
 
 // -------------------------------------------------------------------- in-batch negatives

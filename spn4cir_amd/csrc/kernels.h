@@ -110,12 +110,15 @@ int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, f
                        hipStream_t st);
 struct BankArgs {
     const bf16_t* q; int ldq;        // [B, D] L2-normalised queries
-    const bf16_t* bank;              // [M_local, D]
+    const bf16_t* bank;              // [M_local, D] bf16, or e4m3 bytes [M_local, D] when bank_scale != nullptr
     const int64_t* labels;           // [B] global row ids
     int B, M, D;                     // M = rows in this shard
     int m_begin;                     // global id of row 0 of this shard
     float inv_tau;
+    const float* bank_scale = nullptr;   // fp8 bank: per-row dequantisation scale [M_local]
 };
+// fp32 [M, D] -> OCP e4m3 [M, Dp] (zero padded) with one fp32 scale per row (row max -> 448)
+int bank_quantize_fp8(const float* bank, int M, int D, int Dp, uint8_t* out, float* scale, hipStream_t st);
 // forward: per-row partial softmax statistics over this shard
 //   stats[b] = {max, sum exp(l - max), sum l, label logit (or -inf if the label is not in the shard)}
 int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t ws_bytes, hipStream_t st);

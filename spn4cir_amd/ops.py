@@ -175,10 +175,39 @@ def bank_dim(D):
     raise ValueError(f"embedding dim {D} > {BANK_DIMS[-1]} not supported by the bank kernels")
 
 
-def prepare_bank(bank_f32):
-    """fp32 [M, D] (L2-normalised rows) -> device bf16 [M, bank_dim(D)], zero padded."""
+class Fp8Bank:
+    """Static bank as OCP e4m3 bytes [M, Dp] + one fp32 scale per row (BASELINE config 5).  Accepted wherever a
+    bf16 bank is (bank_stats_fwd / bank_grad_q dispatch on it)."""
+
+    def __init__(self, data, scale):
+        self.data, self.scale = data, scale
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def dequantize(self):
+        """fp32 [M, Dp] exactly as the kernels see it before the bf16 rounding."""
+        return self.data.view(torch.float8_e4m3fn).float() * self.scale[:, None]
+
+
+def prepare_bank(bank_f32, dtype="bf16"):
+    """fp32 [M, D] (L2-normalised rows) -> device bf16 [M, bank_dim(D)], zero padded; dtype="fp8" -> Fp8Bank."""
     M, D = bank_f32.shape
     Dp = bank_dim(D)
+    if dtype == "fp8":
+        _req(bank_f32, torch.float32, "bank")
+        data = torch.empty(M, Dp, dtype=torch.uint8, device=bank_f32.device)
+        scale = torch.empty(M, dtype=torch.float32, device=bank_f32.device)
+        check(lib().spn_bank_quantize_fp8(_p(bank_f32.contiguous()), M, D, Dp, _p(data), _p(scale), _stream()),
+              "bank_quantize_fp8")
+        return Fp8Bank(data, scale)
+    if dtype != "bf16":
+        raise ValueError(dtype)
     out = torch.zeros(M, Dp, dtype=torch.bfloat16, device=bank_f32.device)
     out[:, :D] = bank_f32.to(torch.bfloat16)
     return out
@@ -209,6 +238,10 @@ def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0):
     M = bank_bf16.shape[0]
     stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
     ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
+    if isinstance(bank_bf16, Fp8Bank):
+        check(lib().spn_bank_stats_fwd_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
+                                           m_begin, inv_tau, _p(stats), _p(ws), ws.numel(), _stream()), "bank_stats_fwd_fp8")
+        return stats
     check(lib().spn_bank_stats_fwd(_p(q_bf16), Dp, _p(bank_bf16), _p(labels), B, M, Dp, m_begin, inv_tau, _p(stats),
                                    _p(ws), ws.numel(), _stream()), "bank_stats_fwd")
     return stats
@@ -233,6 +266,11 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
     M = bank_bf16.shape[0]
     dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
     ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
+    if isinstance(bank_bf16, Fp8Bank):
+        check(lib().spn_bank_grad_q_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
+                                        m_begin, inv_tau, _p(row_lse), label_smoothing, M_total or M, grad_scale, _p(dq),
+                                        _p(ws), ws.numel(), _stream()), "bank_grad_q_fp8")
+        return dq
     check(lib().spn_bank_grad_q(_p(q_bf16), Dp, _p(bank_bf16), _p(labels), B, M, Dp, m_begin, inv_tau, _p(row_lse),
                                 label_smoothing, M_total or M, grad_scale, _p(dq), _p(ws), ws.numel(), _stream()),
           "bank_grad_q")

@@ -32,9 +32,10 @@ class Stage2Trainer:
         self._m_begin, self._M_total = 0, 0
         self._refer = None
 
-    def set_banks(self, refer_bank, target_bank):
+    def set_banks(self, refer_bank, target_bank, bank_dtype="bf16"):
         """refer_bank fp32 [N, D] raw features; target_bank fp32 [M, D] L2-normalised rows.
-        In "sharded" mode only this rank's contiguous row range is kept on the device."""
+        In "sharded" mode only this rank's contiguous row range is kept on the device.
+        bank_dtype "fp8": e4m3 + per-row scale storage (BASELINE config 5) instead of bf16."""
         dev = self.tower.device
         self._refer = refer_bank.to(dev, torch.float32).contiguous()
         M = target_bank.shape[0]
@@ -42,10 +43,10 @@ class Stage2Trainer:
         if self.loss_dp.mode == "sharded" and self.world > 1:
             b, e = shard_range(M, self.world, self.rank)
             self._m_begin = b
-            self._bank = ops.prepare_bank(target_bank[b:e].to(dev, torch.float32))
+            self._bank = ops.prepare_bank(target_bank[b:e].to(dev, torch.float32).contiguous(), bank_dtype)
         else:
             self._m_begin = 0
-            self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32))
+            self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32), bank_dtype)
 
     def step(self, ids, refer_idx, labels, cu_seqlens=None, total_rows=0):
         """ids int32 [B_local, L], refer_idx / labels int64 [B_local] (device). Returns the global mean

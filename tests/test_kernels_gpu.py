@@ -292,6 +292,38 @@ def test_bank_matches_golden_loss_cases(ops, golden_dir):
         assert rel_err(dtext, torch.from_numpy(z[f"c{ci}_dtext"])) < 3e-2
 
 
+@pytest.mark.parametrize("B,M,D,tau", [(32, 4099, 512, 0.02), (16, 100000, 768, 0.02), (256, 40000, 768, 0.02),
+                                        (33, 1500, 640, 0.03)])
+def test_bank_fp8(ops, B, M, D, tau):
+    """BASELINE config 5: the bank stored as e4m3 + per-row scale.  (1) the quantised bytes and scales are
+    bit-identical to the oracle's; (2) against the oracle on the SAME dequantised operands only the
+    accumulation order differs (2e-4 on lse / loss, 1.5e-2 relative on dq as for the bf16 bank); (3) against
+    the bf16-bank path the survey's gate |delta loss| <= 1e-2."""
+    from oracle import bank_loss
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, B + M + 5)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    fb = ops.prepare_bank(dev(bank), dtype="fp8")
+    data_ref, scale_ref = bank_loss.quantize_e4m3(bank)
+    assert torch.equal(fb.data[:, :D].cpu(), data_ref) and not fb.data[:, D:].any()
+    assert torch.equal(fb.scale.cpu(), scale_ref)
+    qr = qb[:, :D].cpu().float()
+    br = bf(bank_loss.dequantize_e4m3(data_ref, scale_ref)).float()       # the kernel rounds the dequantised tile to bf16
+    lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+    stats = ops.bank_stats_fwd(qb, fb, dev(labels), 1.0 / tau)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+    assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+    dq = ops.bank_grad_q(qb, fb, dev(labels), 1.0 / tau, lse, 1.0 / B)
+    assert rel_err(dq[:, :D], bank_loss.infonce_grad_q(qr, br, labels, tau)) < 1.5e-2
+    # versus the bf16 bank
+    bank_b = ops.prepare_bank(dev(bank))
+    s16 = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau)
+    lse16, row16, mean16 = ops.bank_loss_finalize(s16, M)
+    assert abs(mean.item() - mean16.item()) < 1e-2 * max(1.0, abs(mean16.item()))
+    dq16 = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse16, 1.0 / B)
+    assert rel_err(dq[:, :D], dq16[:, :D]) < 0.15       # e4m3 keeps 3 mantissa bits of every bank element
+
+
 # ----------------------------------------------------------------------------------- AdamW
 def test_adamw_matches_golden(ops, golden_dir):
     import os

@@ -159,3 +159,20 @@ def test_inbatch_step_loss_and_grads(golden_dir):
         assert (g - r).norm() <= 1e-4 * r.norm() + 1e-7, (k, (g - r).norm().item(), r.norm().item())
         n += 1
     assert n == 61
+
+
+def test_e4m3_quantizer_known_answers():
+    """OCP e4m3fn known values (bias 7, 3 mantissa bits, max 448, RNE): the oracle's fp8 bank format."""
+    from oracle import bank_loss
+    row = torch.tensor([[448.0, 1.0, 1.0625, 1.1875, -0.015625, 2.0 ** -9, 0.0, 240.0]])
+    data, scale = bank_loss.quantize_e4m3(row)
+    assert scale.item() == 1.0
+    # 448 = 0x7E; 1.0 = 0x38; 1.0625 ties to even -> 1.0; 1.1875 ties to even -> 1.25 = 0x3A;
+    # -2^-6 = 0x88 (smallest normal, negative); 2^-9 = smallest subnormal 0x01; 0; 240 = 0x77
+    assert data[0].tolist() == [0x7E, 0x38, 0x38, 0x3A, 0x88, 0x01, 0x00, 0x77]
+    g = torch.Generator().manual_seed(0)
+    bank = torch.nn.functional.normalize(torch.randn(64, 96, generator=g))
+    data, scale = bank_loss.quantize_e4m3(bank)
+    deq = bank_loss.dequantize_e4m3(data, scale)
+    assert (deq - bank).abs().max() <= bank.abs().amax() * 2.0 ** -4          # half an ulp of 3 mantissa bits
+    assert torch.equal(bank_loss.quantize_e4m3(deq)[0], data)                  # idempotent

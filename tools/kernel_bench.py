@@ -61,7 +61,9 @@ def main():
     t = timeit(lambda: ops.colsum(xb)); print(f"  colsum {T}x{4*W}: {t*1e6:8.1f} us  {T*4*W*2/t/1e9:7.1f} GB/s")
     print("== bank (M=40000, D=768)")
     M, D = 40000, 768
-    bank = ops.prepare_bank(torch.nn.functional.normalize(torch.randn(M, D, device=dev)))
+    bank_f = torch.nn.functional.normalize(torch.randn(M, D, device=dev))
+    bank = ops.prepare_bank(bank_f)
+    bank8 = ops.prepare_bank(bank_f, dtype="fp8")
     for B in (32, 256):
         text = torch.randn(B, D, device=dev)
         q32, qb, inv = ops.combine_l2norm_fwd(None, None, text)
@@ -72,6 +74,10 @@ def main():
         lse, row, mean = ops.bank_loss_finalize(st, M)
         t = timeit(lambda: ops.bank_grad_q(qb, bank, labels, 50.0, lse, 1.0 / B))
         print(f"  B={B} grad_q:    {t*1e6:8.1f} us  {M*D*2/t/1e9:7.1f} GB/s (bank bytes)  {4*B*M*D/t/1e12:6.1f} TF")
+        t = timeit(lambda: ops.bank_stats_fwd(qb, bank8, labels, 50.0))
+        print(f"  B={B} stats fwd fp8 bank: {t*1e6:8.1f} us  {M*D/t/1e9:7.1f} GB/s (bank bytes)")
+        t = timeit(lambda: ops.bank_grad_q(qb, bank8, labels, 50.0, lse, 1.0 / B))
+        print(f"  B={B} grad_q    fp8 bank: {t*1e6:8.1f} us  {M*D/t/1e9:7.1f} GB/s (bank bytes)")
     print("== adamw 123.65M")
     n = 123650304
     p = torch.randn(n, device=dev); gr = torch.randn(n, device=dev); m = torch.zeros(n, device=dev); vv = torch.zeros(n, device=dev)
