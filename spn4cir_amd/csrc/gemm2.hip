@@ -18,15 +18,6 @@
 namespace spn {
 
 static constexpr int BK2 = 64;
-#ifndef SPN_NT2_ROLE
-#define SPN_NT2_ROLE 0
-#endif
-#ifndef SPN_NT2_PIPE
-#define SPN_NT2_PIPE 0
-#endif
-#ifndef SPN_NT2_REGSTAGE
-#define SPN_NT2_REGSTAGE 0
-#endif
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -77,28 +68,12 @@ __device__ __forceinline__ void nt2_stage_one(__amdgpu_buffer_rsrc_t rs, char* s
     glds16(rs, sT + R0 * ROWB, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u);
 }
 
-// register-staged variant of one DMA piece: the same 16 B per lane, but global -> VGPR now and VGPR -> LDS later
-template <int PER_WAVE, int BKT>
-__device__ __forceinline__ u32x4 nt2_gload(__amdgpu_buffer_rsrc_t rs, int row0, int ld, int k0, int wid, int lane, int i) {
-    constexpr int CPR = BKT / 8, RPI = 64 / CPR;
-    const int R0 = (wid * PER_WAVE + i) * RPI;
-    const int r = R0 + lane / CPR;
-    const int c = nt2_swz<BKT>(r, lane % CPR);
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u, 0, 0);
-}
-template <int PER_WAVE, int BKT>
-__device__ __forceinline__ void nt2_lstore(char* sT, int wid, int lane, int i, u32x4 v) {
-    constexpr int CPR = BKT / 8, RPI = 64 / CPR, ROWB = BKT * 2;
-    const int R0 = (wid * PER_WAVE + i) * RPI;
-    *(u32x4*)(sT + R0 * ROWB + lane * 16) = v;
-}
-
 template <int BKT>
 __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * (BKT * 2) + (nt2_swz<BKT>(r, c) << 4));
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD, int BKT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M,
                                                                             int N, int K, int lda, int ldb,
@@ -124,69 +99,125 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = zero16();
 
+    // SPN_GEMM_DBG bit 32: clock probe - shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) spent in
+    // the main loop of the last tile, written over the first 8 bytes of the bf16 output
+    const uint64_t dbg_c0 = (ep.dbg & 32) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_r0 = (ep.dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
+
     const int nk = K / BKT;
     auto stage = [&](int kt, int buf) {
         char* s = smem + buf * STAGE;
         nt2_stage<GA, BKT>(rsA, s, m0, lda, kt * BKT, wid, lane);
         nt2_stage<GB, BKT>(rsB, s + A_BYTES, n0, ldb, kt * BKT, wid, lane);
     };
-    if constexpr (SPN_NT2_REGSTAGE && STAGES == 2) {
-    // Register-staged operand pipeline (needs STAGES == 2): piece q of tile kt+2 is loaded global -> VGPR right
-    // after piece q of tile kt+1 has been written VGPR -> LDS, so every piece has one whole k step to land and
-    // the wait before its ds_write is a counted vmcnt on the oldest load only.
-    u32x4 g[GA + GB];
-    if (nk > 0) {
+    if constexpr (SCHED == 2) {
+        // ---- 8-slot staggered schedule (cdna_hip_programming.md "256^2 8-phase template", own chunking) ----
+        // Fixed geometry: 256x256x64 tile, 8 waves (2 x 4), 2 LDS buffers of one k tile each.  A k tile is
+        // consumed in 4 slots, one 64x32 quadrant of the wave's 128x64 output per slot:
+        //   slot 0: read A rows mq0 (8 x b128) + B rows nq0 (4)  -> acc[0..1][0]
+        //   slot 1: read B rows nq1 (4)                          -> acc[0..1][1]
+        //   slot 2: read A rows mq1 (8)                          -> acc[2..3][1]
+        //   slot 3: nothing                                      -> acc[2..3][0]
+        // and staged as 4 chunks of 16 KB (2 DMA per wave each), chunk c of k tile j = the rows read in ONE slot:
+        //   c0 = A mq0, c1 = B nq0 (both read in slot 0), c2 = B nq1 (slot 1), c3 = A mq1 (slot 2).
+        // Every slot is  [LDS reads][one chunk of DMA][counted vmcnt] s_barrier [MFMA x8] s_barrier , and the
+        // waves of the lower M half (wr == 1) run one barrier behind the upper half: on every SIMD one wave is in
+        // its MFMA section while its partner issues memory instructions.  Issue order  c2(j+1), c3(j+1), c0(j+2),
+        // c1(j+2)  in slots 0..3 of k tile j: a chunk is re-staged >= 2 slots after its last read, and a whole k
+        // tile (4 chunks = 8 DMA per wave) stays in flight behind each wait: vmcnt(8), never 0 in steady state.
+        // RAW: a chunk is read one slot after the slot whose pre-barrier wait retired it (both wave halves have
+        // then executed that wait before a barrier the reader has passed).
+        static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && STAGES == 2 && BKT == 64, "phased schedule geometry");
+        auto chunk = [&](int c, int j) {          // stage chunk c of k tile j (wave-uniform j < nk)
+            char* sb = smem + (j & 1) * STAGE;
+            const int k0 = j * BKT;
 #pragma unroll
-        for (int q = 0; q < GA; ++q) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, 0, wid, lane, q);
+            for (int t = 0; t < 2; ++t) {
+                const int i = wid * 2 + t;        // 16 DMA instructions x 8 rows per chunk
+                int row0;
+                if (c == 0 || c == 3) row0 = (i < 8 ? 0 : 128) + (c == 3 ? 64 : 0) + (i & 7) * 8;
+                else row0 = (i >> 2) * 64 + (c == 2 ? 32 : 0) + (i & 3) * 8;
+                const int r = row0 + (lane >> 3);
+                const int cc = nt2_swz<BKT>(r, lane & 7);
+                if (c == 0 || c == 3)
+                    glds16(rsA, sb + row0 * 128, ((uint32_t)(m0 + r) * (uint32_t)lda + (uint32_t)(k0 + cc * 8)) * 2u);
+                else
+                    glds16(rsB, sb + A_BYTES + row0 * 128, ((uint32_t)(n0 + r) * (uint32_t)ldb + (uint32_t)(k0 + cc * 8)) * 2u);
+            }
+        };
+        auto wait_tile = [&](bool full) {          // full: a whole newer k tile was issued behind the awaited chunk
+            if (full) wait_vmcnt<8>();
+            else wait_vmcnt<0>();
+        };
+        if (nk > 0) { chunk(0, 0); chunk(1, 0); chunk(2, 0); chunk(3, 0); }
+        if (nk > 1) { chunk(0, 1); chunk(1, 1); }
+        wait_tile(nk > 1);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger the lower half by one barrier
+        bf16x8 a[2][4], b0[4], b1[4];
+        const int arow = wr * TM + (lane & 31), brow = wc * TN + (lane & 31), cl = lane >> 5;
+        // The MFMA builtins carry no side effects, so instruction selection is free to float them across
+        // s_barrier; the empty volatile asm statements tie their operands (after the first barrier) and their
+        // results (before the second) to the slot.
+#define SPN_SLOT_MFMA(I0, J, BREG)                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+        asm volatile("" : "+v"(BREG[0]), "+v"(BREG[1]), "+v"(BREG[2]), "+v"(BREG[3]));                  \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                              \
+            acc[I0][J] = mfma32(BREG[kk], a[0][kk], acc[I0][J]);                                        \
+            acc[I0 + 1][J] = mfma32(BREG[kk], a[1][kk], acc[I0 + 1][J]);                                \
+        }                                                                                               \
+        asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        __builtin_amdgcn_sched_barrier(0);
+        const bool dma = !(ep.dbg & 2);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sA = smem + (kt & 1) * STAGE;
+            const char* sB = sA + A_BYTES;
+            const bool n1 = kt + 1 < nk && dma, n2 = kt + 2 < nk && dma;
+            const bool rd = !(ep.dbg & 4) || kt == 0;
+            // slot 0
+            if (rd) {
 #pragma unroll
-        for (int q = 0; q < GB; ++q) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, 0, wid, lane, q);
+                for (int kk = 0; kk < 4; ++kk) b0[kk] = nt2_frag<BKT>(sB, brow, kk * 2 + cl);
 #pragma unroll
-        for (int q = 0; q < GA; ++q) nt2_lstore<GA, BKT>(smem, wid, lane, q, g[q]);
-#pragma unroll
-        for (int q = 0; q < GB; ++q) nt2_lstore<GB, BKT>(smem + A_BYTES, wid, lane, q, g[GA + q]);
-    }
-    if (nk > 1) {
-#pragma unroll
-        for (int q = 0; q < GA; ++q) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, BKT, wid, lane, q);
-#pragma unroll
-        for (int q = 0; q < GB; ++q) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, BKT, wid, lane, q);
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tile kt is visible in slot kt&1; nobody reads slot (kt+1)&1 any more
-        const char* sA = smem + (kt & 1) * STAGE;
-        const char* sB = sA + A_BYTES;
-        char* sF = smem + ((kt + 1) & 1) * STAGE;
-        const bool do_wr = kt + 1 < nk, ld2 = kt + 2 < nk;
-        const int kf = (kt + 2) * BKT;
-        bf16x8 a[MI], b[NJ];
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int c = kk * 2 + (lane >> 5);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
-            if (do_wr) {
-#pragma unroll
-                for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q) {
-                    nt2_lstore<GA, BKT>(sF, wid, lane, q, g[q]);
-                    if (ld2) g[q] = nt2_gload<GA, BKT>(rsA, m0, lda, kf, wid, lane, q);
-                }
-#pragma unroll
-                for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q) {
-                    nt2_lstore<GB, BKT>(sF + A_BYTES, wid, lane, q, g[GA + q]);
-                    if (ld2) g[GA + q] = nt2_gload<GB, BKT>(rsB, n0, ldb, kf, wid, lane, q);
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[0][kk] = nt2_frag<BKT>(sA, arow, kk * 2 + cl);
+                    a[1][kk] = nt2_frag<BKT>(sA, arow + 32, kk * 2 + cl);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (n1) chunk(2, kt + 1);
+            wait_tile(n1);                              // c2(kt) for slot 1
+            SPN_SLOT_MFMA(0, 0, b0)
+            // slot 1
+            if (rd) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int kk = 0; kk < 4; ++kk) b1[kk] = nt2_frag<BKT>(sB, brow + 32, kk * 2 + cl);
+            }
+            if (n1) chunk(3, kt + 1);
+            wait_tile(n1);                              // c3(kt) for slot 2
+            SPN_SLOT_MFMA(0, 1, b1)
+            // slot 2
+            if (rd) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[0][kk] = nt2_frag<BKT>(sA, arow + 64, kk * 2 + cl);
+                    a[1][kk] = nt2_frag<BKT>(sA, arow + 96, kk * 2 + cl);
+                }
+            }
+            if (n2) chunk(0, kt + 2);
+            SPN_SLOT_MFMA(2, 1, b1)
+            // slot 3
+            if (n2) chunk(1, kt + 2);
+            if (kt + 1 < nk) wait_tile(n2);             // c0, c1 of k tile kt+1 for its slot 0
+            SPN_SLOT_MFMA(2, 0, b0)
         }
-    }
+#undef SPN_SLOT_MFMA
+        if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two halves
     } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -198,66 +229,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // everyone's part of tile kt landed; everyone is done with tile kt-1
-        // The DMA of tile kt+STAGES-1 is spread over the four k16 steps (after each step's LDS reads,
-        // before its MFMAs) instead of being issued as one burst behind the barrier, where both waves
+        // SCHED 1: the DMA of tile kt+STAGES-1 is spread over the four k16 steps (after each step's LDS reads,
+        // before its MFMAs) instead of being issued as one burst behind the barrier (SCHED 0), where both waves
         // of a SIMD would stall the matrix pipe together.
         const bool do_stage = kt + STAGES - 1 < nk && !(ep.dbg & 2);
         char* sF = smem + fill * STAGE;
         const int kf = (ep.dbg & 1) ? 0 : (kt + STAGES - 1) * BKT;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_BYTES;
-#if SPN_NT2_PIPE
-        // Software-pipelined fragments: the LDS reads of k16 step kk+1 (and this step's share of the next tile's
-        // DMA) are issued BEFORE the MFMAs of step kk, whose operands were read one step earlier.
-        bf16x8 a[2][MI], b[2][NJ];
-        {
-            const int c = lane >> 5;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) a[0][i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[0][j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
-        }
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const int cb = kk & 1, nb = cb ^ 1;
-            if (kk + 1 < KSTEPS) {
-                const int c = (kk + 1) * 2 + (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[nb][i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) b[nb][j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
-            }
-            if (do_stage) {
-#pragma unroll
-                for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
-                    nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q);
-#pragma unroll
-                for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
-                    nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q);
-            }
-#if SPN_NT2_PIPE == 1
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[cb][j], a[cb][i], acc[i][j]);
-#if SPN_NT2_PIPE == 1
-            __builtin_amdgcn_sched_barrier(0);
-#elif SPN_NT2_PIPE == 2
-            // interleave: one memory instruction in the shadow of each MFMA
-#pragma unroll
-            for (int t = 0; t < MI + NJ; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-#endif
-        }
-#else
         bf16x8 a[MI], b[NJ];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -268,21 +247,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = nt2_frag<BKT>(sB, wc * TN + j * 32 + (lane & 31), c);
             }
-            if (SPREAD) {
-#if SPN_NT2_ROLE
-                // role split: in k step kt only the waves of one half (wid>>2 == kt&1; waves w and w+4 share a
-                // SIMD) issue the DMA of the next tile, all of it; their SIMD partners issue none, so the matrix
-                // pipe never has both of its waves parked in VMEM issue at once.
-                if (do_stage && ((wid >> 2) == (kt & 1))) {
-                    constexpr int GA2 = GA * 2, GB2 = GB * 2;
-#pragma unroll
-                    for (int q = kk * ((GA2 + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA2 + KSTEPS - 1) / KSTEPS) && q < GA2; ++q)
-                        nt2_stage_one<GA2, BKT>(rsA, sF, m0, lda, kf, wid & 3, lane, q);
-#pragma unroll
-                    for (int q = kk * ((GB2 + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB2 + KSTEPS - 1) / KSTEPS) && q < GB2; ++q)
-                        nt2_stage_one<GB2, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid & 3, lane, q);
-                }
-#else
+            if (SCHED == 1) {
                 if (do_stage) {
 #pragma unroll
                     for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
@@ -291,7 +256,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                     for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
                         nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q, ep.dbg & 16);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             } else if (kk == 0 && do_stage) {
                 stage(kt + STAGES - 1, fill);
@@ -300,19 +264,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
-            if (SPREAD) __builtin_amdgcn_sched_barrier(0);
+            if (SCHED == 1) __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
-
     }
     // Epilogue.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3, the 4
     // consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
     // Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
     // first staged through LDS (fp32, 16-B units XOR-swizzled by row) and the epilogue math + all
     // global traffic run row-major: one wave instruction = one or two whole rows, fully coalesced.
+    if ((ep.dbg & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
+        uint32_t* o = (uint32_t*)ep.out_bf16;
+        o[0] = (uint32_t)(__builtin_readcyclecounter() - dbg_c0);
+        o[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+        return;
+    }
     if (ep.dbg & 8) {
         float t = 0.f;
 #pragma unroll
@@ -464,11 +432,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, bool SPREAD, int BKT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
 static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
                       hipStream_t st) {
     constexpr int LDS = STAGES * (BM + BN) * BKT * 2;
-    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT, SPREAD, BKT>;
+    auto kern = gemm_nt2_kernel<BM, BN, WM, WN, STAGES, MODE, ACT, SCHED, BKT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -481,6 +449,14 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     return SPN_OK;
 }
 
+static bool nt_phased() {
+    static const bool v = [] {
+        const char* e = getenv("SPN_GEMM_NT_PHASED");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 static bool gemm_spread() {
     static const bool v = [] {
         const char* e = getenv("SPN_GEMM_SPREAD");
@@ -489,12 +465,13 @@ static bool gemm_spread() {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BKT = 64>
+template <int BM, int BN, int WM, int WN, int STAGES, int BKT = 64, bool PHASED = false>
 static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
                         const GemmEpilogue& ep, hipStream_t st) {
-#define SPN_NT2(MODE_, ACT_)                                                                       \
-    (gemm_spread() ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, true, BKT>(A, B, M, N, K, lda, ldb, ep, st) \
-                   : launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, false, BKT>(A, B, M, N, K, lda, ldb, ep, st))
+#define SPN_NT2(MODE_, ACT_)                                                                                   \
+    (PHASED ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, PHASED ? 2 : 1, BKT>(A, B, M, N, K, lda, ldb, ep, st) \
+            : gemm_spread() ? launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, 1, BKT>(A, B, M, N, K, lda, ldb, ep, st) \
+                            : launch_nt2<BM, BN, WM, WN, STAGES, MODE_, ACT_, 0, BKT>(A, B, M, N, K, lda, ldb, ep, st))
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) return SPN_NT2(GEMM_STORE, ACT_NONE);
         if (ep.act == ACT_QUICKGELU) return SPN_NT2(GEMM_STORE, ACT_QUICKGELU);
@@ -534,9 +511,12 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
     switch (gemm_cfg()) {
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
-        case 3: return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
+            if (nt_phased()) return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
+            return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 4: return dispatch_nt2<256, 256, 2, 4, 4, 32>(A, B, M, N, K, lda, ldb, mode, e2, st);   // measured slower
         case 5: return dispatch_nt2<256, 256, 2, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);       // 4 waves x 128x128
+        case 6: return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);   // 8-slot staggered
         default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
     }
 }

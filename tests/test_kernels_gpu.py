@@ -368,3 +368,26 @@ def test_topk_identical_sets(ops, golden_dir):
     for i in range(got2.shape[0]):
         row = [j for j in order[i] if j != int(ex[i])][:10]
         assert list(got2[i]) == row
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (4096, 768, 768), (19712, 768, 3072), (1000, 260, 192)])
+def test_gemm_nt_phased_schedule_race_screen(ops, M, N, K):
+    """The staggered 8-slot schedule orders LDS-DMA writes and ds_reads only by counted vmcnt + barriers.
+    Screen for rare races: 40 launches, half of them while a bandwidth-heavy copy runs on a second stream
+    (perturbs DMA latency), must all be bit-identical to the first and match the fp64 product of the same
+    bf16 operands (fp32 accumulation: 2e-3 relative to the largest output)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)).cuda()
+    b = bf(torch.randn(N, K, generator=g)).cuda()
+    first = ops.gemm_nt(a, b, out_dtype=torch.float32)
+    ref = (a.double() @ b.double().t())
+    assert ((first.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    for it in range(40):
+        if it % 2:
+            with torch.cuda.stream(side):
+                big.add_(1.0)
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32)
+        assert torch.equal(out, first), it
+    torch.cuda.synchronize()

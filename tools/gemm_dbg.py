@@ -14,7 +14,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         for _ in range(20): ops.gemm_nt(a, b)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print(f"  {M}x{N}x{K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF", flush=True)
+        extra = ""
+        if int(os.environ.get("SPN_GEMM_DBG", "0")) & 32:
+            out = ops.gemm_nt(a, b); torch.cuda.synchronize()
+            c = out.view(-1)[:4].view(torch.int32).cpu().tolist()
+            cyc, ticks = c[0] & 0xffffffff, c[1] & 0xffffffff
+            extra = f"  main loop of the last tile: {cyc} shader cycles in {ticks * 10} ns = {cyc / max(ticks, 1) * 100:.0f} MHz"
+        print(f"  {M}x{N}x{K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TF{extra}", flush=True)
 else:
     for dbg in (sys.argv[1:] or ["0", "1", "2", "4", "6", "8", "14"]):
         print(f"== SPN_GEMM_DBG={dbg} CFG={os.environ.get('SPN_GEMM_CFG', 'default')}", flush=True)
