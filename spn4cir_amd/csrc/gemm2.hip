@@ -457,6 +457,14 @@ static bool nt_phased() {
     return v;
 }
 
+static bool tn_phased() {
+    static const bool v = [] {
+        const char* e = getenv("SPN_GEMM_TN_PHASED");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 static bool gemm_spread() {
     static const bool v = [] {
         const char* e = getenv("SPN_GEMM_SPREAD");
@@ -559,7 +567,7 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* sT, int cb, int kk, int l
     return u.v;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int Kr,
                                                                             int N1, int N2, int lda, int ldb,
@@ -599,6 +607,70 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
         tn2_stage<BM, GA>(rsA, s, kb + kt * BK2, lda, m0, wid, lane);
         tn2_stage<BN, GB>(rsB, s + A_BYTES, kb + kt * BK2, ldb, n0, wid, lane);
     };
+    if constexpr (SCHED == 2) {
+        // Staggered schedule as in gemm_nt2_kernel (SCHED 2), with the k16 step as the slot: the LDS image is
+        // k-major, so chunk c of a k tile = its k rows 16c..16c+15 of A and of B (16 KB, 2 DMA per wave) and slot c
+        // reads exactly that chunk (4 + 2 transpose-read fragments) for 8 MFMA over all of the wave's 128x64
+        // output.  Chunk c of k tile j+2 is staged in slot c+2 of k tile j (>= 2 slots after its last read);
+        // five chunks = 10 DMA per wave stay in flight behind each wait: vmcnt(10).
+        static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && STAGES == 2, "phased schedule geometry");
+        auto chunk = [&](int c, int j) {
+            char* sb = smem + (j & 1) * STAGE;
+            const int R0 = c * 16 + wid * 2;
+            const int r = R0 + (lane >> 5), pos16 = lane & 31;
+            const int c32 = (pos16 >> 1) ^ ((r & 3) << 1);
+            const uint32_t kr = (uint32_t)(kb + j * BK2 + r);
+            const uint32_t co = (uint32_t)(c32 * 16 + (pos16 & 1) * 8);
+            glds16(rsA, sb + R0 * 512, (kr * (uint32_t)lda + (uint32_t)m0 + co) * 2u);
+            glds16(rsB, sb + A_BYTES + R0 * 512, (kr * (uint32_t)ldb + (uint32_t)n0 + co) * 2u);
+        };
+        auto wait_chunks = [&](bool full) {
+            if (full) wait_vmcnt<10>();
+            else wait_vmcnt<0>();
+        };
+        if (nk > 0) { chunk(0, 0); chunk(1, 0); chunk(2, 0); chunk(3, 0); }
+        if (nk > 1) { chunk(0, 1); chunk(1, 1); }
+        wait_chunks(nk > 1);
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sA = smem + (kt & 1) * STAGE;
+            const char* sB = sA + A_BYTES;
+            const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = tn2_frag<BM>(sA, wr * TM + i * 32, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = tn2_frag<BN>(sB, wc * TN + j * 32, kk, lane);
+                // slot kk of k tile kt issues chunk (kk+2)&3 of k tile kt+1 (kk < 2) or kt+2 (kk >= 2)
+                if (kk < 2 ? n1 : n2) chunk((kk + 2) & 3, kk < 2 ? kt + 1 : kt + 2);
+                // ... and retires the chunk of the NEXT slot: 5 newer chunks are in flight behind it
+                if (kk < 3 || n1) wait_chunks(kk < 2 ? n1 : n2);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(b[0]), "+v"(b[1]));
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(b[j], a[i], acc[i][j]);
+                if (do_colsum) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) accs[i] = mfma32(ones, a[i], accs[i]);
+                }
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[0][1]),
+                             "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) stage(s, s);
@@ -629,6 +701,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
         }
         cur = cur == STAGES - 1 ? 0 : cur + 1;
         fill = fill == STAGES - 1 ? 0 : fill + 1;
+    }
     }
     float* Cz = C + (size_t)blockIdx.y * split_stride;
 #pragma unroll
@@ -696,11 +769,11 @@ size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2) {
     return ((size_t)s * N1 * N2 + (size_t)s * N1) * sizeof(float);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int SCHED = 0>
 static int launch_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* ws, int splits,
                       int k_chunk, float* cs_ws, hipStream_t st) {
     constexpr int LDS = STAGES * (BM + BN) * 128;
-    auto kern = gemm_tn2_kernel<BM, BN, WM, WN, STAGES>;
+    auto kern = gemm_tn2_kernel<BM, BN, WM, WN, STAGES, SCHED>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -733,7 +806,10 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
         ProfScope prof(PK_GEMM_TN, 2.0 * Kr * N1 * N2, st);
         switch (gemm_cfg()) {
             case 1: rc = launch_tn2<256, 128, 4, 2, 3>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
-            case 3: rc = launch_tn2<256, 256, 2, 4, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
+            case 3:
+                rc = tn_phased() ? launch_tn2<256, 256, 2, 4, 2, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st)
+                                 : launch_tn2<256, 256, 2, 4, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st);
+                break;
             default: rc = launch_tn2<256, 256, 4, 2, 2>(A, B, Kr, N1, N2, lda, ldb, ws, splits, k_chunk, cs_ws, st); break;
         }
     }

@@ -391,3 +391,23 @@ def test_gemm_nt_phased_schedule_race_screen(ops, M, N, K):
         out = ops.gemm_nt(a, b, out_dtype=torch.float32)
         assert torch.equal(out, first), it
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("Kr,N1,N2", [(64, 768, 2304), (200, 768, 768), (4096, 768, 3072), (19712, 3072, 768), (1000, 1032, 2056)])
+def test_gemm_tn_phased_schedule_race_screen(ops, Kr, N1, N2):
+    """Same screen for the weight-gradient kernel (split-K partials + reduction are deterministic)."""
+    g = torch.Generator().manual_seed(Kr + N1 + N2)
+    a = bf(torch.randn(Kr, N1, generator=g)).cuda()
+    b = bf(torch.randn(Kr, N2, generator=g)).cuda()
+    first = ops.gemm_tn(a, b)
+    ref = (a.double().t() @ b.double())
+    assert ((first.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    for it in range(30):
+        if it % 2:
+            with torch.cuda.stream(side):
+                big.add_(1.0)
+        out = ops.gemm_tn(a, b)
+        assert torch.equal(out, first), it
+    torch.cuda.synchronize()
