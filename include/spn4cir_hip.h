@@ -193,6 +193,20 @@ int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void*
 int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- image preprocessing
+ * targetpad_transform (clip4cir/data_utils.py:42-65,84-98): TargetPad -> Resize(dim, BICUBIC) -> CenterCrop(dim) ->
+ * ToTensor -> Normalize on a decoded RGB image, bit-identical to the Pillow/torchvision pipeline the reference
+ * runs on the CPU.  src_rgb: device uint8 [H, W, 3]; pad_x / pad_y: TargetPad's zero borders (virtual);
+ * kx [ow, ksize_x] int32 22-bit fixed-point coefficients and bx [ow, 2] = (first source column, count) of the
+ * horizontal pass over the PADDED width, ky / by likewise for the vertical pass (host-computed, Pillow's
+ * precompute_coeffs); crop_left / crop_top: CenterCrop offsets in the resized image; tmp: device scratch
+ * (H + 2 pad_y) * dim * 3 bytes; out_chw: fp32 [3, dim, dim] (may be NULL), out_u8_hwc: the uint8 crop before
+ * ToTensor [dim, dim, 3] (may be NULL); mean3 / std3: HOST float[3]. */
+int spn_preprocess_image(const uint8_t* src_rgb, int H, int W, int pad_x, int pad_y, const int32_t* kx, const int32_t* bx,
+                         int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y, int crop_left, int crop_top, int dim,
+                         const float* mean3, const float* std3, void* tmp, float* out_chw, uint8_t* out_u8_hwc,
+                         void* stream);
+
 /* ---------------------------------------------------------------- CLIP vision tower (inference)
  * VisionTransformer.forward (clip/model.py:223-242): frozen in stage 2, used by the bank builders
  * (models_negplus.py:59-125) and extract_index_features (utils.py:24-50).  image: fp32 [B,3,res,res]

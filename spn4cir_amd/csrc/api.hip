@@ -352,4 +352,12 @@ int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, f
     return text_bwd_tail(tc(cfg), ids, (char*)acts, grads, (char*)ws, ws_bytes, ST(stream));
 }
 
+int spn_preprocess_image(const uint8_t* src_rgb, int H, int W, int pad_x, int pad_y, const int32_t* kx, const int32_t* bx,
+                         int ksize_x, const int32_t* ky, const int32_t* by, int ksize_y, int crop_left, int crop_top, int dim,
+                         const float* mean3, const float* std3, void* tmp, float* out_chw, uint8_t* out_u8_hwc,
+                         void* stream) {
+    return preprocess_image(src_rgb, H, W, pad_x, pad_y, kx, bx, ksize_x, ky, by, ksize_y, crop_left, crop_top, dim, mean3,
+                            std3, (uint8_t*)tmp, out_chw, out_u8_hwc, ST(stream));
+}
+
 }  // extern "C"

@@ -133,6 +133,11 @@ size_t bank_workspace_bytes(int B, int M, int D);
 int inbatch_grad_t(const bf16_t* q, const bf16_t* t, int ldq, const float* row_lse, int B, int D, float inv_tau,
                    float grad_scale, float* dt, hipStream_t st);
 
+// preprocess.hip (mean3 / std3 are HOST pointers)
+int preprocess_image(const uint8_t* src, int H, int W, int hp, int vp, const int32_t* kx, const int32_t* bx, int ksize_x,
+                     const int32_t* ky, const int32_t* by, int ksize_y, int crop_left, int crop_top, int dim,
+                     const float* mean3, const float* std3, uint8_t* tmp, float* out, uint8_t* out_u8, hipStream_t st);
+
 // topk.hip
 int cosine_scores_f64(const float* q, const float* gallery, int Nq, int Ng, int D, double* out, hipStream_t st);
 int topk_from_scores(const double* scores, int Nq, int Ng, int K, const int32_t* exclude, int32_t* idx, double* val,

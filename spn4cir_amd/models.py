@@ -123,7 +123,12 @@ class CIRPlus(nn.Module):
         self.plus = plus
         self.neg_num = neg_num
         self.tokenizer = tokenizer
+        # callable(PIL image | uint8 [H,W,3]) -> fp32 [3, dim, dim] ON THE DEVICE (data_utils.py:84-98 semantics,
+        # bit-identical output; use it from the main process, not from DataLoader workers)
         self.preprocess = None
+        if transform == "targetpad":
+            from .preprocess import TargetPadTransform
+            self.preprocess = TargetPadTransform(target_ratio, self.input_dim, self.device)
         self.refer_bank = None
         self._target_bank = None
         self._target_bank_dev = None

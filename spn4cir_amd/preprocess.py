@@ -1,0 +1,103 @@
+"""Host side of the GPU image preprocessing (targetpad_transform, clip4cir/data_utils.py:42-65,84-98).
+
+The image is decoded on the host (PIL or any decoder) to uint8 RGB and uploaded once; padding, the two-pass
+bicubic resampling, centre crop, ToTensor and Normalize run in two HIP kernels (csrc/preprocess.hip).  What the
+host computes here is geometry and Pillow's coefficient tables (precompute_coeffs + normalize_coeffs_8bpc,
+double arithmetic), cached per (input size, output size)."""
+import ctypes as C
+import functools
+import math
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .ops import _p, _stream
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@functools.lru_cache(maxsize=4096)
+def _coeffs(in_size, out_size):
+    """Pillow's bicubic window for every output coordinate: (int32 [out, ksize], int32 [out, 2] = (first, count))."""
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / fscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(w)
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << _PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return kk, bounds
+
+
+def targetpad_geometry(w, h, target_ratio, dim):
+    """(pad_x, pad_y, resized_w, resized_h, crop_left, crop_top) of targetpad_transform for a w x h image."""
+    hp = vp = 0
+    if max(w, h) / min(w, h) >= target_ratio:                    # data_utils.py:58-63
+        scaled = max(w, h) / target_ratio
+        hp = max(int((scaled - w) / 2), 0)
+        vp = max(int((scaled - h) / 2), 0)
+    wp, hpad = w + 2 * hp, h + 2 * vp
+    if wp <= hpad:                                               # torchvision Resize(int): shorter side -> dim
+        ow, oh = dim, int(dim * hpad / wp)
+    else:
+        ow, oh = int(dim * wp / hpad), dim
+    return hp, vp, ow, oh, int(round((ow - dim) / 2.0)), int(round((oh - dim) / 2.0))
+
+
+class TargetPadTransform:
+    """GPU `targetpad_transform(target_ratio, dim)`: uint8 RGB [H, W, 3] (numpy / CPU or device tensor, or a PIL
+    image) -> fp32 [3, dim, dim] on the device, bit-identical to the reference's CPU pipeline."""
+
+    def __init__(self, target_ratio=1.25, dim=224, device="cuda", mean=CLIP_MEAN, std=CLIP_STD):
+        self.target_ratio, self.dim, self.device = float(target_ratio), int(dim), torch.device(device)
+        self._mean = (C.c_float * 3)(*mean)
+        self._std = (C.c_float * 3)(*std)
+        self._tables = {}
+
+    def _device_tables(self, in_size, out_size):
+        key = (in_size, out_size)
+        if key not in self._tables:
+            kk, bounds = _coeffs(in_size, out_size)
+            self._tables[key] = (torch.from_numpy(kk).to(self.device), torch.from_numpy(bounds).to(self.device), kk.shape[1])
+        return self._tables[key]
+
+    def __call__(self, image, return_uint8=False):
+        if not torch.is_tensor(image):
+            image = torch.from_numpy(np.array(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8))
+        if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
+            raise ValueError("expected a uint8 RGB image [H, W, 3]")
+        src = image.to(self.device).contiguous()
+        H, W = int(src.shape[0]), int(src.shape[1])
+        hp, vp, ow, oh, left, top = targetpad_geometry(W, H, self.target_ratio, self.dim)
+        kx, bx, ksx = self._device_tables(W + 2 * hp, ow)
+        ky, by, ksy = self._device_tables(H + 2 * vp, oh)
+        d = self.dim
+        tmp = torch.empty((H + 2 * vp) * d * 3, dtype=torch.uint8, device=self.device)
+        out = torch.empty(3, d, d, dtype=torch.float32, device=self.device)
+        u8 = torch.empty(d, d, 3, dtype=torch.uint8, device=self.device) if return_uint8 else None
+        check(lib().spn_preprocess_image(_p(src), H, W, hp, vp, _p(kx), _p(bx), ksx, _p(ky), _p(by), ksy, left, top, d,
+                                         self._mean, self._std, _p(tmp), _p(out), _p(u8), _stream()), "preprocess_image")
+        return (out, u8) if return_uint8 else out
