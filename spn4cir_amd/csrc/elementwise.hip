@@ -67,6 +67,50 @@ int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int
     return SPN_OK;
 }
 
+// The same tile routine over MANY matrices in one launch: `layers` repetitions (strides p_stride / wb_stride) of up
+// to 4 matrices described by d; blockIdx.x -> (layer, matrix, tile).  One launch instead of 4 per layer for the
+// bf16 weight refresh after every optimizer step.
+__global__ void cast_transpose_multi_kernel(const float* __restrict__ p, bf16_t* __restrict__ wb, CastTransposeSet d) {
+    __shared__ float tile[32][33];
+    const int layer = blockIdx.x / d.tile_start[4];
+    int t = blockIdx.x % d.tile_start[4];
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (t >= d.tile_start[i]) m = i;
+    t -= d.tile_start[m];
+    const int rows = d.rows[m], cols = d.cols[m];
+    const float* x = p + (size_t)layer * d.p_stride + d.src[m];
+    bf16_t* y = wb + (size_t)layer * d.wb_stride + d.dst[m];
+    bf16_t* yt = wb + (size_t)layer * d.wb_stride + d.dst_t[m];
+    const int tiles_c = (cols + 31) / 32;
+    const int tr = t / tiles_c, tc = t % tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = tr * 32 + ty + i * 8, c = tc * 32 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = x[(size_t)r * cols + c];
+            y[(size_t)r * cols + c] = f2bf(v);
+        }
+        tile[ty + i * 8][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tc * 32 + ty + i * 8, r = tr * 32 + tx;
+        if (r < rows && c < cols) yt[(size_t)c * rows + r] = f2bf(tile[tx][ty + i * 8]);
+    }
+}
+
+int cast_transpose_multi(const float* p, bf16_t* wb, const CastTransposeSet& d, int layers, hipStream_t st) {
+    if (layers <= 0 || d.tile_start[4] <= 0) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)(layers * d.tile_start[4])), dim3(256), 0, st, p, wb, d);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return SPN_ERR_ARG;
     const int tiles = ((rows + 31) / 32) * ((cols + 31) / 32);

@@ -45,6 +45,13 @@ int gemm_cfg();
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
 int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);             // y[c][r] = x[r][c]
 int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int cols, hipStream_t st);
+struct CastTransposeSet {           // up to 4 matrices per repetition (element offsets), see cast_transpose_multi
+    int64_t src[4], dst[4], dst_t[4];
+    int rows[4], cols[4];
+    int tile_start[5];              // prefix sums of the 32x32 tile counts; [4] = tiles per repetition
+    int64_t p_stride, wb_stride;
+};
+int cast_transpose_multi(const float* p, bf16_t* wb, const CastTransposeSet& d, int layers, hipStream_t st);
 int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int accumulate, float* ws, size_t ws_bytes,
                 hipStream_t st);
 size_t colsum_workspace_bytes(int rows, int cols);

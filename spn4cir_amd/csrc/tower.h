@@ -93,6 +93,7 @@ int64_t block_bf16_size(int W);
 BlockParams block_params_at(const float* p, const bf16_t* wb, int W);
 BlockGrads block_grads_at(float* g, int W);
 int block_refresh_bf16(const float* p, bf16_t* wb, int W, hipStream_t st);
+int blocks_refresh_bf16(const float* p, int64_t p_stride, bf16_t* wb, int64_t wb_stride, int layers, int W, hipStream_t st);
 size_t block_act_bytes(const BlockCfg& c);
 BlockActs block_acts_at(char* base, const BlockCfg& c);
 size_t block_bwd_scratch_bytes(const BlockCfg& c);

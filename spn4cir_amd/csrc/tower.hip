@@ -70,6 +70,24 @@ int block_refresh_bf16(const float* p, bf16_t* wb, int W, hipStream_t st) {
     return SPN_OK;
 }
 
+// all `layers` blocks in ONE launch (p / wb point at block 0, strides in elements)
+int blocks_refresh_bf16(const float* p, int64_t p_stride, bf16_t* wb, int64_t wb_stride, int layers, int W, hipStream_t st) {
+    int64_t o[13];
+    block_param_offsets(W, o);
+    const int64_t w2 = (int64_t)W * W;
+    CastTransposeSet d;
+    const int64_t src[4] = {o[2], o[4], o[8], o[10]};
+    const int64_t dst[4] = {0, 6 * w2, 8 * w2, 16 * w2}, dst_t[4] = {3 * w2, 7 * w2, 12 * w2, 20 * w2};
+    const int rows[4] = {3 * W, W, 4 * W, W}, cols[4] = {W, W, W, 4 * W};
+    d.tile_start[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+        d.src[i] = src[i]; d.dst[i] = dst[i]; d.dst_t[i] = dst_t[i]; d.rows[i] = rows[i]; d.cols[i] = cols[i];
+        d.tile_start[i + 1] = d.tile_start[i] + ((rows[i] + 31) / 32) * ((cols[i] + 31) / 32);
+    }
+    d.p_stride = p_stride; d.wb_stride = wb_stride;
+    return cast_transpose_multi(p, wb, d, layers, st);
+}
+
 size_t block_act_bytes(const BlockCfg& c) {
     const size_t T = (size_t)c.rows(), W = c.W;
     size_t b = 0;
@@ -332,8 +350,7 @@ int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStre
     SPN_TRY(text_check(c));
     TextLayout t;
     text_layout(c, &t);
-    for (int l = 0; l < c.layers; ++l)
-        SPN_TRY(block_refresh_bf16(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W, st));
+    SPN_TRY(blocks_refresh_bf16(params + t.blocks, t.block_size, wb, t.bf16_block_size, c.layers, c.W, st));
     SPN_TRY(cast_transpose_f32_bf16(params + t.text_proj, wb + t.bf16_text_proj, wb + t.bf16_text_proj_t, c.W, c.D, st));
     return SPN_OK;
 }
