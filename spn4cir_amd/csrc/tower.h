@@ -99,8 +99,19 @@ BlockActs block_acts_at(char* base, const BlockCfg& c);
 size_t block_bwd_scratch_bytes(const BlockCfg& c);
 size_t block_op_ws_bytes(const BlockCfg& c);
 int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st);
+// Optional overlap of the weight-gradient (TN) GEMMs with the rest of a block's backward: they feed nothing
+// downstream, so they run on a side stream behind events while the main stream continues with the data path
+// (NT GEMMs, LayerNorm / attention backward).  dxb_alt: second bf16 residual-gradient buffer [T, W] (the TN
+// GEMMs still read the old one while LayerNorm backward writes the new one); ws2: their own split-K workspace.
+struct BwdOverlap {
+    hipStream_t side;
+    hipEvent_t ev[6];
+    bf16_t* dxb_alt;
+    float* ws2;
+    size_t ws2_bytes;
+};
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
-              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st);
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov = nullptr);
 
 // training path (CLIP kind 0 only): activations kept per layer, clip4cir/models.py:156-158 (wo_bank first stage)
 size_t vision_train_act_bytes(const VisionCfg& c);

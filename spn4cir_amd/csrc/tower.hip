@@ -190,7 +190,7 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
 
 // dx / dx_bf16: gradient w.r.t. the block output on entry, w.r.t. the block input on exit.
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
-              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st) {
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov) {
     const int T = c.rows(), W = c.W;
     const size_t Ts = (size_t)T;
     char* p = scratch;
@@ -201,28 +201,53 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
     float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
 
+    // weight-gradient GEMMs: side stream + own workspace when overlapping, otherwise in line
+    const hipStream_t sw = ov ? ov->side : st;
+    float* wws = ov ? ov->ws2 : ws;
+    const size_t wws_bytes = ov ? ov->ws2_bytes : ws_bytes;
+    bf16_t* dxb_mid = ov ? ov->dxb_alt : dx_bf16;     // the residual gradient between the two halves of the block
+    auto fork = [&](int i) -> int {                    // side stream may start once the main stream got here
+        if (!ov) return SPN_OK;
+        hipError_t e = hipEventRecord(ov->ev[i], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ov->side, ov->ev[i], 0);
+        return e == hipSuccess ? SPN_OK : (int)e;
+    };
+    auto join = [&](int i) -> int {                    // main stream waits for everything enqueued on the side stream
+        if (!ov) return SPN_OK;
+        hipError_t e = hipEventRecord(ov->ev[i], ov->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ov->ev[i], 0);
+        return e == hipSuccess ? SPN_OK : (int)e;
+    };
+
     // MLP
+    SPN_TRY(fork(0));                                  // dx_bf16 is final
     {
         GemmEpilogue e;
         e.aux_in = A.pre; e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
         SPN_TRY(gemm_nt(dx_bf16, P.w_proj_t, T, 4 * W, W, W, W, GEMM_DACT, e, st));
     }
-    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, wws, wws_bytes, sw));
+    if (ov) {                                          // ev[4]: the side stream no longer reads dx_bf16
+        hipError_t e = hipEventRecord(ov->ev[4], ov->side);
+        if (e != hipSuccess) return (int)e;
+    }
+    SPN_TRY(fork(1));                                  // dpre is final
     {
         GemmEpilogue e;
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dpre, P.w_fc_t, T, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, ws, ws_bytes, st));
-    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dx_bf16, G.ln2_g, G.ln2_b, 0, T, W, ws,
+    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, wws, wws_bytes, sw));
+    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dxb_mid, G.ln2_g, G.ln2_b, 0, T, W, ws,
                           ws_bytes, st));
     // attention
+    SPN_TRY(fork(2));                                  // dxb_mid is final
     {
         GemmEpilogue e;
         e.out_bf16 = dattn; e.ldc = W;
-        SPN_TRY(gemm_nt(dx_bf16, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
+        SPN_TRY(gemm_nt(dxb_mid, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dx_bf16, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dxb_mid, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, wws, wws_bytes, sw));
     {
         AttnBwdArgs g;
         AttnArgs& a = g.f;
@@ -237,14 +262,22 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         g.delta = delta;
         SPN_TRY(attention_bwd(g, st));
     }
+    SPN_TRY(fork(3));                                  // dqkv is final
     {
         GemmEpilogue e;
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dqkv, P.w_qkv_t, T, W, 3 * W, 3 * W, 3 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, ws, ws_bytes, st));
+    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, wws, wws_bytes, sw));
+    if (ov) {                                          // LayerNorm backward rewrites dx_bf16: w_proj's GEMM must be done with it
+        hipError_t e = hipStreamWaitEvent(st, ov->ev[4], 0);
+        if (e != hipSuccess) return (int)e;
+    }
     SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, dx_bf16, G.ln1_g, G.ln1_b, 0, T, W, ws,
                           ws_bytes, st));
+    // every parameter gradient of the block is final in `st` order on return (DDP bucket hooks rely on it), and
+    // the scratch / dxb_alt buffers are free for the next block
+    SPN_TRY(join(5));
     return SPN_OK;
 }
 
@@ -321,12 +354,48 @@ static TextActs text_acts_at(char* base, const TextCfg& c) {
     return A;
 }
 
+static size_t tn_side_ws_bytes(const BlockCfg& c) {
+    const int T = c.rows(), W = c.W;
+    size_t m = 0;
+    auto mx = [&](size_t v) { if (v > m) m = v; };
+    mx(gemm_tn_workspace_bytes(T, W, 4 * W));
+    mx(gemm_tn_workspace_bytes(T, 4 * W, W));
+    mx(gemm_tn_workspace_bytes(T, W, W));
+    mx(gemm_tn_workspace_bytes(T, 3 * W, W));
+    return align256(m);
+}
+
+// SPN_BWD_OVERLAP=1 (opt-in) runs the weight-gradient GEMMs of the text tower's backward on a side stream.
+// Measured on config 2: 19.0 -> 18.5 ms per step (+2.7 %), but the co-running kernels stretch each other
+// (gemm_nt 83 -> 98 us, gemm_tn 90 -> 151 us), so per-kernel timings stop being meaningful; off by default.
+// (Two processes sharing ONE GPU with it enabled crawl - the 2-rank single-GPU tests took 13 min instead of 4 s.)
+// The side stream and its events are created once per process (one process per GPU).
+static const BwdOverlap* bwd_overlap(bf16_t* dxb_alt, float* ws2, size_t ws2_bytes, BwdOverlap* out) {
+    static const bool on = [] {
+        const char* e = getenv("SPN_BWD_OVERLAP");
+        return e && e[0] == '1';
+    }();
+    if (!on) return nullptr;
+    static BwdOverlap base;
+    static bool ok = [] {
+        if (hipStreamCreateWithFlags(&base.side, hipStreamNonBlocking) != hipSuccess) return false;
+        for (int i = 0; i < 6; ++i)
+            if (hipEventCreateWithFlags(&base.ev[i], hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }();
+    if (!ok) return nullptr;
+    *out = base;
+    out->dxb_alt = dxb_alt; out->ws2 = ws2; out->ws2_bytes = ws2_bytes;
+    return out;
+}
+
 size_t text_ws_bytes(const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
     const size_t T = (size_t)bc.rows();
     size_t b = block_bwd_scratch_bytes(bc);
     b += align256(T * c.W * 4);              // dx
-    b += align256(T * c.W * 2);              // dx_bf16
+    b += 2 * align256(T * c.W * 2);          // dx_bf16 + its alternate (overlapped backward)
+    b += align256(tn_side_ws_bytes(bc));     // split-K workspace of the side-stream weight-gradient GEMMs
     b += align256((size_t)c.B * c.D * 2);    // dfeats bf16
     b += align256((size_t)c.B * c.W * 4);    // dln_e
     b += align256((size_t)c.B * c.W * 4);    // de
@@ -398,6 +467,9 @@ struct TextBwdWs {
     char* scratch;
     float* dx;
     bf16_t* dxb;
+    bf16_t* dxb2;
+    float* ws2;
+    size_t ws2_bytes;
     bf16_t* dfb;
     float *dln, *de;
     float* opws;
@@ -413,6 +485,9 @@ static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w
     w->scratch = p; p += block_bwd_scratch_bytes(bc);
     w->dx = (float*)take(T * c.W * 4);
     w->dxb = (bf16_t*)take(T * c.W * 2);
+    w->dxb2 = (bf16_t*)take(T * c.W * 2);
+    w->ws2_bytes = tn_side_ws_bytes(bc);
+    w->ws2 = (float*)take(w->ws2_bytes);
     w->dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
     w->dln = (float*)take((size_t)c.B * c.W * 4);
     w->de = (float*)take((size_t)c.B * c.W * 4);
@@ -459,7 +534,9 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
     BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
     const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
-    return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st);
+    BwdOverlap ovs;
+    const BwdOverlap* ov = bwd_overlap(w.dxb2, w.ws2, w.ws2_bytes, &ovs);
+    return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st, ov);
 }
 
 // phase 3: token / positional embedding gradients
