@@ -218,7 +218,8 @@ def _bank_case(B, M, D, seed):
 
 @pytest.mark.parametrize("B,M,D,tau", [(4, 500, 64, 0.01), (32, 4099, 512, 0.02), (16, 40000, 768, 0.03),
                                         (70, 3000, 768, 0.02), (256, 40000, 768, 0.02), (33, 1500, 640, 0.02),
-                                        (2048, 5000, 768, 0.02), (512, 20000, 768, 0.02)])
+                                        (2048, 5000, 768, 0.02), (512, 20000, 768, 0.02),
+                                        (1, 7, 128, 0.02), (3, 33, 256, 0.01)])   # bank smaller than one tile, B = 1
 def test_bank_infonce(ops, B, M, D, tau):
     from oracle import bank_loss
     text, refer, bank, ridx, labels = _bank_case(B, M, D, B + M)
