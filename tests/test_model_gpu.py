@@ -264,3 +264,29 @@ def test_config1_inbatch_step_matches_reference(golden_dir):
         n += 1
     assert n == 61
     print("config 1: loss", loss.item(), "ref", ref_loss, "worst per-parameter grad error", worst)
+
+
+def test_zscir_models_bank_protocol(golden_dir):
+    """zscir/models_bank.py argument order + per-triplet reference rows: reproduces the `loss_trip` capture of the
+    reference (plus=False path) and its text_projection gradient."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    from spn4cir_amd.models_bank import CIRPlus
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    s = np.load(os.path.join(golden_dir, "cirplus_step.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    model = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"))
+    model.refer_bank = torch.from_numpy(s["trip_bank"])
+    model.target_bank = torch.from_numpy(s["target_bank"])
+    B = z["ids"].shape[0]
+    out = model.forward(None, torch.from_numpy(z["ids"]), None, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]),
+                        torch.from_numpy(s["ref_img_ids"]), grad_ckpt=True)
+    loss = out["bank_loss"]
+    ref = float(s["loss_trip"])
+    assert abs(loss.item() - ref) < 1e-2 * max(1.0, abs(ref))
+    loss.backward()
+    g = dict(model.clip.named_parameters())["text_projection"].grad.cpu()
+    r = torch.from_numpy(s["grad_trip_text_projection"])
+    assert ((g - r).norm() / r.norm()).item() < 5e-2
