@@ -84,7 +84,7 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
 //   dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat));  dgamma = sum_r dy*xhat;  dbeta = sum_r dy
 // Each wave walks rows wave_id, wave_id+nwaves, ... and keeps per-column dgamma/dbeta partials in
 // registers; partials go to ws[nwaves_total][2][W] and are folded by a second kernel.
-static constexpr int LNB_BLOCKS = 512;
+static constexpr int LNB_BLOCKS = 1024;
 
 template <typename TDY, int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
@@ -106,8 +106,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
     for (int row = wave; row < rows; row += nwaves) {
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[LN_MAXV], g[LN_MAXV];
+        f32x4 xh[LN_MAXV], g[LN_MAXV], dprev[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        // the gradient already in dx (accumulate) is fetched together with x and dy, not after the row reduction
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + i * 64;
+            dprev[i] = (accumulate_dx && c < nv) ? *(const f32x4*)(dx + (size_t)row * W + c * 4) : f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
                 float* dp = dx + (size_t)row * W + c * 4;
-                if (accumulate_dx) o += *(const f32x4*)dp;
+                o += dprev[i];
                 *(f32x4*)dp = o;
                 if (dxb) {
                     bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
