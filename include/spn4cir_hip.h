@@ -277,6 +277,7 @@ int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* w
  * kernel ids: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd, 4 bank fwd, 5 bank bwd.
  * total_work is FLOPs for ids 0-3 and algorithmic HBM bytes for ids 4-5. */
 int spn_prof_enable(int max_records);
+int spn_prof_select(unsigned mask, int sample_every); /* bit k = kernel class k; record every n-th launch */
 int spn_prof_disable(void);
 int spn_prof_reset(void);
 int spn_prof_collect(int kernel_id, double* total_ms, double* total_work, int* count);

@@ -110,6 +110,7 @@ _SIGS = {
     "spn_fusion_fwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, vp]),
     "spn_fusion_bwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_prof_enable": (i32, [i32]),
+    "spn_prof_select": (i32, [C.c_uint, i32]),
     "spn_prof_disable": (i32, []),
     "spn_prof_reset": (i32, []),
     "spn_prof_collect": (i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),

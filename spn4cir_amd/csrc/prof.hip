@@ -10,15 +10,24 @@ struct ProfRec { int kid; double work; hipEvent_t a, b; bool closed; };
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static size_t g_pool_next = 0;
+static unsigned g_mask = ~0u;          // kernel classes being recorded
+static int g_every = 1;                // ... every g_every-th launch of each
+static int g_seen[PK_COUNT];
+static bool g_open[PK_COUNT];          // the current launch of the class is being recorded
 
 void prof_record(int kid, double work, hipStream_t st, bool end) {
+    if (kid < 0 || kid >= PK_COUNT || !((g_mask >> kid) & 1u)) return;
     if (!end) {
-        if (g_pool_next + 2 > g_pool.size()) return;   // pool exhausted: stop recording
+        g_open[kid] = (g_seen[kid]++ % g_every) == 0;
+        if (!g_open[kid]) return;
+        if (g_pool_next + 2 > g_pool.size()) { g_open[kid] = false; return; }   // pool exhausted: stop recording
         ProfRec r{kid, work, g_pool[g_pool_next], g_pool[g_pool_next + 1], false};
         g_pool_next += 2;
         (void)hipEventRecord(r.a, st);
         g_recs.push_back(r);
     } else {
+        if (!g_open[kid]) return;
+        g_open[kid] = false;
         for (size_t i = g_recs.size(); i-- > 0;) {
             if (g_recs[i].kid == kid && !g_recs[i].closed) {
                 (void)hipEventRecord(g_recs[i].b, st);
@@ -45,7 +54,19 @@ int spn_prof_enable(int max_records) {
     }
     g_recs.clear();
     g_pool_next = 0;
+    for (int i = 0; i < PK_COUNT; ++i) { g_seen[i] = 0; g_open[i] = false; }
     g_prof_on = true;
+    return 0;
+}
+
+/* Restrict the recording to the kernel classes in `mask` (bit = ProfKernel id) and to every `sample_every`-th
+ * launch of each: an event pair around a launch keeps it from overlapping its neighbours' ramp-up / drain, so a
+ * bench that times every kernel slows the step it measures (7 % on config 2). */
+int spn_prof_select(unsigned mask, int sample_every) {
+    if (sample_every <= 0) return SPN_ERR_ARG;
+    g_mask = mask;
+    g_every = sample_every;
+    for (int i = 0; i < PK_COUNT; ++i) { g_seen[i] = 0; g_open[i] = false; }
     return 0;
 }
 
