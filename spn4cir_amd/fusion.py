@@ -141,3 +141,68 @@ class BlipBankStep:
         dproj = ops.combine_l2norm_bwd(q, inv, dq)
         grads = self.enc.backward(dproj)
         return mean, grads, dtau, q
+
+
+class BlipStage2Trainer:
+    """blip4cir stage-2 loop (blip4cir/train.py:110-129) on one GPU or data-parallel over RCCL (BASELINE config 4):
+    triplets sharded across ranks, fusion encoder replicated, bank replicated or sharded exactly as for the CLIP
+    path (spn4cir_amd.distributed.BankLossDP), flat-gradient all-reduce, fused AdamW on the flat buffer and a
+    scalar AdamW for the learnable temperature (models.py:29).  The reference optimises [encoder, tau] with
+    AdamW(lr, betas (0.9, 0.999), eps 1e-7) and default weight decay."""
+
+    def __init__(self, encoder, tau=0.03, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
+                 bank_mode="sharded", label_smoothing=0.0, learn_tau=True, bucket_elems=8 << 20):
+        from . import distributed as dp
+        self.enc, self.group = encoder, group
+        self.lr, self.betas, self.eps, self.wd, self.ls = lr, betas, eps, weight_decay, label_smoothing
+        self.world, self.rank = dp._world(group)
+        self.loss_dp = dp.BankLossDP(ops, group, bank_mode if (self.world > 1 or dp._FORCE) else "replicated")
+        self.reducer = dp.GradBucketReducer(encoder.grads, group, bucket_elems)
+        self._shard_range = dp.shard_range
+        self.m = torch.zeros_like(encoder.params)
+        self.v = torch.zeros_like(encoder.params)
+        dev = encoder.device
+        self.tau = torch.tensor([float(tau)], dtype=torch.float32, device=dev)      # learnable temperature
+        self.learn_tau = learn_tau
+        self._tau_m = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._tau_v = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._tau_g = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self._bank, self._m_begin, self._M_total = None, 0, 0
+
+    def set_bank(self, target_bank, bank_dtype="bf16"):
+        """target_bank fp32 [M, Dp], L2-normalised rows; sharded mode keeps only this rank's rows on the device."""
+        dev = self.enc.device
+        self._M_total = target_bank.shape[0]
+        if self.loss_dp.mode == "sharded" and self.world > 1:
+            b, e = self._shard_range(self._M_total, self.world, self.rank)
+            self._m_begin = b
+            self._bank = ops.prepare_bank(target_bank[b:e].to(dev, torch.float32).contiguous(), bank_dtype)
+        else:
+            self._m_begin = 0
+            self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32), bank_dtype)
+
+    def step(self, ids, mask, ref_tokens, labels):
+        """ids/mask int32 [B_local, L], ref_tokens fp32 [B_local, S, E], labels int64 [B_local] global bank rows.
+        Returns the global mean loss (1-element device tensor)."""
+        enc = self.enc
+        tau = float(self.tau.item()) if self.learn_tau else float(self.tau[0])
+        proj = enc.forward(ids, mask, ref_tokens)
+        q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
+        ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / tau, self.ls)
+        dq = self.loss_dp.backward(ctx)[:, :enc.Dp].contiguous()
+        if self.learn_tau:
+            self._tau_g.copy_((-(q * dq).sum() / tau).reshape(1))
+        dproj = ops.combine_l2norm_bwd(q, inv, dq)
+        enc.backward(dproj)
+        self.reducer.on_span_ready(0, enc.n_params)
+        self.reducer.finish()
+        self.step_count += 1
+        ops.adamw_step(enc.params, enc.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)
+        enc.mark_stale()
+        if self.learn_tau:
+            if self.world > 1:
+                torch.distributed.all_reduce(self._tau_g, group=self.group)
+            ops.adamw_step(self.tau, self._tau_g, self._tau_m, self._tau_v, self.step_count, self.lr, self.betas, self.eps,
+                           self.wd)
+        return ctx["loss"]

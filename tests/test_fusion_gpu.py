@@ -76,3 +76,71 @@ def test_blip_vit_matches_oracle():
     assert (1 - cos_t).max() < 1e-3
     cos_p = torch.nn.functional.cosine_similarity(pooled.cpu().double(), pooled_ref.double(), dim=-1)
     assert (1 - cos_p).max() < 1e-3
+
+
+def _blip_setup(golden_dir):
+    from spn4cir_amd.fusion import FusionEncoder, fusion_cfg_from_state_dict
+    z = np.load(os.path.join(golden_dir, "blip_fusion.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    c = fusion_cfg_from_state_dict(sd)
+    enc = FusionEncoder(c["hidden"], c["layers"], c["heads"], c["intermediate"], c["enc_width"],
+                        sd["text_proj.weight"].shape[0], c["vocab"], c["max_pos"], "cuda")
+    enc.load_state_dict(sd)
+    return z, enc
+
+
+def _blip_worker(rank, world, port, mode, golden_dir, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd.fusion import BlipStage2Trainer
+        z, enc = _blip_setup(golden_dir)
+        tr = BlipStage2Trainer(enc, tau=float(z["tau"]), lr=1e-3, bank_mode=mode)
+        tr.set_bank(torch.from_numpy(z["bank"]))
+        B = z["ids"].shape[0]
+        bl = B // world
+        sl = slice(rank * bl, (rank + 1) * bl)
+        losses = []
+        for _ in range(2):
+            losses.append(tr.step(torch.from_numpy(z["ids"][sl]).cuda(), torch.from_numpy(z["mask"][sl]).cuda(),
+                                  torch.from_numpy(z["enc"][sl]).cuda(), torch.from_numpy(z["labels"][sl]).cuda()).item())
+        out.put((rank, losses, enc.params.cpu().numpy(), tr.tau.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+def test_blip_trainer_two_ranks_match_single_process(golden_dir, mode):
+    """BASELINE config 4's data-parallel step (two ranks sharing the test GPU over gloo): loss trajectory, updated
+    encoder parameters and the learnable temperature equal the single-process step on the whole batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import socket
+    import torch.multiprocessing as mp
+    from spn4cir_amd.fusion import BlipStage2Trainer
+    z, enc = _blip_setup(golden_dir)
+    B = z["ids"].shape[0]
+    if B % 2:
+        pytest.skip("odd golden batch")
+    tr = BlipStage2Trainer(enc, tau=float(z["tau"]), lr=1e-3)
+    tr.set_bank(torch.from_numpy(z["bank"]))
+    ref_losses = [tr.step(torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["mask"]).cuda(),
+                          torch.from_numpy(z["enc"]).cuda(), torch.from_numpy(z["labels"]).cuda()).item() for _ in range(2)]
+    assert abs(ref_losses[0] - float(z["loss"])) < 2e-2 * max(1.0, abs(float(z["loss"])))
+    ref_params, ref_tau = enc.params.cpu(), tr.tau.item()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_blip_worker, args=(r, 2, port, mode, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, losses, params, tau in res:
+        assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-3, (losses, ref_losses)
+        assert abs(tau - ref_tau) < 1e-5 * max(1.0, abs(ref_tau))
+        d = (torch.from_numpy(params) - ref_params).abs().max().item()
+        assert d < 5e-4, d          # two AdamW steps at lr 1e-3: split-K / reduction-order noise only

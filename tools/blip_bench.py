@@ -3,12 +3,14 @@
 tau 0.03, AdamW; reference token bank resident on the device in fp32 (a random [N_img, 577, 768] slab).
 
     python tools/blip_bench.py [--enc-width 768|1024] [--steps 10]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 tools/blip_bench.py
+        (config 4: data parallel, B triplets per GPU, bank sharded over the ranks)
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from spn4cir_amd import ops
-from spn4cir_amd.fusion import BlipBankStep, FusionEncoder
+from spn4cir_amd.fusion import BlipStage2Trainer, FusionEncoder
 
 
 def main():
@@ -21,8 +23,16 @@ def main():
     ap.add_argument("--images", type=int, default=2000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
     a = ap.parse_args()
-    dev = torch.device("cuda")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
     g = torch.Generator().manual_seed(0)
     enc = FusionEncoder(768, 12, 12, 3072, a.enc_width, 256, 30524, 512, dev)
     with torch.no_grad():
@@ -40,17 +50,13 @@ def main():
     ids = (ids * mask).to(dev); mask = mask.to(dev)
     ref_bank = torch.randn(a.images, a.tokens, a.enc_width, device=dev)          # per-image token bank (models.py:76)
     ridx = torch.randint(0, a.images, (B,), generator=g).to(dev)
-    bank = ops.prepare_bank(torch.nn.functional.normalize(torch.randn(a.bank, 256, generator=g)).to(dev))
     labels = torch.randint(0, a.bank, (B,), generator=g).to(dev)
-    step = BlipBankStep(enc, tau=0.03)
-    m, v = torch.zeros_like(enc.params), torch.zeros_like(enc.params)
+    trainer = BlipStage2Trainer(enc, tau=0.03, lr=5e-6, bank_mode=a.bank_mode)
+    trainer.set_bank(torch.nn.functional.normalize(torch.randn(a.bank, 256, generator=g)))
 
     def one(i):
         tokens = ref_bank[ridx]                                                  # [B, 577, E] gather (models.py:98)
-        loss, grads, dtau, q = step.step(ids, mask, tokens, bank, labels)
-        ops.adamw_step(enc.params, grads, m, v, i + 1, 5e-6, (0.9, 0.999), 1e-7, 0.01)
-        enc.mark_stale()
-        return loss
+        return trainer.step(ids, mask, tokens, labels)
 
     for i in range(a.warmup):
         loss = one(i)
@@ -59,14 +65,21 @@ def main():
     for i in range(a.steps):
         loss = one(a.warmup + i)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = (time.perf_counter() - t0) / a.steps
+    if rank != 0:
+        dist.destroy_process_group()
+        return
     T, TS, W, I, E = B * L, B * a.tokens, 768, 3072, a.enc_width
     fwd = 12 * (2 * T * W * 3 * W + 2 * T * W * W * 2 + 2 * TS * E * 2 * W + 2 * T * W * I * 2
                 + 4 * B * 12 * L * L * 64 + 4 * B * 12 * L * a.tokens * 64)
     print(json.dumps({"workload": f"blip4cir stage-2 step, BERT-base fusion, B={B}, L={L}, {a.tokens} image tokens, "
-                                  f"enc_width {E}, bank {a.bank}x256", "triplets_per_s": round(B / dt, 1),
+                                  f"enc_width {E}, bank {a.bank}x256, {world} GPU(s)", "triplets_per_s": round(B * world / dt, 1),
                       "ms_per_step": round(dt * 1e3, 2), "loss": round(loss.item(), 4),
-                      "model_tflops": round(3 * fwd / dt / 1e12, 1), "params_M": round(enc.n_params / 1e6, 2)}))
+                      "model_tflops_per_gpu": round(3 * fwd / dt / 1e12, 1), "params_M": round(enc.n_params / 1e6, 2)}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
