@@ -412,3 +412,47 @@ def test_gemm_tn_phased_schedule_race_screen(ops, Kr, N1, N2):
         out = ops.gemm_tn(a, b)
         assert torch.equal(out, first), it
     torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- seeded shape sweeps
+def test_shape_sweep_gemm(ops):
+    """40 seeded random shapes through both GEMM kernels (ragged M / N / Kr, every K multiple of 64, duplicate rows):
+    against the fp64 product of the same bf16 operands, 2e-3 relative to the largest output."""
+    rng = np.random.default_rng(123)
+    for it in range(40):
+        M, N = int(rng.integers(1, 1400)), int(rng.integers(1, 200)) * 8
+        K = int(rng.integers(1, 20)) * 64
+        g = torch.Generator().manual_seed(it)
+        a, b = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, K, generator=g)).cuda()
+        ref = a.double() @ b.double().t()
+        out = ops.gemm_nt(a, b, out_dtype=torch.float32)
+        assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3, ("nt", M, N, K)
+        Kr, N1 = int(rng.integers(1, 3000)), int(rng.integers(1, 150)) * 8
+        x, y = bf(torch.randn(Kr, N1, generator=g)).cuda(), bf(torch.randn(Kr, N, generator=g)).cuda()
+        ref = x.double().t() @ y.double()
+        out = ops.gemm_tn(x, y)
+        assert ((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item() < 2e-3, ("tn", Kr, N1, N)
+
+
+def test_shape_sweep_bank(ops):
+    """25 seeded (B, M, D, tau) draws incl. M not a multiple of the 32-row tile, M < 32, labels on the first / last
+    row and duplicated labels: loss statistics and dq against the oracle on the same bf16 operands."""
+    from oracle import bank_loss
+    rng = np.random.default_rng(321)
+    dims = [64, 128, 256, 512, 640, 768, 1024]
+    for it in range(25):
+        B, M = int(rng.integers(1, 300)), int(rng.integers(1, 9000))
+        D, tau = int(dims[rng.integers(0, len(dims))]), float(rng.choice([0.01, 0.02, 0.03, 0.07]))
+        text, refer, bank, ridx, labels = _bank_case(B, M, D, 1000 + it)
+        if B > 2:
+            labels[1] = labels[2]                      # duplicate targets inside a batch
+        q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+        bank_b = ops.prepare_bank(dev(bank))
+        qr, br = qb[:, :D].cpu().float(), bank_b[:, :D].cpu().float()
+        lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+        stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau)
+        lse, row, mean = ops.bank_loss_finalize(stats, M)
+        assert (lse.cpu().double() - lse_ref).abs().max() < 3e-4, (B, M, D, tau)
+        assert abs(mean.item() - row_ref.mean().item()) < 3e-4, (B, M, D, tau)
+        dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)
+        assert rel_err(dq[:, :D], bank_loss.infonce_grad_q(qr, br, labels, tau)) < 2e-2, (B, M, D, tau)
