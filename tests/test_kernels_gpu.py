@@ -456,3 +456,40 @@ def test_shape_sweep_bank(ops):
         assert abs(mean.item() - row_ref.mean().item()) < 3e-4, (B, M, D, tau)
         dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)
         assert rel_err(dq[:, :D], bank_loss.infonce_grad_q(qr, br, labels, tau)) < 2e-2, (B, M, D, tau)
+
+
+def test_output_canaries(ops):
+    """Out-of-bounds screen (SURVEY section 5): outputs are carved out of larger buffers filled with a sentinel;
+    ragged shapes (rows / columns that do not fill a tile) must leave every byte outside the output untouched."""
+    import ctypes as C
+    from spn4cir_amd._lib import check, lib
+    from spn4cir_amd.ops import _p, _stream, workspace
+    SENT = -12345.0
+    for (M, N, K) in [(1, 8, 64), (257, 264, 128), (1000, 260, 192), (300, 776, 64)]:
+        g = torch.Generator().manual_seed(M)
+        a, b = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, K, generator=g)).cuda()
+        pad = 4096
+        buf = torch.full((pad + M * N + pad,), SENT, dtype=torch.float32, device="cuda")
+        out = buf[pad:pad + M * N]
+        check(lib().spn_gemm_nt(_p(a), _p(b), M, N, K, K, K, None, 0, None, _p(out), None, N, _stream()), "gemm_nt")
+        torch.cuda.synchronize()
+        assert (buf[:pad] == SENT).all() and (buf[pad + M * N:] == SENT).all(), ("nt f32", M, N, K)
+        ref = a.double() @ b.double().t()
+        assert ((out.view(M, N).double() - ref).abs().max() / ref.abs().max()).item() < 2e-3
+        bufb = torch.full((pad + M * N + pad,), SENT, dtype=torch.bfloat16, device="cuda")
+        outb = bufb[pad:pad + M * N]
+        check(lib().spn_gemm_nt(_p(a), _p(b), M, N, K, K, K, None, 0, _p(outb), None, None, N, _stream()), "gemm_nt")
+        torch.cuda.synchronize()
+        sb = torch.tensor(SENT, dtype=torch.bfloat16).item()
+        assert (bufb[:pad].float() == sb).all() and (bufb[pad + M * N:].float() == sb).all(), ("nt bf16", M, N, K)
+    for (Kr, N1, N2) in [(5, 8, 8), (333, 264, 776), (2000, 776, 2312)]:
+        g = torch.Generator().manual_seed(Kr)
+        x, y = bf(torch.randn(Kr, N1, generator=g)).cuda(), bf(torch.randn(Kr, N2, generator=g)).cuda()
+        pad = 4096
+        buf = torch.full((pad + N1 * N2 + pad,), SENT, dtype=torch.float32, device="cuda")
+        out = buf[pad:pad + N1 * N2].view(N1, N2)
+        ops.gemm_tn(x, y, out=out)
+        torch.cuda.synchronize()
+        assert (buf[:pad] == SENT).all() and (buf[pad + N1 * N2:] == SENT).all(), ("tn", Kr, N1, N2)
+        ref = x.double().t() @ y.double()
+        assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3
