@@ -308,7 +308,44 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
         if (ep.bias && n < N) bias_lo = *(const f32x4*)(ep.bias + n);
         if (ep.bias && hi) bias_hi = *(const f32x4*)(ep.bias + n + 4);
+        constexpr int ITERS = (CHUNK + NW * RPI - 1) / (NW * RPI);   // rows of a chunk handled by one lane
         for (int ch = 0; ch < NCH; ++ch) {
+            // the epilogue's global READS of this chunk (pre-activation / residual) are issued first, so that their
+            // latency hides behind the LDS staging of the accumulators instead of stalling every row
+            [[maybe_unused]] bf16x8 pf_aux[ITERS];
+            [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
+            if constexpr (MODE == GEMM_DACT || MODE == GEMM_RESID) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int rr = wid * RPI + lane / LPR + it * NW * RPI;
+                    const int m = m0 + ch * CHUNK + rr;
+                    const bool ok = rr < CHUNK && m < M && n < N;
+                    if constexpr (MODE == GEMM_DACT) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf_aux[it][e] = (bf16_t)0.f;
+                        if (ok) {
+                            const size_t o = (size_t)m * ep.ldc + n;
+                            if (wide) {
+                                pf_aux[it] = *(const bf16x8*)(ep.aux_in + o);
+                            } else {
+                                const bf16x4 p0 = *(const bf16x4*)(ep.aux_in + o);
+                                bf16x4 p1 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                                if (hi) p1 = *(const bf16x4*)(ep.aux_in + o + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { pf_aux[it][e] = p0[e]; pf_aux[it][4 + e] = p1[e]; }
+                            }
+                        }
+                    } else {
+                        pf_r0[it] = f32x4{0, 0, 0, 0};
+                        pf_r1[it] = f32x4{0, 0, 0, 0};
+                        if (ok) {
+                            const float* rp = ep.resid + (size_t)m * ep.ldr + n;
+                            pf_r0[it] = *(const f32x4*)rp;
+                            if (hi) pf_r1[it] = *(const f32x4*)(rp + 4);
+                        }
+                    }
+                }
+            }
             __syncthreads();   // operand tiles (or the previous chunk) are no longer read
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -325,9 +362,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                     }
             }
             __syncthreads();
-            for (int rr = wid * RPI + lane / LPR; rr < CHUNK; rr += NW * RPI) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int rr = wid * RPI + lane / LPR + it * NW * RPI;
                 const int m = m0 + ch * CHUNK + rr;
-                if (m >= M || n >= N) continue;
+                if (rr >= CHUNK || m >= M || n >= N) continue;
                 f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
                 f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
                 v0 = v0 * ep.alpha + bias_lo;
@@ -359,20 +398,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                         }
                     }
                 } else if constexpr (MODE == GEMM_RESID) {
-                    const float* rp = ep.resid + (size_t)m * ep.ldr + n;
-                    v0 += *(const f32x4*)rp;
-                    if (hi) v1 += *(const f32x4*)(rp + 4);
+                    v0 += pf_r0[it];
+                    v1 += pf_r1[it];
                 } else if constexpr (MODE == GEMM_DACT) {
-                    bf16x8 p;
-                    if (wide) {
-                        p = *(const bf16x8*)(ep.aux_in + o);
-                    } else {
-                        const bf16x4 p0 = *(const bf16x4*)(ep.aux_in + o);
-                        bf16x4 p1 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                        if (hi) p1 = *(const bf16x4*)(ep.aux_in + o + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { p[e] = p0[e]; p[4 + e] = p1[e]; }
-                    }
+                    const bf16x8 p = pf_aux[it];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
