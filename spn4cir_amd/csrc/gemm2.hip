@@ -733,21 +733,53 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
     }
     }
     float* Cz = C + (size_t)blockIdx.y * split_stride;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wr * TM + i * 32 + (lane & 31);
-        if (m >= N1) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
-                if (n >= N2) continue;
-                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *(f32x4*)(Cz + (size_t)m * ldc + n) = v;
-            }
+    if (do_colsum && lane < 32) {
         // every row of the ones-product equals the column sum; lanes 0..31 hold columns m
-        if (do_colsum && lane < 32) colsum_out[(size_t)blockIdx.y * N1 + m] = accs[i][0];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wr * TM + i * 32 + lane;
+            if (m < N1) colsum_out[(size_t)blockIdx.y * N1 + m] = accs[i][0];
+        }
+    }
+    // split-K partials leave through LDS (same staging as gemm_nt2's epilogue): the MFMA layout would store 16 B
+    // per row per instruction; row-major, one wave instruction writes two whole 512-B rows.
+    {
+        constexpr int LDS_BYTES = STAGES * STAGE;
+        constexpr int CR0 = LDS_BYTES / (BN * 4);
+        constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;
+        constexpr int NCH = (BM + CHUNK - 1) / CHUNK;
+        constexpr int LPR = BN / 8, RPI = 64 / LPR;
+        static_assert(LPR <= 64 && 64 % LPR == 0, "row mapping");
+        float* sC = (float*)smem;
+        const int u = lane % LPR, n = n0 + u * 8;
+        const bool hi = n + 4 < N2;              // N2 % 8 == 0 is checked by the launcher; kept for symmetry
+        for (int ch = 0; ch < NCH; ++ch) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int rl = wr * TM + i * 32 + (lane & 31);
+                if (rl / CHUNK != ch) continue;
+                const int r = rl - ch * CHUNK;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *(f32x4*)(sC + r * BN + ((unit ^ (r & 15)) << 2)) = v;
+                    }
+            }
+            __syncthreads();
+            for (int rr = wid * RPI + lane / LPR; rr < CHUNK; rr += NW * RPI) {
+                const int m = m0 + ch * CHUNK + rr;
+                if (m >= N1 || n >= N2) continue;
+                const f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
+                const f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
+                float* o = Cz + (size_t)m * ldc + n;
+                *(f32x4*)o = v0;
+                if (hi) *(f32x4*)(o + 4) = v1;
+            }
+        }
     }
 }
 
