@@ -40,6 +40,30 @@ __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ base, int l
     }
 }
 
+// The same for NSRC matrices at once: every global load of the block is in flight before the first LDS store
+// (the one-matrix loop above serialises load -> wait -> store per 16 B and per matrix).
+template <int ROWS, int NTHREADS, int NSRC>
+__device__ __forceinline__ void load_rows_multi(const bf16_t* const (&base)[NSRC], const int (&ld)[NSRC], int L, int tid,
+                                                bf16_t* const (&dst)[NSRC]) {
+    constexpr int ITER = (ROWS * 8 + NTHREADS - 1) / NTHREADS;
+    bf16x8 v[NSRC][ITER];
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTHREADS, r = i >> 3, ch = i & 7;
+            v[k][it] = zero8s();
+            if (i < ROWS * 8 && r < L) v[k][it] = *(const bf16x8*)(base[k] + (size_t)r * ld[k] + ch * 8);
+        }
+#pragma unroll
+    for (int k = 0; k < NSRC; ++k)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTHREADS, r = i >> 3, ch = i & 7;
+            if (i < ROWS * 8) *(bf16x8*)(dst[k] + r * SLD + ch * 8) = v[k][it];
+        }
+}
+
 // fragment: "row" index (lane&15) walks LDS rows, 8 k-values contiguous along the row
 __device__ __forceinline__ bf16x8 rfrag(const bf16_t* s, int ld, int row_base, int kcol, int lane) {
     return *(const bf16x8*)(s + (row_base + (lane & 15)) * ld + kcol + (lane >> 4) * 8);
@@ -86,8 +110,12 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
     const bf16_t* kb = a.k + row0 * a.ldk + h * SHD;
     const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
     const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
-    load_rows<KP>(kb, a.ldk, L, tid, NT * 64, Ks);
-    load_rows<KP>(vb, a.ldv, L, tid, NT * 64, Vs);
+    {
+        const bf16_t* const bases[2] = {kb, vb};
+        const int lds_[2] = {a.ldk, a.ldv};
+        bf16_t* const dsts[2] = {Ks, Vs};
+        load_rows_multi<KP, NT * 64, 2>(bases, lds_, L, tid, dsts);
+    }
     const int q0 = w * 16, qrow = q0 + (lane & 15);
     bf16x8 qf[2];
 #pragma unroll
@@ -184,10 +212,12 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
     const bf16_t* dob = g.d_o + row0 * g.lddo + h * SHD;
     const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
-    load_rows<TR_>(qb, a.ldq, L, tid, NT * 64, Qs);
-    load_rows<TR_>(kb, a.ldk, L, tid, NT * 64, Ks);
-    load_rows<TR_>(vb, a.ldv, L, tid, NT * 64, Vs);
-    load_rows<TR_>(dob, g.lddo, L, tid, NT * 64, Os);
+    {
+        const bf16_t* const bases[4] = {qb, kb, vb, dob};
+        const int lds_[4] = {a.ldq, a.ldk, a.ldv, g.lddo};
+        bf16_t* const dsts[4] = {Qs, Ks, Vs, Os};
+        load_rows_multi<TR_, NT * 64, 4>(bases, lds_, L, tid, dsts);
+    }
     for (int i = tid; i < PLD; i += NT * 64) {           // the zero row of P / dS
         Pm[ZR * PLD + i] = (bf16_t)0.0f;
         Dm[ZR * PLD + i] = (bf16_t)0.0f;
