@@ -428,7 +428,9 @@ __global__ void bank_loss_finalize_kernel(const float* __restrict__ stats, int n
 
 size_t bank_workspace_bytes(int B, int M, int D) {
     const BankChunking c = bank_chunking(B, M);
-    const size_t a = (size_t)c.nchunks * B * 4 * sizeof(float);
+    size_t a = (size_t)c.nchunks * B * 4 * sizeof(float);
+    const size_t g = (size_t)gemm_bank_stats_tiles(M) * B * 4 * sizeof(float);   // GEMM-path statistics partials
+    if (g > a) a = g;
     const size_t b = (size_t)c.nchunks * B * D * sizeof(float);
     return a > b ? a : b;
 }
@@ -480,6 +482,26 @@ static int bank_check(const BankArgs& a) {
 int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st) {
     int rc = bank_check(a);
     if (rc) return rc;
+    // Large batches: the logits pass as a 256x256-tile GEMM with a statistics epilogue (the bank is read once, the
+    // queries come from L2); the streaming kernel below re-reads every bank tile once per 32 queries, which is the
+    // right trade only while B is small (8-way data parallel: 32 per GPU).  SPN_BANK_GEMM=0 forces streaming.
+    static const bool use_gemm = [] {
+        const char* e = getenv("SPN_BANK_GEMM");
+        return !(e && e[0] == '0');
+    }();
+    if (use_gemm && !a.bank_scale && a.B >= 128 && a.D % 64 == 0) {
+        const int nt = gemm_bank_stats_tiles(a.M);
+        if (ws_bytes < (size_t)nt * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
+        {
+            const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
+            ProfScope prof(PK_BANK_FWD, bytes, st);
+            rc = gemm_bank_stats(a.q, a.bank, a.B, a.M, a.D, a.ldq, a.D, a.labels, a.inv_tau, a.m_begin, ws, st);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, ws, nt, a.B, stats);
+        SPN_CHECK_LAUNCH();
+        return SPN_OK;
+    }
     const BankChunking c = bank_chunking(a.B, a.M);
     if (ws_bytes < (size_t)c.nchunks * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
     SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)

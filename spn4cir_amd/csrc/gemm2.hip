@@ -366,9 +366,46 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             for (int it = 0; it < ITERS; ++it) {
                 const int rr = wid * RPI + lane / LPR + it * NW * RPI;
                 const int m = m0 + ch * CHUNK + rr;
-                if (rr >= CHUNK || m >= M || n >= N) continue;
+                if (rr >= CHUNK || m >= M) continue;          // wave-uniform per row pair for the shuffles below
+                if (MODE != GEMM_BANKSTATS && n >= N) continue;
                 f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
                 f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
+                if constexpr (MODE == GEMM_BANKSTATS) {
+                    // this lane's 8 logits of row m -> {max, sum exp, sum, label logit}, merged over the LPR lanes
+                    // that share the row (consecutive lanes: xor shuffles below LPR stay inside the row)
+                    const int64_t lab = ep.bs_labels[m] - (int64_t)ep.bs_m_begin;
+                    float mx = -INFINITY, sl = 0.f, lv = -INFINITY, l = 0.f;
+                    float z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (e < 4 ? v0[e] : v1[e - 4]) * ep.bs_inv_tau;
+                        const bool ok = n + e < N;
+                        z[e] = ok ? x : -INFINITY;
+                        if (ok) {
+                            mx = fmaxf(mx, x);
+                            sl += x;
+                            if ((int64_t)(n + e) == lab) lv = x;
+                        }
+                    }
+                    if (mx > -INFINITY) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) l += __expf(z[e] - mx);
+                    }
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) {
+                        const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
+                        const float mn = fmaxf(mx, m2);
+                        if (mn > -INFINITY) l = l * __expf(mx - mn) + l2 * __expf(m2 - mn);
+                        mx = mn;
+                        sl += __shfl_xor(sl, off, 64);
+                        lv = fmaxf(lv, __shfl_xor(lv, off, 64));
+                    }
+                    if (u == 0) {
+                        const int tile_n = n0 / BN;
+                        *(f32x4*)(ep.bs_out + ((size_t)tile_n * M + m) * 4) = f32x4{mx, l, sl, lv};
+                    }
+                    continue;
+                }
                 v0 = v0 * ep.alpha + bias_lo;
                 v1 = v1 * ep.alpha + bias_hi;
                 const size_t o = (size_t)m * ep.ldc + n;
@@ -526,6 +563,19 @@ static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
     }
 #undef SPN_NT2
     return SPN_ERR_ARG;
+}
+
+int gemm_bank_stats_tiles(int M) { return (M + 255) / 256; }
+
+int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
+                    float inv_tau, int m_begin, float* partial, hipStream_t st) {
+    if (B <= 0 || M <= 0 || D <= 0 || !labels || !partial) return SPN_ERR_ARG;
+    if (D % BK2 || ldq % 8 || ldb % 8) return SPN_ERR_SHAPE;
+    if ((uint64_t)B * ldq * 2 >= (1ull << 32) || (uint64_t)M * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    GemmEpilogue e;
+    e.bs_labels = labels; e.bs_out = partial; e.bs_inv_tau = inv_tau; e.bs_m_begin = m_begin;
+    e.ldc = 8;
+    return launch_nt2<256, 256, 2, 4, 2, GEMM_BANKSTATS, ACT_NONE, 2, 64>(q, bank, B, M, D, ldq, ldb, e, st);
 }
 
 int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode, const GemmEpilogue& ep,

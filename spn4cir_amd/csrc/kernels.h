@@ -5,7 +5,7 @@
 
 namespace spn {
 
-enum { GEMM_STORE = 0, GEMM_RESID = 1, GEMM_DACT = 2 };
+enum { GEMM_STORE = 0, GEMM_RESID = 1, GEMM_DACT = 2, GEMM_BANKSTATS = 3 };
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2 };
 
 struct GemmEpilogue {
@@ -20,6 +20,13 @@ struct GemmEpilogue {
     int act = ACT_NONE;
     float alpha = 1.0f;
     int direct_store = 0;            // gemm2 only: 1 = store from the MFMA layout (no LDS staging)
+    // GEMM_BANKSTATS (gemm2, 256x256 tile only): A = queries [B, D], B = bank rows [M, D]; nothing is stored but the
+    // per-row softmax statistics of each 256-column tile: bs_out[(tile_n * B + row) * 4] = {max, sum exp, sum, label logit}
+    // of logits * bs_inv_tau (the layout bank_stats_fold_kernel reduces)
+    const int64_t* bs_labels = nullptr;
+    float* bs_out = nullptr;
+    float bs_inv_tau = 1.0f;
+    int bs_m_begin = 0;
     int dbg = 0;                     // gemm2 only, SPN_GEMM_DBG bottleneck-elimination bits (wrong results): 1 = every k tile
                                      // re-reads k0 = 0, 2 = no DMA after the prologue, 4 = LDS fragments read once per
                                      // k step, 8 = no epilogue
@@ -35,6 +42,10 @@ size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2);
 // gemm2.hip (second generation; gemm_nt / gemm_tn dispatch to these unless SPN_GEMM_V1=1)
 int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
              const GemmEpilogue& ep, hipStream_t st);
+// logits statistics of q [B, D] against bank [M, D] on the GEMM path; partial [ceil(M/256)][B][4] floats
+int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
+                    float inv_tau, int m_begin, float* partial, hipStream_t st);
+int gemm_bank_stats_tiles(int M);
 int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
              float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
