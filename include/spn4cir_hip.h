@@ -242,6 +242,21 @@ int spn_vision_fwd_train(const spn_vision_cfg* cfg, const float* params, const v
 int spn_vision_bwd(const spn_vision_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
                    const float* dfeats, float* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- fp32-exact encode mode (validation)
+ * The forward of the two CLIP towers (clip/model.py:223-242, 345-358) with every GEMM on the f32-input MFMA
+ * (an f32 fmaf chain), fp32 activations and fp32 attention: for Recall@K validation, where the bf16 towers'
+ * feature error (1 - cos ~ 4e-5) is enough to flip near-ties of a ranking.  Reads the fp32
+ * parameters directly (no bf16 mirror); inference only; text: dense layout (cfg->T == 0); vision: kind 0. */
+size_t spn_text_exact_ws_bytes(const spn_text_cfg* cfg);
+int spn_text_fwd_exact(const spn_text_cfg* cfg, const float* params, const int32_t* ids, void* ws, size_t ws_bytes,
+                       float* feats, void* stream);
+size_t spn_vision_exact_ws_bytes(const spn_vision_cfg* cfg);
+int spn_vision_fwd_exact(const spn_vision_cfg* cfg, const float* params, const float* image, void* ws, size_t ws_bytes,
+                         float* feats, void* stream);
+/* C[M,N] = act(alpha * A[M,K] . op(B) + bias) (+ resid), all fp32; op(B) = B[N,K]^T (b_is_kn = 0) or B[K,N] (1) */
+int spn_gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int b_is_kn, const float* bias,
+                 int act, const float* resid, int ldr, float* C, int ldc, float alpha, void* stream);
+
 /* ---------------------------------------------------------------- BLIP fusion encoder
  * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of
  * blip4cir/models.py:95-105.  ids [B,L] int32 (ids[:,0] = [ENC]), mask [B,L] int32 {0,1} (may be NULL),

@@ -102,6 +102,11 @@ _SIGS = {
     "spn_bank_stats_fwd_fp8": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "spn_bank_grad_q_fp8": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_preprocess_image": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "spn_text_exact_ws_bytes": (sz, [C.POINTER(TextCfg)]),
+    "spn_text_fwd_exact": (i32, [C.POINTER(TextCfg), vp, vp, vp, sz, vp, vp]),
+    "spn_vision_exact_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
+    "spn_vision_fwd_exact": (i32, [C.POINTER(VisionCfg), vp, vp, vp, sz, vp, vp]),
+    "spn_gemm_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, f32, vp]),
     "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),

@@ -360,4 +360,24 @@ int spn_preprocess_image(const uint8_t* src_rgb, int H, int W, int pad_x, int pa
                             std3, (uint8_t*)tmp, out_chw, out_u8_hwc, ST(stream));
 }
 
+size_t spn_text_exact_ws_bytes(const spn_text_cfg* cfg) { return cfg ? text_exact_ws_bytes(tc(cfg)) : 0; }
+size_t spn_vision_exact_ws_bytes(const spn_vision_cfg* cfg) { return cfg ? vision_exact_ws_bytes(vc(cfg)) : 0; }
+
+int spn_text_fwd_exact(const spn_text_cfg* cfg, const float* params, const int32_t* ids, void* ws, size_t ws_bytes,
+                       float* feats, void* stream) {
+    if (!cfg || !params || !ids || !ws || !feats) return SPN_ERR_ARG;
+    return text_fwd_exact(tc(cfg), params, ids, (char*)ws, ws_bytes, feats, ST(stream));
+}
+
+int spn_vision_fwd_exact(const spn_vision_cfg* cfg, const float* params, const float* image, void* ws, size_t ws_bytes,
+                         float* feats, void* stream) {
+    if (!cfg || !params || !image || !ws || !feats) return SPN_ERR_ARG;
+    return vision_fwd_exact(vc(cfg), params, image, (char*)ws, ws_bytes, feats, ST(stream));
+}
+
+int spn_gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int b_is_kn, const float* bias,
+                 int act, const float* resid, int ldr, float* C, int ldc, float alpha, void* stream) {
+    return gemm_f32(A, B, M, N, K, lda, ldb, b_is_kn, bias, act, resid, ldr, C, ldc, alpha, ST(stream));
+}
+
 }  // extern "C"

@@ -121,6 +121,16 @@ int vision_fwd_train(const VisionCfg& c, const float* params, const bf16_t* wb, 
 int vision_bwd(const VisionCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats, float* grads,
                char* ws, size_t ws_bytes, hipStream_t st);
 
+// exact.hip: fp32-exact inference of the CLIP towers (f32-input MFMA GEMMs, fp32 attention) for validation
+int gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int b_kn, const float* bias, int act,
+             const float* resid, int ldr, float* C, int ldc, float alpha, hipStream_t st);
+size_t text_exact_ws_bytes(const TextCfg& c);
+int text_fwd_exact(const TextCfg& c, const float* params, const int32_t* ids, char* ws, size_t ws_bytes, float* feats,
+                   hipStream_t st);
+size_t vision_exact_ws_bytes(const VisionCfg& c);
+int vision_fwd_exact(const VisionCfg& c, const float* params, const float* image, char* ws, size_t ws_bytes, float* feats,
+                     hipStream_t st);
+
 void text_layout(const TextCfg& c, TextLayout* t);
 size_t text_act_bytes(const TextCfg& c);
 size_t text_ws_bytes(const TextCfg& c);

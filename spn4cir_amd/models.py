@@ -72,13 +72,15 @@ def _attach(root, dotted, param):
 class CIRPlus(nn.Module):
     def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
                  device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
-                 tokenizer=None, pack_eot=False, wo_bank=False):
+                 tokenizer=None, pack_eot=False, wo_bank=False, exact_eval=False):
         """`clip_model_name`: path to a CLIP state-dict file (as clip.load accepts, clip/clip.py:120-123),
         a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline).
         `pack_eot`: run the text tower on the live rows only (everything after a caption's EOT token is dead
         under the causal mask); same loss and gradients, ~L/mean_len fewer rows."""
         super().__init__()
         self.pack_eot = bool(pack_eot)
+        # exact_eval: encode_image / encode_text outside of training run the fp32-exact towers (validation mode)
+        self.exact_eval = bool(exact_eval)
         self.wo_bank = bool(wo_bank)   # clip4cir/models.py:23: in-batch negatives, visual tower trainable
         self._pack = (None, 0)
         self.device = torch.device(device)
@@ -280,11 +282,15 @@ class CIRPlus(nn.Module):
         if self.vision is None:
             raise RuntimeError("this checkpoint has no ViT image tower (ModifiedResNet towers are not implemented)")
         with torch.no_grad():
+            if self.exact_eval:
+                return self.vision.forward_exact(image.to(self.device, torch.float32))
             return self.vision.forward(image)
 
     def encode_text(self, text):
         """list[str] (or pre-tokenised ids) -> un-normalised text features [B, D] (models_negplus.py:43-46)."""
         ids = self.tokenize(text)
+        if self.exact_eval and not torch.is_grad_enabled():
+            return self.tower.forward_exact(ids)
         return self.tower.forward(ids, *self._pack)
 
     def element_wise_sum(self, refer_image_feats, text_feats):

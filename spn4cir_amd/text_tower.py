@@ -146,6 +146,20 @@ class TextTower:
         self._last_T = T
         return feats
 
+    def forward_exact(self, ids):
+        """fp32-exact features (f32-input MFMA GEMMs, fp32 attention; inference only): for validation / retrieval,
+        where the bf16 tower's ~1e-2 relative feature error can flip near-ties of a ranking."""
+        if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
+            raise ValueError("ids must be a contiguous int32 device tensor")
+        B, L = ids.shape
+        cfg = self._cfg(B, L)
+        need = lib().spn_text_exact_ws_bytes(C.byref(cfg))
+        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        check(lib().spn_text_fwd_exact(C.byref(cfg), _p(self.params), _p(ids), _p(ws), ws.numel(), _p(feats), _stream()),
+              "text_fwd_exact")
+        return feats
+
     def backward(self, dfeats):
         """d(loss)/d(feats) fp32 [B, D] -> fills self.grads (overwrites) and returns it."""
         ids = self._last

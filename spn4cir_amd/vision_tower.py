@@ -107,6 +107,19 @@ class VisionTower:
                   "vision_refresh_bf16")
             self._stale = False
 
+    def forward_exact(self, image):
+        """fp32-exact image features of the CLIP tower (see TextTower.forward_exact)."""
+        if self.kind != 0:
+            raise RuntimeError("the exact mode exists for the CLIP towers only")
+        image = image.to(self.device, torch.float32).contiguous()
+        B = image.shape[0]
+        cfg = self._cfg(B)
+        ws = torch.empty(lib().spn_vision_exact_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        check(lib().spn_vision_fwd_exact(C.byref(cfg), _p(self.params), _p(image), _p(ws), ws.numel(), _p(feats), _stream()),
+              "vision_fwd_exact")
+        return feats
+
     # ------------------------------------------------------------------ training (CLIP tower, wo_bank / first stage)
     def forward_train(self, image):
         """As forward(), but keeps every layer's activations for backward() (clip4cir/models.py:156-158 runs the

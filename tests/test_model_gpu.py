@@ -290,3 +290,45 @@ def test_zscir_models_bank_protocol(golden_dir):
     g = dict(model.clip.named_parameters())["text_projection"].grad.cpu()
     r = torch.from_numpy(s["grad_trip_text_projection"])
     assert ((g - r).norm() / r.norm()).item() < 5e-2
+
+
+def test_exact_encode_mode_matches_fp32_oracle(golden_dir):
+    """fp32-exact towers (f32-input MFMA, fp32 attention): features against the REFERENCE's own fp32 outputs captured in
+    tiny_clip.npz - 1e-5 relative to the largest feature (accumulation order is the only difference) - and, on a
+    synthetic retrieval task, top-K index sets identical to the fp32 oracle end to end."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    from oracle import clip_text, recall
+    from spn4cir_amd.models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    model = CIRPlus(sd, device=torch.device("cuda"), exact_eval=True)
+    with torch.no_grad():
+        tf = model.encode_text(torch.from_numpy(z["ids"])).cpu()
+        vf = model.encode_image(torch.from_numpy(z["image"]).cuda()).cpu()
+    tref, vref = torch.from_numpy(z["text_feats"]), torch.from_numpy(z["image_feats"])
+    assert (tf - tref).abs().max() < 1e-5 * tref.abs().max().clamp_min(1.0), (tf - tref).abs().max()
+    assert (vf - vref).abs().max() < 1e-5 * vref.abs().max().clamp_min(1.0), (vf - vref).abs().max()
+    # end-to-end ranking identity on a ViT-B/32-sized text tower
+    from spn4cir_amd import synthetic
+    from spn4cir_amd.text_tower import TextTower
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-B/32"]
+    sd2 = synthetic.text_state_dict(W, layers, D, seed=0)
+    ids = synthetic.token_ids(24, seed=1)
+    tower = TextTower(W, layers, heads, D, 49408, 77, "cuda")
+    tower.load_clip_state_dict(sd2)
+    t_gpu = tower.forward_exact(ids.cuda()).cpu()
+    with torch.no_grad():
+        t_cpu = clip_text.encode_text(sd2, ids)
+    assert (t_gpu - t_cpu).abs().max() < 2e-5 * t_cpu.abs().max()
+    g = torch.Generator().manual_seed(9)
+    gallery = torch.nn.functional.normalize(torch.randn(6000, D, generator=g))
+    ref = torch.randn(24, D, generator=g)
+    og, _ = recall.ranked_indices(torch.nn.functional.normalize(ref + t_gpu).numpy(), gallery.numpy())
+    oc, _ = recall.ranked_indices(torch.nn.functional.normalize(ref + t_cpu).numpy(), gallery.numpy())
+    same10 = np.mean([set(og[i, :10]) == set(oc[i, :10]) for i in range(24)])
+    same50 = np.mean([set(og[i, :50]) == set(oc[i, :50]) for i in range(24)])
+    print("exact mode: top-10 / top-50 set identity", same10, same50)
+    assert same10 == 1.0 and same50 >= 0.95

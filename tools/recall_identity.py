@@ -29,12 +29,14 @@ def main():
     tower = TextTower(W, layers, heads, D, 49408, 77, "cuda")
     tower.load_clip_state_dict(sd)
     t_gpu = tower.forward(ids.cuda()).cpu()
+    t_exact = tower.forward_exact(ids.cuda()).cpu()
     with torch.no_grad():
         t_cpu = clip_text.encode_text(sd, ids)
     out = {"model": a.model, "queries": a.queries, "gallery": a.gallery,
            "text_feature_1_minus_cos_max": float((1 - torch.nn.functional.cosine_similarity(t_gpu.double(), t_cpu.double())).max())}
-    for name, gal in (("isotropic random gallery", gallery),):
-        pg = torch.nn.functional.normalize(ref_feats + t_gpu)
+    for name, gal, tq in (("isotropic random gallery, bf16 tower", gallery, t_gpu),
+                          ("isotropic random gallery, fp32-exact tower (forward_exact)", gallery, t_exact)):
+        pg = torch.nn.functional.normalize(ref_feats + tq)
         pc = torch.nn.functional.normalize(ref_feats + t_cpu)
         og, sg = recall.ranked_indices(pg.numpy(), gal.numpy())
         oc, sc = recall.ranked_indices(pc.numpy(), gal.numpy())
