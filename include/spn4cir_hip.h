@@ -257,6 +257,18 @@ int spn_vision_fwd_exact(const spn_vision_cfg* cfg, const float* params, const f
 int spn_gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int b_is_kn, const float* bias,
                  int act, const float* resid, int ldr, float* C, int ldc, float alpha, void* stream);
 
+/* ---------------------------------------------------------------- ModifiedResNet image towers (fp32 path)
+ * CLIP's RN50 / RN101 / RN50x4 visual towers (clip/model.py:10-155; RN50x4 is train_negplus.py's default model)
+ * for encode_image (bank builders, validation).  NHWC fp32 activations; a convolution is spn_im2col3x3_f32 (3x3,
+ * padding 1, stride s; 1x1 convolutions need none) + spn_gemm_f32 with the eval-mode BatchNorm folded into weight and
+ * bias by the host and act = 3 (ReLU after bias + residual) where the block has one; nn.AvgPool2d(k);
+ * AttentionPool2d = spn_attnpool_tokens_f32 (mean token + positional embedding), q/k/v/c projections through
+ * spn_gemm_f32 and spn_attnpool_attend_f32 (the pooled token attends to all S = HW + 1 tokens, head_dim 64). */
+int spn_im2col3x3_f32(const float* x, float* out, int B, int H, int W, int C, int stride, int nchw, int ldk, void* stream);
+int spn_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int k, void* stream);
+int spn_attnpool_tokens_f32(const float* x_nhwc, const float* pos, float* tok, int B, int HW, int C, void* stream);
+int spn_attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, void* stream);
+
 /* ---------------------------------------------------------------- BLIP fusion encoder
  * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of
  * blip4cir/models.py:95-105.  ids [B,L] int32 (ids[:,0] = [ENC]), mask [B,L] int32 {0,1} (may be NULL),

@@ -107,6 +107,10 @@ _SIGS = {
     "spn_vision_exact_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
     "spn_vision_fwd_exact": (i32, [C.POINTER(VisionCfg), vp, vp, vp, sz, vp, vp]),
     "spn_gemm_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, f32, vp]),
+    "spn_im2col3x3_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "spn_avgpool_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "spn_attnpool_tokens_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spn_attnpool_attend_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),

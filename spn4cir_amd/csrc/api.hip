@@ -380,4 +380,24 @@ int spn_gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, i
     return gemm_f32(A, B, M, N, K, lda, ldb, b_is_kn, bias, act, resid, ldr, C, ldc, alpha, ST(stream));
 }
 
+int spn_im2col3x3_f32(const float* x, float* out, int B, int H, int W, int C, int stride, int nchw, int ldk, void* stream) {
+    if (!x || !out) return SPN_ERR_ARG;
+    return im2col3x3_f32(x, out, B, H, W, C, stride, nchw, ldk, ST(stream));
+}
+
+int spn_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int k, void* stream) {
+    if (!x || !y) return SPN_ERR_ARG;
+    return avgpool_nhwc_f32(x, y, B, H, W, C, k, ST(stream));
+}
+
+int spn_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int HW, int C, void* stream) {
+    if (!x || !pos || !tok) return SPN_ERR_ARG;
+    return attnpool_tokens_f32(x, pos, tok, B, HW, C, ST(stream));
+}
+
+int spn_attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, void* stream) {
+    if (!q || !k || !v || !out) return SPN_ERR_ARG;
+    return attnpool_attend_f32(q, k, v, out, B, S, H, ST(stream));
+}
+
 }  // extern "C"

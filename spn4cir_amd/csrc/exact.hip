@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                     if (ACT == ACT_QUICKGELU) v = v / (1.0f + expf(-1.702f * v));
                     else if (ACT == ACT_GELU_ERF) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
                     if (resid) v += resid[(size_t)m * ldr + n + e];
+                    if (ACT == ACT_RELU_POST) v = fmaxf(v, 0.f);
                     C[(size_t)m * ldc + n + e] = v;
                 }
             }
@@ -136,8 +137,120 @@ int gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int l
         hipLaunchKernelGGL(gemm_f32_kernel<ACT_QUICKGELU>, grid, dim3(256), 0, st, A, B, M, N, K, lda, ldb, b_kn, bias, resid, ldr, C, ldc, alpha);
     else if (act == ACT_GELU_ERF)
         hipLaunchKernelGGL(gemm_f32_kernel<ACT_GELU_ERF>, grid, dim3(256), 0, st, A, B, M, N, K, lda, ldb, b_kn, bias, resid, ldr, C, ldc, alpha);
+    else if (act == ACT_RELU_POST)
+        hipLaunchKernelGGL(gemm_f32_kernel<ACT_RELU_POST>, grid, dim3(256), 0, st, A, B, M, N, K, lda, ldb, b_kn, bias, resid, ldr, C, ldc, alpha);
     else
         return SPN_ERR_ARG;
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// --------------------------------------------------------------------------- ModifiedResNet pieces
+// CLIP's ResNet image towers (clip/model.py:10-155: RN50, RN101, RN50x4 - the argparse default of
+// train_negplus.py:192) run on this fp32 path only: NHWC activations, every convolution = im2col + gemm_f32 with the
+// (eval-mode) BatchNorm folded into weight and bias on the host, AvgPool2d, and the single-query attention pool.
+// out[(b, oy, ox), c*9 + ky*3 + kx] = x[b, oy*s + ky - 1, ox*s + kx - 1, c] (zero padding 1); columns >= 9C are zero.
+__global__ void im2col3x3_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
+                                     int stride, int nchw, int Ho, int Wo, int ldk) {
+    const size_t total = (size_t)B * Ho * Wo * ldk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % ldk);
+        const size_t row = i / ldk;
+        float v = 0.f;
+        if (col < 9 * C) {
+            const int c = col / 9, ky = (col % 9) / 3, kx = col % 3;
+            const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((size_t)Wo * Ho));
+            const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = nchw ? x[(((size_t)b * C + c) * H + iy) * W + ix] : x[(((size_t)b * H + iy) * W + ix) * C + c];
+        }
+        out[i] = v;
+    }
+}
+
+int im2col3x3_f32(const float* x, float* out, int B, int H, int W, int C, int stride, int nchw, int ldk, hipStream_t st) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0 || ldk < 9 * C) return SPN_ERR_ARG;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t n = (size_t)B * Ho * Wo * ldk;
+    hipLaunchKernelGGL(im2col3x3_f32_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, st,
+                       x, out, B, H, W, C, stride, nchw, Ho, Wo, ldk);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// nn.AvgPool2d(k) (kernel = stride = k, no padding) on NHWC
+__global__ void avgpool_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C, int k) {
+    const int Ho = H / k, Wo = W / k;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    const float inv = 1.0f / (float)(k * k);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
+        float s = 0.f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) s += x[(((size_t)b * H + oy * k + dy) * W + ox * k + dx) * C + c];
+        y[i] = s * inv;
+    }
+}
+
+int avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int k, hipStream_t st) {
+    if (B <= 0 || C <= 0 || k <= 0 || H < k || W < k) return SPN_ERR_ARG;
+    const size_t n = (size_t)B * (H / k) * (W / k) * C;
+    hipLaunchKernelGGL(avgpool_nhwc_f32_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256), 0, st,
+                       x, y, B, H, W, C, k);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// AttentionPool2d token assembly (clip/model.py:69-71): tok[b,0] = mean_i x[b,i] + pos[0]; tok[b,1+i] = x[b,i] + pos[1+i]
+__global__ void attnpool_tokens_f32_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ tok,
+                                           int B, int HW, int C) {
+    const size_t total = (size_t)B * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), b = (int)(i / C);
+        float s = 0.f;
+        for (int j = 0; j < HW; ++j) {
+            const float v = x[((size_t)b * HW + j) * C + c];
+            s += v;
+            tok[((size_t)b * (HW + 1) + 1 + j) * C + c] = v + pos[(size_t)(1 + j) * C + c];
+        }
+        tok[(size_t)b * (HW + 1) * C + c] = s / (float)HW + pos[c];
+    }
+}
+
+int attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int HW, int C, hipStream_t st) {
+    if (B <= 0 || HW <= 0 || C <= 0) return SPN_ERR_ARG;
+    const size_t n = (size_t)B * C;
+    hipLaunchKernelGGL(attnpool_tokens_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, pos, tok, B, HW, C);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// single-query multi-head attention (the pooled token attends to all S tokens), head_dim 64: one wave per (b, h)
+__global__ void attnpool_attend_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                           float* __restrict__ out, int B, int S, int H) {
+    const int lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh % H, C = H * 64;
+    const float qd = q[(size_t)b * C + h * 64 + lane] * 0.125f;
+    float mx = -INFINITY, l = 0.f, o = 0.f;
+    for (int j = 0; j < S; ++j) {
+        const size_t row = ((size_t)b * S + j) * C + h * 64 + lane;
+        const float s = wave_sum(qd * k[row]);
+        const float mn = fmaxf(mx, s);
+        const float corr = expf(mx - mn), p = expf(s - mn);
+        l = l * corr + p;
+        o = o * corr + p * v[row];
+        mx = mn;
+    }
+    out[(size_t)b * C + h * 64 + lane] = o / l;
+}
+
+int attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, hipStream_t st) {
+    if (B <= 0 || S <= 0 || H <= 0) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(attnpool_attend_f32_kernel, dim3((B * H + 3) / 4), dim3(256), 0, st, q, k, v, out, B, S, H);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -6,7 +6,7 @@
 namespace spn {
 
 enum { GEMM_STORE = 0, GEMM_RESID = 1, GEMM_DACT = 2, GEMM_BANKSTATS = 3 };
-enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2 };
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_RELU_POST = 3 /* gemm_f32 only: ReLU after bias + residual */ };
 
 struct GemmEpilogue {
     const float* bias = nullptr;     // [N] fp32, added before everything else

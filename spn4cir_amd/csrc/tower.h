@@ -124,6 +124,10 @@ int vision_bwd(const VisionCfg& c, const float* params, const bf16_t* wb, char* 
 // exact.hip: fp32-exact inference of the CLIP towers (f32-input MFMA GEMMs, fp32 attention) for validation
 int gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int b_kn, const float* bias, int act,
              const float* resid, int ldr, float* C, int ldc, float alpha, hipStream_t st);
+int im2col3x3_f32(const float* x, float* out, int B, int H, int W, int C, int stride, int nchw, int ldk, hipStream_t st);
+int avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int k, hipStream_t st);
+int attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int HW, int C, hipStream_t st);
+int attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, hipStream_t st);
 size_t text_exact_ws_bytes(const TextCfg& c);
 int text_fwd_exact(const TextCfg& c, const float* params, const int32_t* ids, char* ws, size_t ws_bytes, float* feats,
                    hipStream_t st);

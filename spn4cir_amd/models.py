@@ -114,8 +114,12 @@ class CIRPlus(nn.Module):
                 self._params["visual." + key] = p
         else:
             for k, v in sd.items():
-                if k.startswith("visual."):
-                    _attach(self.clip, k, nn.Parameter(v.to(self.device).float(), requires_grad=False))
+                if k.startswith("visual.") and torch.is_floating_point(v):
+                    _attach(self.clip, k.replace("downsample.-1", "downsample.avgpool"), nn.Parameter(v.to(self.device).float(),
+                                                                                                   requires_grad=False))
+            if "visual.layer1.0.conv1.weight" in sd and "visual.attnpool.positional_embedding" in sd:
+                from .resnet_tower import ResNetTower          # ModifiedResNet (RN50x4 = train_negplus.py's default)
+                self.vision = ResNetTower(sd, self.device)
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.combining_function = self.element_wise_sum
         self.tau = tau
@@ -157,6 +161,8 @@ class CIRPlus(nn.Module):
             patch = sd["visual.conv1.weight"].shape[-1]
             grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
             return patch * grid
+        if "visual.attnpool.positional_embedding" in sd:            # ModifiedResNet: clip/model.py:417-419
+            return round((sd["visual.attnpool.positional_embedding"].shape[0] - 1) ** 0.5) * 32
         return 224
 
     def load_ckpt(self, model_path, is_origin=False):
@@ -280,7 +286,7 @@ class CIRPlus(nn.Module):
     def encode_image(self, image):
         """fp32 [B, 3, res, res] -> un-normalised image features [B, D] (models_negplus.py:39-41)."""
         if self.vision is None:
-            raise RuntimeError("this checkpoint has no ViT image tower (ModifiedResNet towers are not implemented)")
+            raise RuntimeError("this checkpoint has no image tower")
         with torch.no_grad():
             if self.exact_eval:
                 return self.vision.forward_exact(image.to(self.device, torch.float32))

@@ -1,0 +1,125 @@
+"""Host side of CLIP's ModifiedResNet image towers (RN50 / RN101 / RN50x4..., clip4cir/clip/model.py:10-155) for
+`encode_image` (bank builders, validation): frozen, inference only, fp32.
+
+Activations are NHWC fp32 on the device; every convolution is `spn_im2col3x3_f32` (3x3) or nothing (1x1) followed by
+`spn_gemm_f32` with the eval-mode BatchNorm folded into weight and bias once at load time; AvgPool2d and the
+attention pool have their own small kernels.  The layer sequence is driven from here (about 3 launches per
+convolution); the arithmetic is all in csrc/exact.hip."""
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib
+from .ops import _p, _stream
+
+ACT_NONE, ACT_RELU_POST = 0, 3
+
+
+def resnet_cfg_from_state_dict(sd, prefix="visual."):
+    """clip/model.py:412-419."""
+    counts = [len({k.split(".")[2] for k in sd if k.startswith(f"{prefix}layer{b}.")}) for b in (1, 2, 3, 4)]
+    width = sd[prefix + "layer1.0.conv1.weight"].shape[0]
+    grid = round((sd[prefix + "attnpool.positional_embedding"].shape[0] - 1) ** 0.5)
+    return dict(layers=tuple(counts), width=width, res=grid * 32, heads=width * 32 // 64,
+                embed_dim=sd[prefix + "attnpool.c_proj.weight"].shape[0])
+
+
+def _fold(conv_w, bn, eps=1e-5):
+    """conv [Co, Ci, kh, kw] + eval BatchNorm -> ([Co, K padded to a multiple of 4] fp32, bias [Co])."""
+    s = bn["weight"].float() / torch.sqrt(bn["running_var"].float() + eps)
+    w = (conv_w.float() * s[:, None, None, None]).reshape(conv_w.shape[0], -1)
+    b = bn["bias"].float() - bn["running_mean"].float() * s
+    K = w.shape[1]
+    Kp = (K + 3) // 4 * 4
+    if Kp != K:
+        w = torch.cat([w, torch.zeros(w.shape[0], Kp - K)], dim=1)
+    return w.contiguous(), b.contiguous()
+
+
+class ResNetTower:
+    def __init__(self, sd, device="cuda", prefix="visual."):
+        self.device = torch.device(device)
+        cfg = resnet_cfg_from_state_dict(sd, prefix)
+        self.layers, self.width, self.res = cfg["layers"], cfg["width"], cfg["res"]
+        self.heads, self.embed_dim = cfg["heads"], cfg["embed_dim"]
+        g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        bn = lambda p: {n: g[p + n] for n in ("weight", "bias", "running_mean", "running_var")}
+        dev = lambda t: t.to(self.device)
+        self.stem = [tuple(map(dev, _fold(g[f"conv{i}.weight"], bn(f"bn{i}.")))) for i in (1, 2, 3)]
+        self.blocks = []
+        for li, n in enumerate(self.layers, start=1):
+            for bi in range(n):
+                p = f"layer{li}.{bi}."
+                blk = dict(stride=2 if (bi == 0 and li > 1) else 1,
+                           c1=tuple(map(dev, _fold(g[p + "conv1.weight"], bn(p + "bn1.")))),
+                           c2=tuple(map(dev, _fold(g[p + "conv2.weight"], bn(p + "bn2.")))),
+                           c3=tuple(map(dev, _fold(g[p + "conv3.weight"], bn(p + "bn3.")))), down=None)
+                if p + "downsample.0.weight" in g:
+                    blk["down"] = tuple(map(dev, _fold(g[p + "downsample.0.weight"], bn(p + "downsample.1."))))
+                self.blocks.append(blk)
+        a = "attnpool."
+        self.pos = dev(g[a + "positional_embedding"].float().contiguous())
+        self.proj = {n: (dev(g[a + n + "_proj.weight"].float().contiguous()), dev(g[a + n + "_proj.bias"].float().contiguous()))
+                     for n in ("q", "k", "v", "c")}
+
+    # ------------------------------------------------------------------ primitives
+    def _gemm(self, a, w, bias, M, N, K, lda, act=ACT_NONE, resid=None):
+        out = torch.empty(M, N, dtype=torch.float32, device=self.device)
+        check(lib().spn_gemm_f32(_p(a), _p(w), M, N, K, lda, w.shape[1], 0, _p(bias), act, _p(resid), N, _p(out), N, 1.0,
+                                 _stream()), "gemm_f32")
+        return out
+
+    def _conv3x3(self, x, B, H, W, Cin, wb, stride=1, nchw=False, act=ACT_RELU_POST):
+        w, b = wb
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        ldk = w.shape[1]
+        cols = torch.empty(B * Ho * Wo, ldk, dtype=torch.float32, device=self.device)
+        check(lib().spn_im2col3x3_f32(_p(x), _p(cols), B, H, W, Cin, stride, int(nchw), ldk, _stream()), "im2col3x3")
+        return self._gemm(cols, w, b, B * Ho * Wo, w.shape[0], ldk, ldk, act), Ho, Wo
+
+    def _conv1x1(self, x, M, Cin, wb, act=ACT_NONE, resid=None):
+        w, b = wb
+        return self._gemm(x, w, b, M, w.shape[0], Cin, Cin, act, resid)
+
+    def _avgpool(self, x, B, H, W, Cc, k):
+        y = torch.empty(B * (H // k) * (W // k), Cc, dtype=torch.float32, device=self.device)
+        check(lib().spn_avgpool_nhwc_f32(_p(x), _p(y), B, H, W, Cc, k, _stream()), "avgpool")
+        return y, H // k, W // k
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, image):
+        """fp32 [B, 3, res, res] -> un-normalised image features fp32 [B, embed_dim] (clip/model.py:139-154)."""
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.res or image.shape[3] != self.res:
+            raise ValueError(f"expected [B,3,{self.res},{self.res}], got {tuple(image.shape)}")
+        x = image.to(self.device, torch.float32).contiguous()
+        B, H, W = x.shape[0], self.res, self.res
+        x, H, W = self._conv3x3(x, B, H, W, 3, self.stem[0], stride=2, nchw=True)
+        x, H, W = self._conv3x3(x, B, H, W, self.width // 2, self.stem[1])
+        x, H, W = self._conv3x3(x, B, H, W, self.width // 2, self.stem[2])
+        x, H, W = self._avgpool(x, B, H, W, self.width, 2)
+        Cc = self.width
+        for blk in self.blocks:
+            planes = blk["c1"][0].shape[0]
+            out = self._conv1x1(x, B * H * W, Cc, blk["c1"], ACT_RELU_POST)
+            out, _, _ = self._conv3x3(out, B, H, W, planes, blk["c2"])
+            Ho, Wo = H, W
+            identity = x
+            if blk["stride"] > 1:
+                out, Ho, Wo = self._avgpool(out, B, H, W, planes, blk["stride"])
+            if blk["down"] is not None:
+                if blk["stride"] > 1:
+                    identity, _, _ = self._avgpool(x, B, H, W, Cc, blk["stride"])
+                identity = self._conv1x1(identity, B * Ho * Wo, Cc, blk["down"])
+            x = self._conv1x1(out, B * Ho * Wo, planes, blk["c3"], ACT_RELU_POST, resid=identity)
+            H, W, Cc = Ho, Wo, planes * 4
+        S = H * W + 1
+        tok = torch.empty(B * S, Cc, dtype=torch.float32, device=self.device)
+        check(lib().spn_attnpool_tokens_f32(_p(x), _p(self.pos), _p(tok), B, H * W, Cc, _stream()), "attnpool_tokens")
+        q = self._gemm(tok, self.proj["q"][0], self.proj["q"][1], B, Cc, Cc, S * Cc)          # rows b*S: the pooled token
+        k = self._gemm(tok, self.proj["k"][0], self.proj["k"][1], B * S, Cc, Cc, Cc)
+        v = self._gemm(tok, self.proj["v"][0], self.proj["v"][1], B * S, Cc, Cc, Cc)
+        o = torch.empty(B, Cc, dtype=torch.float32, device=self.device)
+        check(lib().spn_attnpool_attend_f32(_p(q), _p(k), _p(v), _p(o), B, S, Cc // 64, _stream()), "attnpool_attend")
+        return self._gemm(o, self.proj["c"][0], self.proj["c"][1], B, self.embed_dim, Cc, Cc)
+
+    forward_exact = forward       # the tower only has the fp32 path

@@ -332,3 +332,42 @@ def test_exact_encode_mode_matches_fp32_oracle(golden_dir):
     same50 = np.mean([set(og[i, :50]) == set(oc[i, :50]) for i in range(24)])
     print("exact mode: top-10 / top-50 set identity", same10, same50)
     assert same10 == 1.0 and same50 >= 0.95
+
+
+def test_resnet_tower_matches_reference(golden_dir):
+    """CLIP ModifiedResNet image tower (fp32 path: im2col + f32-MFMA GEMM with folded BatchNorm, attention pool)
+    against the reference's encode_image on a tiny RN CLIP: 1e-4 relative to the largest feature (BatchNorm folding
+    and accumulation order), 1 - cos < 1e-6."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    from spn4cir_amd.resnet_tower import ResNetTower
+    z = np.load(os.path.join(golden_dir, "tiny_clip_resnet.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    t = ResNetTower(sd, "cuda")
+    assert (t.layers, t.width, t.res, t.embed_dim) == ((1, 2, 1, 1), 8, 64, 128)
+    out = t.forward(torch.from_numpy(z["image"])).cpu()
+    ref = torch.from_numpy(z["image_feats"])
+    assert (out - ref).abs().max() < 1e-4 * ref.abs().max(), (out - ref).abs().max()
+    cos = torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)
+    assert (1 - cos).max() < 1e-6
+
+
+def test_cirplus_with_resnet_image_tower(golden_dir):
+    """A checkpoint whose visual tower is a ModifiedResNet (train_negplus.py's default RN50x4 family): encode_image
+    goes through ResNetTower, input_dim follows the attention pool's grid."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import numpy as np
+    from spn4cir_amd.models import CIRPlus
+    zt = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    zr = np.load(os.path.join(golden_dir, "tiny_clip_resnet.npz"))
+    sd = {k[4:]: torch.from_numpy(zt[k]) for k in zt.files if k.startswith("sd::") and not k.startswith("sd::visual.")}
+    sd.update({k[4:]: torch.from_numpy(zr[k]) for k in zr.files if k.startswith("sd::")})
+    model = CIRPlus(sd, device=torch.device("cuda"))
+    assert model.input_dim == 64
+    out = model.encode_image(torch.from_numpy(zr["image"]).cuda()).cpu()
+    ref = torch.from_numpy(zr["image_feats"])
+    assert (out - ref).abs().max() < 1e-4 * ref.abs().max()

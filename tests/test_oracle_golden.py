@@ -176,3 +176,15 @@ def test_e4m3_quantizer_known_answers():
     deq = bank_loss.dequantize_e4m3(data, scale)
     assert (deq - bank).abs().max() <= bank.abs().amax() * 2.0 ** -4          # half an ulp of 3 mantissa bits
     assert torch.equal(bank_loss.quantize_e4m3(deq)[0], data)                  # idempotent
+
+
+def test_resnet_tower_matches_reference(golden_dir):
+    """ModifiedResNet restatement (oracle/clip_resnet.py) against the reference's encode_image on a tiny RN CLIP."""
+    from oracle import clip_resnet
+    z = np.load(os.path.join(golden_dir, "tiny_clip_resnet.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    cfg = clip_resnet.resnet_cfg_from_state_dict(sd)
+    assert cfg["layers"] == (1, 2, 1, 1) and cfg["width"] == 8 and cfg["res"] == 64 and cfg["embed_dim"] == 128
+    out = clip_resnet.encode_image(sd, torch.from_numpy(z["image"]))
+    ref = torch.from_numpy(z["image_feats"])
+    assert (out - ref).abs().max() < 1e-5 * ref.abs().max().clamp_min(1.0)

@@ -14,12 +14,67 @@ CFG = {  # width, layers, heads, patch, res, embed_dim, kind
 }
 
 
+def resnet_state_dict(layers, width, res, embed_dim, seed=0):
+    """Seeded random ModifiedResNet weights with the shapes of clip/model.py:94-137."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name] = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.05 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.05 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 0.8 + 0.4 * torch.rand(c, generator=g)
+
+    conv("visual.conv1.weight", width // 2, 3, 3); bn("visual.bn1", width // 2)
+    conv("visual.conv2.weight", width // 2, width // 2, 3); bn("visual.bn2", width // 2)
+    conv("visual.conv3.weight", width, width // 2, 3); bn("visual.bn3", width)
+    inpl = width
+    for li, n in enumerate(layers, start=1):
+        planes = width * 2 ** (li - 1)
+        for bi in range(n):
+            p = f"visual.layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            conv(p + "conv1.weight", planes, inpl, 1); bn(p + "bn1", planes)
+            conv(p + "conv2.weight", planes, planes, 3); bn(p + "bn2", planes)
+            conv(p + "conv3.weight", planes * 4, planes, 1); bn(p + "bn3", planes * 4)
+            if stride > 1 or inpl != planes * 4:
+                conv(p + "downsample.0.weight", planes * 4, inpl, 1); bn(p + "downsample.1", planes * 4)
+            inpl = planes * 4
+    C, grid = width * 32, res // 32
+    sd["visual.attnpool.positional_embedding"] = torch.randn(grid * grid + 1, C, generator=g) / C ** 0.5
+    for n, o in (("q", C), ("k", C), ("v", C), ("c", embed_dim)):
+        sd[f"visual.attnpool.{n}_proj.weight"] = torch.randn(o, C, generator=g) * C ** -0.5
+        sd[f"visual.attnpool.{n}_proj.bias"] = torch.zeros(o)
+    return sd
+
+
+RN_CFG = {"RN50": ((3, 4, 6, 3), 64, 224, 1024), "RN50x4": ((4, 6, 10, 6), 80, 288, 640)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
     a = ap.parse_args()
+    if a.model in RN_CFG:
+        from spn4cir_amd.resnet_tower import ResNetTower
+        layers, width, res, D = RN_CFG[a.model]
+        t = ResNetTower(resnet_state_dict(layers, width, res, D), "cuda")
+        img = torch.randn(a.batch, 3, res, res).cuda()
+        t.forward(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            t.forward(img)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps({"model": a.model + " (ModifiedResNet, fp32 path)", "batch": a.batch,
+                          "images_per_s": round(a.batch / dt, 1), "ms_per_batch": round(dt * 1e3, 2)}))
+        return
     W, layers, H, p, res, D, kind = CFG[a.model]
     t = VisionTower(W, layers, H, p, res, D, "cuda", kind=kind)
     g = torch.Generator().manual_seed(0)
