@@ -175,6 +175,13 @@ class CIRPlus(nn.Module):
                 if k in own and own[k].shape == v.shape:
                     own[k].copy_(v.to(own[k].device, own[k].dtype))
         self.tower.mark_stale()
+        # a stage-1 checkpoint also carries a fine-tuned image tower: re-derive what is computed from its weights
+        if isinstance(self.vision, VisionTower):
+            self.vision.mark_stale()
+        elif self.vision is not None:
+            from .resnet_tower import ResNetTower
+            vis = {k[len("clip."):]: v for k, v in self.state_dict().items() if k.startswith("clip.visual.")}
+            self.vision = ResNetTower({k.replace("downsample.avgpool", "downsample.-1"): v for k, v in vis.items()}, self.device)
 
     # ---------------------------------------------------------------------------- banks
     @property

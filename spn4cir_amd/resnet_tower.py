@@ -42,7 +42,7 @@ class ResNetTower:
         cfg = resnet_cfg_from_state_dict(sd, prefix)
         self.layers, self.width, self.res = cfg["layers"], cfg["width"], cfg["res"]
         self.heads, self.embed_dim = cfg["heads"], cfg["embed_dim"]
-        g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        g = {k[len(prefix):]: v.detach().cpu() for k, v in sd.items() if k.startswith(prefix)}   # folding runs on the host
         bn = lambda p: {n: g[p + n] for n in ("weight", "bias", "running_mean", "running_var")}
         dev = lambda t: t.to(self.device)
         self.stem = [tuple(map(dev, _fold(g[f"conv{i}.weight"], bn(f"bn{i}.")))) for i in (1, 2, 3)]

@@ -85,6 +85,24 @@ def test_checkpoint_roundtrip(golden_dir, tmp_path):
     torch.save({"CLIP": sd}, str(tmp_path / "stage1.pt"))             # stage-1 format (models_negplus.py:54-55)
     model.load_ckpt(str(tmp_path / "stage1.pt"), is_origin=True)
     assert torch.allclose(model.encode_text(ids), f0, atol=1e-6)
+    # a stage-1 checkpoint also replaces the image tower: the derived bf16 operands / folded weights must follow
+    img = torch.from_numpy(z["image"]).cuda()
+    v0 = model.encode_image(img).clone()
+    sd2 = {k: (v * 0.5 if k == "visual.proj" else v) for k, v in sd.items()}
+    torch.save({"CLIP": sd2}, str(tmp_path / "stage1b.pt"))
+    model.load_ckpt(str(tmp_path / "stage1b.pt"), is_origin=True)
+    assert torch.allclose(model.encode_image(img), 0.5 * v0, atol=1e-3 * v0.abs().max().item())
+    zr = np.load(os.path.join(golden_dir, "tiny_clip_resnet.npz"))
+    sdr = {k: v for k, v in sd.items() if not k.startswith("visual.")}
+    sdr.update({k[4:]: torch.from_numpy(zr[k]) for k in zr.files if k.startswith("sd::")})
+    mr = CIRPlus(sdr, device=torch.device("cuda"))
+    imr = torch.from_numpy(zr["image"]).cuda()
+    r0 = mr.encode_image(imr).clone()
+    sdr2 = {k: (v * 0.5 if k == "visual.attnpool.c_proj.weight" else v) for k, v in sdr.items()}
+    torch.save({"CLIP": sdr2}, str(tmp_path / "stage1r.pt"))
+    mr.load_ckpt(str(tmp_path / "stage1r.pt"), is_origin=True)
+    bias = torch.from_numpy(zr["sd::visual.attnpool.c_proj.bias"]).cuda()
+    assert torch.allclose(mr.encode_image(imr) - bias, 0.5 * (r0 - bias), atol=1e-5)
 
 
 def test_trainer_steps_match_oracle():
