@@ -1,0 +1,178 @@
+"""blip4cir `CIRPlus` protocol (blip4cir/models.py:16-121) over the MI355X path: fusion encoder (med.py BertModel
++ text_proj), BLIP ViT image side, static token / target banks, learnable temperature.
+
+    model = CIRPlus(blip_state_dict_or_path, tau=0.03, tokenizer=my_bert_tokenizer)
+    loss = model.forward(text, indexs, target_indexs, refer_indexs)['bank_loss']; loss.backward()
+
+`text` is a list of strings when a tokenizer is given (any callable `texts -> (ids [B,L], attention_mask [B,L])`;
+the reference's `BertTokenizer('bert-base-uncased')` + `[ENC]` first token needs a vocabulary download that this
+repository cannot vendor), or an already tokenised `(ids, mask)` pair.  State-dict keys follow BLIP_Retrieval:
+`visual_encoder.*`, `vision_proj.*`, `text_encoder.*`, `text_proj.*` (under `blip.` in CIRPlus.state_dict())."""
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+from .fusion import FusionEncoder, fusion_cfg_from_state_dict
+from .vision_tower import VisionTower
+
+
+class _FusionBankStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, tau_param, model, ids, mask, tokens, labels):
+        enc = model.fusion
+        tau = float(tau_param.detach())
+        proj = enc.forward(ids, mask, tokens)
+        q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
+        bank = model._target_bank_dev
+        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau)
+        lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
+        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0])
+        return mean.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        m, st = ctx.model, ctx.st
+        enc = m.fusion
+        bank = m._target_bank_dev
+        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], float(grad_out) / st["B"],
+                             M_total=bank.shape[0])[:, :enc.Dp].contiguous()
+        dtau = (-(st["q"] * dq).sum() / st["tau"]).reshape(())            # models.py:29: tau is an nn.Parameter
+        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq))
+        for key, view in enc.named_views(flat).items():
+            p = m._params[key]
+            p.grad = view if p.grad is None else p.grad + view
+        return torch.zeros((), device=grad_out.device), dtau, None, None, None, None, None
+
+
+class CIRPlus(nn.Module):
+    def __init__(self, blip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25, encoder="both",
+                 device=torch.device("cuda"), plus=False, tokenizer=None, image_size=384, patch=16, enc_token_id=None):
+        super().__init__()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("spn4cir_amd runs on an MI355X (device='cuda'); there is no CPU path")
+        sd = blip_model_name
+        if isinstance(sd, str):
+            if not os.path.isfile(sd):
+                raise RuntimeError(f"BLIP checkpoint {sd} not found")
+            sd = torch.load(sd, map_location="cpu")
+            sd = sd.get("model", sd.get("BLIP_Retrieval", sd))
+        self.plus, self.encoder, self.tokenizer, self.enc_token_id = plus, encoder, tokenizer, enc_token_id
+        c = fusion_cfg_from_state_dict(sd, "text_encoder.")
+        self.output_dim = sd["text_proj.weight"].shape[0]
+        self.fusion = FusionEncoder(c["hidden"], c["layers"], c["heads"], c["intermediate"], c["enc_width"], self.output_dim,
+                                    c["vocab"], c["max_pos"], self.device)
+        fsd = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
+        fsd.update({k: v for k, v in sd.items() if k.startswith("text_proj.")})
+        self.fusion.load_state_dict(fsd)
+        self.vision = None
+        if "visual_encoder.cls_token" in sd:
+            W = sd["visual_encoder.cls_token"].shape[-1]
+            layers = len({k.split(".")[2] for k in sd if k.startswith("visual_encoder.blocks.")})
+            patch = sd["visual_encoder.patch_embed.proj.weight"].shape[-1]
+            grid = round((sd["visual_encoder.pos_embed"].shape[1] - 1) ** 0.5)
+            image_size = patch * grid
+            self.vision = VisionTower(W, layers, W // 64, patch, image_size, self.output_dim, self.device, kind=1)
+            self.vision.load_blip_state_dict(sd)
+        self.input_dim = image_size
+        self.tau = nn.Parameter(tau * torch.ones([], device=self.device))
+        self.blip = nn.Module()                      # parameter container: names as in BLIP_Retrieval.state_dict()
+        self._params = {}
+        for key, view in self.fusion.named_views().items():
+            name = key if key.startswith("text_proj.") else "text_encoder." + key
+            p = nn.Parameter(view, requires_grad=True)
+            self._register(name, p)
+            self._params[key] = p
+        if self.vision is not None:
+            for key, view in self.vision.named_views().items():
+                if key == "vision_proj_t":
+                    continue                          # exposed through the towers; stored transposed internally
+                name = key if key.startswith("vision_proj.") else "visual_encoder." + key
+                self._register(name, nn.Parameter(view, requires_grad=False))
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self.preprocess = None
+        if transform == "targetpad":
+            from .preprocess import TargetPadTransform
+            self.preprocess = TargetPadTransform(target_ratio, self.input_dim, self.device)
+        self.refer_bank = None
+        self._target_bank = self._target_bank_dev = None
+
+    def _register(self, dotted, param):
+        node = self.blip
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(node, p):
+                node.add_module(p, nn.Module())
+            node = getattr(node, p)
+        node.register_parameter(parts[-1], param)
+
+    # ------------------------------------------------------------------------------- banks
+    @property
+    def target_bank(self):
+        return self._target_bank
+
+    @target_bank.setter
+    def target_bank(self, bank):
+        self._target_bank = bank
+        self._target_bank_dev = None if bank is None else ops.prepare_bank(bank.to(self.device, torch.float32))
+
+    def load_refer_bank(self, bank_path):
+        self.refer_bank = torch.load(bank_path)
+
+    def img_embed(self, image, return_pool_and_normalized=False):
+        """BLIP_Retrieval.img_embed (blip_cir.py:54-70): token sequence [B, S, W] (and normalised vision_proj of token 0)."""
+        if self.vision is None:
+            raise RuntimeError("this checkpoint has no visual_encoder")
+        with torch.no_grad():
+            feats, tokens = self.vision.forward(image, return_tokens=True)
+        if return_pool_and_normalized:
+            return tokens, torch.nn.functional.normalize(feats, dim=-1)
+        return tokens
+
+    # -------------------------------------------------------------------------------- step
+    def tokenize(self, text):
+        if isinstance(text, (tuple, list)) and len(text) == 2 and torch.is_tensor(text[0]):
+            ids, mask = text
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("no tokenizer: pass tokenizer=callable(texts) -> (ids, mask) or feed (ids, mask) "
+                                   "(blip_cir.py:87-88 uses BertTokenizer('bert-base-uncased') + the [ENC] id)")
+            ids, mask = self.tokenizer(list(text))
+        ids = ids.to(self.device, torch.int32).clone()
+        if self.enc_token_id is not None:
+            ids[:, 0] = self.enc_token_id              # blip_cir.py:88
+        return ids.contiguous(), mask.to(self.device, torch.int32).contiguous()
+
+    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text):
+        """Inference form (blip_cir.py:82-103, train=False): normalised text_proj of the fused [ENC] token."""
+        ids, mask = self.tokenize(text)
+        with torch.no_grad():
+            proj = self.fusion.forward(ids, mask, r_image_embeds.to(self.device, torch.float32))
+        return torch.nn.functional.normalize(proj, dim=-1)
+
+    def forward(self, text, indexs, target_indexs, refer_indexs, reference_image=None, target_image=None):
+        """blip4cir/models.py:95-110 -> {'bank_loss': 0-dim tensor}; backward() fills .grad of the fusion encoder's
+        parameters and of `tau`."""
+        ids, mask = self.tokenize(text)
+        idx = refer_indexs if self.plus else indexs
+        tokens = self.refer_bank[idx.to(self.refer_bank.device)].to(self.device, torch.float32)
+        labels = target_indexs.to(self.device, torch.int64)
+        loss = _FusionBankStep.apply(self._anchor, self.tau, self, ids, mask, tokens, labels)
+        return {"bank_loss": loss}
+
+    def parameters_changed(self):
+        self.fusion.mark_stale()
+
+    def load_ckpt(self, model_path, is_origin=False):
+        saved = torch.load(model_path, map_location="cpu")
+        src = {"blip." + k: v for k, v in saved["BLIP_Retrieval"].items()} if is_origin else saved["state_dict"]
+        own = self.state_dict()
+        with torch.no_grad():
+            for k, v in src.items():
+                if k in own and own[k].shape == v.shape:
+                    own[k].copy_(v.to(own[k].device, own[k].dtype))
+        self.fusion.mark_stale()
+        if self.vision is not None:
+            self.vision.mark_stale()

@@ -144,3 +144,38 @@ def test_blip_trainer_two_ranks_match_single_process(golden_dir, mode):
         assert abs(tau - ref_tau) < 1e-5 * max(1.0, abs(ref_tau))
         d = (torch.from_numpy(params) - ref_params).abs().max().item()
         assert d < 5e-4, d          # two AdamW steps at lr 1e-3: split-K / reduction-order noise only
+
+
+def test_blip_cirplus_protocol(golden_dir):
+    """blip4cir/models.py CIRPlus protocol on the kernels: forward -> {'bank_loss'}, backward fills the fusion
+    encoder's gradients and d(loss)/d(tau); same numbers as the captured reference step (pre-tokenised input)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd.blip_models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "blip_fusion.npz"))
+    sd = {}
+    for k in z.files:
+        if k.startswith("sd::"):
+            name = k[4:]
+            sd[name if name.startswith("text_proj.") else "text_encoder." + name] = torch.from_numpy(z[k])
+    model = CIRPlus(sd, tau=float(z["tau"]), device=torch.device("cuda"), plus=True)
+    model.refer_bank = torch.from_numpy(z["enc"])                         # one token row per triplet here
+    model.target_bank = torch.from_numpy(z["bank"])
+    B = z["ids"].shape[0]
+    out = model.forward((torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])), None, torch.from_numpy(z["labels"]),
+                        torch.arange(B))
+    loss = out["bank_loss"]
+    assert abs(loss.item() - float(z["loss"])) < 2e-2 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    named = dict(model.blip.named_parameters())
+    g = named["text_proj.weight"].grad.cpu()
+    r = torch.from_numpy(z["grad::text_proj.weight"])
+    assert ((g - r).norm() / r.norm()).item() < 6e-2
+    g2 = named["text_encoder.encoder.layer.0.crossattention.self.query.weight"].grad.cpu()
+    r2 = torch.from_numpy(z["grad::encoder.layer.0.crossattention.self.query.weight"])
+    assert ((g2 - r2).norm() / r2.norm()).item() < 6e-2
+    assert model.tau.grad is not None and torch.isfinite(model.tau.grad)
+    q = model.img_txt_fusion(torch.from_numpy(z["enc"]), None, (torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])))
+    cos = torch.nn.functional.cosine_similarity(q.cpu().double(), torch.from_numpy(z["q"]).double(), dim=-1)
+    assert (1 - cos).max() < 1e-3
+    assert any(k.startswith("blip.text_encoder.encoder.layer.0.") for k in model.state_dict()) and "tau" in model.state_dict()
