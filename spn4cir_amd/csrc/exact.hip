@@ -330,8 +330,6 @@ static int attention_f32(const float* qkv, float* out, int B, int H, int L, int 
 
 // ------------------------------------------------------------------------------ one block
 // scratch (all fp32): h [T,W] | qkv [T,3W] | attn [T,W] | x_mid [T,W] | u [T,4W]
-static size_t block_exact_scratch(const BlockCfg& c) { return alx((size_t)c.B * c.L * c.W * 4) * 0 + (size_t)c.B * c.L * c.W * 4 * 10; }
-
 static int block_fwd_exact(const BlockCfg& c, const float* p, const float* x_in, float* x_out, float* scr, hipStream_t st) {
     int64_t o[13];
     block_param_offsets(c.W, o);
