@@ -117,9 +117,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    # SPN_DP_FORCE_COLLECTIVES=1 (1-GPU debugging aid): run the N-GPU code path - RCCL init, sharded bank, bucketed
+    # gradient all-reduce - with a 1-rank group
+    force_dp = os.environ.get("SPN_DP_FORCE_COLLECTIVES") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from spn4cir_amd import _lib, synthetic
     from spn4cir_amd.models import CIRPlus
@@ -140,7 +145,7 @@ def main():
     ids, ridx, labels = ids_all[sl].to(dev), ridx_all[sl].to(dev), lab_all[sl].to(dev)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -273,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 
