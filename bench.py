@@ -125,6 +125,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        dist.barrier()
+        C.CDLL(None).fflush(None)          # emit RCCL's start-up banner now, not after the result line
 
     from spn4cir_amd import _lib, synthetic
     from spn4cir_amd.models import CIRPlus
@@ -277,10 +279,16 @@ def main():
             out["packed_eot"] = packed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
-        print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner to the C stdout buffer: flush it first so that the JSON line is the LAST line
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
