@@ -141,10 +141,21 @@ class GradBucketReducer:
         if sum(e - s for s, e in self._pending) >= self.bucket_elems:
             self._flush()
 
-    def finish(self):
+    def finish(self, keep_last=0):
+        """Make the compute stream wait for the all-reduces.  keep_last = n leaves the n most recent ones in
+        flight and returns their handles (the caller overlaps them with work that does not touch those spans,
+        e.g. AdamW over the already-reduced part of the buffer, then calls .wait() on each)."""
         if _skip(self.world):
-            return
+            return []
         self._flush()
-        for w in self._works:
+        cut = len(self._works) - keep_last if keep_last else len(self._works)
+        for w in self._works[:cut]:
             w.wait()            # the compute stream waits for the RCCL stream; no host sync on RCCL
+        rest = self._works[cut:]
         self._works = []
+        return rest
+
+    def flush(self):
+        """Close the current bucket now (its all-reduce starts behind the work enqueued so far)."""
+        if not _skip(self.world):
+            self._flush()

@@ -59,15 +59,35 @@ class Stage2Trainer:
                                    self.model.label_smoothing)
         dq = self.loss_dp.backward(ctx)
         dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :t.embed_dim].contiguous())
-        t.backward_phased(dtext, self.reducer.on_span_ready)
-        self.reducer.finish()
+        # Data parallel: the embedding gradients (the head of the flat buffer, 38 M of the 124 M parameters) are only
+        # final when backward ends, so their all-reduce cannot hide behind backward.  It gets its own bucket and runs
+        # under the AdamW update of everything else (HBM-bound vs link-bound), then the embeddings are updated.
+        tail_end = t.layer_spans()[-1][1]
+
+        def on_span(start, end):
+            if start == 0 and self.world > 1 and not self.check_finite:
+                self.reducer.flush()                      # everything before the tail goes out as its own bucket(s)
+            self.reducer.on_span_ready(start, end)
+
+        t.backward_phased(dtext, on_span)
+        split = self.world > 1 and not self.check_finite
+        pending = self.reducer.finish(keep_last=1 if split else 0)
         self.step_count += 1
         found = None
         if self.check_finite:
             self.found_inf.zero_()
             ops.grad_check_finite(t.grads, self.found_inf)
             found = self.found_inf
-        ops.adamw_step(t.params, t.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd,
-                       1.0, found)
+        if split and pending:
+            s = tail_end
+            ops.adamw_step(t.params[s:], t.grads[s:], self.m[s:], self.v[s:], self.step_count, self.lr, self.betas, self.eps,
+                           self.wd, 1.0, None)
+            for w in pending:
+                w.wait()
+            ops.adamw_step(t.params[:s], t.grads[:s], self.m[:s], self.v[:s], self.step_count, self.lr, self.betas, self.eps,
+                           self.wd, 1.0, None)
+        else:
+            ops.adamw_step(t.params, t.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd,
+                           1.0, found)
         t.refresh()
         return ctx["loss"]
