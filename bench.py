@@ -33,9 +33,11 @@ PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 2MD + projection
 
-KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn_kernel", "mfma"), 2: ("attention_fwd_kernel", "mfma"),
-           3: ("attention_bwd_{delta,dq,dkv}", "mfma"), 4: ("bank_stream_kernel<fwd>", "hbm"),
-           5: ("bank_stream_kernel<bwd>", "hbm")}
+# attention at L = 77, head_dim 64 has 39 flop per byte of q/k/v/o traffic (ridge: 312): it is bounded by HBM, and is
+# priced on its algorithmic bytes (fwd: read qkv, write o = 8 W B per token; bwd: read qkv, o, dO, write dqkv = 16 W B)
+KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn_kernel (+ split-K reduce)", "mfma"),
+           2: ("attention_small_fwd_kernel", "hbm"), 3: ("attention_small_bwd_kernel", "hbm"),
+           4: ("bank forward pass (GEMM path at B >= 128)", "hbm"), 5: ("bank_stream_kernel<bwd>", "hbm")}
 
 
 def parse():
@@ -218,8 +220,11 @@ def main():
                 ms, work, n = C.c_double(), C.c_double(), C.c_int()
                 lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(n))
                 if n.value:
+                    w = work.value
+                    if kid in (2, 3):     # the profiler counts flops for attention; price it on bytes (see KERNELS)
+                        w = n.value * float(B * ids.shape[1]) * W * 2.0 * (4 if kid == 2 else 8)
                     per_kernel[kid] = dict(kernel=name, bound=bound, launches=n.value, total_ms=ms.value,
-                                           avg_us=ms.value / n.value * 1e3, work=work.value)
+                                           avg_us=ms.value / n.value * 1e3, work=w)
         roof = None
         extra = {}
         pass_ms = None
