@@ -18,6 +18,38 @@ import torch
 from . import ops
 
 
+class _Slice:
+    """Contiguous [begin, end) view of an indexable dataset (one rank's share of the validation queries)."""
+
+    def __init__(self, ds, begin, end):
+        self.ds, self.begin, self.end = ds, begin, end
+
+    def __len__(self):
+        return self.end - self.begin
+
+    def __getitem__(self, i):
+        return self.ds[self.begin + i]
+
+
+def _shard(dataset, distributed, group):
+    """validation shards the QUERY set across ranks, the gallery is replicated, metrics are summed counts."""
+    import torch.distributed as dist
+    if not distributed or not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dataset, None
+    from .distributed import shard_range
+    b, e = shard_range(len(dataset), dist.get_world_size(group), dist.get_rank(group))
+    return _Slice(dataset, b, e), group
+
+
+def _reduce_counts(counts, n, device, sharded, group):
+    """[hits...] and the local query count -> percentages over the GLOBAL query count (identical on every rank)."""
+    t = torch.tensor(list(counts) + [n], dtype=torch.float64, device=device)
+    if sharded:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+    return [float(x) / float(t[-1]) * 100 for x in t[:-1]]
+
+
 def _batches(dataset, bs=32):
     n = len(dataset)
     for s in range(0, n, bs):
@@ -62,8 +94,11 @@ def _scores_and_topk(predicted, index_features, exclude_idx, K):
 
 
 def compute_fiq_val_metrics(relative_val_dataset, model, index_features: torch.Tensor, index_names: List[str],
-                            device=torch.device("cuda")) -> Tuple[float, float]:
-    """validate.py:19-51 -> (recall@10, recall@50) in percent."""
+                            device=torch.device("cuda"), distributed=False, group=None) -> Tuple[float, float]:
+    """validate.py:19-51 -> (recall@10, recall@50) in percent.  distributed=True: every rank scores its share of the
+    queries against the whole gallery and the hit counts are all-reduced."""
+    relative_val_dataset, grp = _shard(relative_val_dataset, distributed, group)
+    sharded = isinstance(relative_val_dataset, _Slice)
     predicted, target_names, refer_names = generate_fiq_val_predictions(model, relative_val_dataset, index_names,
                                                                         index_features, device)
     name2idx = _name_index(index_names)
@@ -73,8 +108,8 @@ def compute_fiq_val_metrics(relative_val_dataset, model, index_features: torch.T
     _, top = _scores_and_topk(predicted, feats, ref_idx, 50)
     hit = top == tgt_idx[:, None]
     n = len(target_names)
-    r10 = hit[:, :10].any(dim=1).sum().item() / n * 100
-    r50 = hit[:, :50].any(dim=1).sum().item() / n * 100
+    r10, r50 = _reduce_counts([hit[:, :10].any(dim=1).sum().item(), hit[:, :50].any(dim=1).sum().item()], n, device,
+                              sharded, grp)
     return r10, r50
 
 
@@ -96,8 +131,10 @@ def generate_cirr_val_predictions(model, relative_val_dataset, index_names: List
 
 
 def compute_cirr_val_metrics(relative_val_dataset, model, index_features: torch.Tensor, index_names: List[str],
-                             device=torch.device("cuda")):
-    """validate.py:111-156 -> (Rs@1, Rs@2, Rs@3, R@1, R@5, R@10, R@50) in percent."""
+                             device=torch.device("cuda"), distributed=False, group=None):
+    """validate.py:111-156 -> (Rs@1, Rs@2, Rs@3, R@1, R@5, R@10, R@50) in percent (distributed: see the FashionIQ one)."""
+    relative_val_dataset, grp = _shard(relative_val_dataset, distributed, group)
+    sharded = isinstance(relative_val_dataset, _Slice)
     predicted, reference_names, target_names, group_members = generate_cirr_val_predictions(
         model, relative_val_dataset, index_names, index_features, device)
     if index_features.dim() > 2:                                        # validate.py:120-121
@@ -109,7 +146,7 @@ def compute_cirr_val_metrics(relative_val_dataset, model, index_features: torch.
     tgt_idx = torch.tensor([name2idx[str(t)] for t in target_names], dtype=torch.int64, device=device)
     scores, top = _scores_and_topk(predicted, feats, ref_idx, 50)
     hit = top == tgt_idx[:, None].to(torch.int32)
-    recalls = [hit[:, :k].any(dim=1).sum().item() / n * 100 for k in (1, 5, 10, 50)]
+    recall_counts = [hit[:, :k].any(dim=1).sum().item() for k in (1, 5, 10, 50)]
     # subset metric (validate.py:139-142): rank of the target among its group members, reference removed
     gm = torch.tensor([[name2idx[str(m)] for m in g] for g in group_members], dtype=torch.int64, device=device)
     gs = torch.gather(scores, 1, gm)                                    # [n, G] fp64
@@ -119,8 +156,8 @@ def compute_cirr_val_metrics(relative_val_dataset, model, index_features: torch.
     rank = ahead.sum(dim=1)
     in_group = (gm == tgt_idx[:, None]).any(dim=1)
     assert bool(in_group.all()), "every target must be one of its group members (validate.py:145)"
-    group_recalls = [(rank < k).sum().item() / n * 100 for k in (1, 2, 3)]
-    return tuple(group_recalls + recalls)
+    group_counts = [(rank < k).sum().item() for k in (1, 2, 3)]
+    return tuple(_reduce_counts(group_counts + recall_counts, n, device, sharded, grp))
 
 
 def synthetic_recall_at_k(model, n_gallery=6000, n_query=2000, seed=7, device=torch.device("cuda")):

@@ -124,3 +124,59 @@ def test_rccl_call_pattern_on_one_rank():
     r = subprocess.run([sys.executable, "-c", _NCCL_WORLD1, str(_free_port())], env=env, capture_output=True, text=True,
                        timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+class _SlicedStub:
+    """encode_text stub whose pre-made features follow the rank's query slice (the metric code needs the protocol only)."""
+
+    def __init__(self, feats, begin):
+        self.feats, self.pos, self.output_dim = feats, begin, feats.shape[1]
+
+    def encode_text(self, captions):
+        out = self.feats[self.pos:self.pos + len(captions)]
+        self.pos += len(captions)
+        return out
+
+
+def _val_worker(rank, world, port, golden_dir, out):
+    import json
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd import validate
+        from spn4cir_amd.distributed import shard_range
+        z = np.load(os.path.join(golden_dir, "recall.npz"))
+        names, members = json.loads(str(z["names"])), json.loads(str(z["members"]))
+        gallery, text = torch.from_numpy(z["gallery"]).cuda(), torch.from_numpy(z["text_feats"]).cuda()
+        ref_idx, tgt_idx = z["ref_idx"], z["tgt_idx"]
+        fiq = [(names[r], names[t], [f"a {i}.", f"b {i}?"]) for i, (r, t) in enumerate(zip(ref_idx, tgt_idx))]
+        cirr = [(names[r], names[t], f"cap {i}", members[i]) for i, (r, t) in enumerate(zip(ref_idx, tgt_idx))]
+        b, _ = shard_range(len(fiq), world, rank)
+        r = validate.compute_fiq_val_metrics(fiq, _SlicedStub(text, b), gallery, names, distributed=True)
+        c = validate.compute_cirr_val_metrics(cirr, _SlicedStub(text, b), gallery, names, distributed=True)
+        out.put((rank, tuple(r), tuple(c)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_sharded_validation_matches_reference(golden_dir):
+    """validation shards the query set over the ranks (gallery replicated) and sums hit counts - every rank
+    must report the reference's FashionIQ / CIRR metrics."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "recall.npz"))
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, fiq, cirr in res:
+        assert fiq == pytest.approx(tuple(z["fiq"]), abs=1e-9)
+        assert cirr == pytest.approx(tuple(z["cirr"]), abs=1e-4)
