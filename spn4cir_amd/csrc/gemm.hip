@@ -152,11 +152,12 @@ int gemm_cfg() {
 
 int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
             const GemmEpilogue& ep, hipStream_t st) {
-    // 256x256 tiles need >= ~3/4 of the 256 CUs worth of tiles to pay off; small products (the packed text tower:
+    // 256x256 tiles need roughly half of the 256 CUs worth of tiles to pay off (measured break-even between 63 and 150
+    // tiles); small products (the packed text tower:
     // M ~ 5 k rows, N = 768 -> 63 tiles) run on the 128x128 kernel below, which brings 4x the workgroups.
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const bool small = gemm_cfg() == 3 && t256 < 160 && t128 >= 2 * t256 && mode != GEMM_BANKSTATS;
+    const bool small = gemm_cfg() == 3 && t256 < 112 && t128 >= 2 * t256 && mode != GEMM_BANKSTATS;
     if (!gemm_use_v1() && !small) return gemm_nt2(A, B, M, N, K, lda, ldb, mode, ep, st);
     if (M <= 0 || N <= 0 || K <= 0) return SPN_ERR_ARG;
     if (K % BK || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
