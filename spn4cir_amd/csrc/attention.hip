@@ -183,6 +183,10 @@ int attention_fwd(const AttnArgs& a, hipStream_t st) {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         return attention_small_fwd(a, st);
     }
+    if (attention_cross_ok(a) && !attn_force_flash()) {
+        ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
+        return attention_cross_fwd(a, st);
+    }
     {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         hipLaunchKernelGGL(attention_fwd_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, a);
@@ -403,6 +407,7 @@ int attention_bwd(const AttnBwdArgs& g, hipStream_t st) {
     hipLaunchKernelGGL(attention_delta_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const bf16_t*)a.o, a.ldo, g.d_o,
                        g.lddo, g.delta, a.B, a.H, a.Lq);
     SPN_CHECK_LAUNCH();
+    if (attention_cross_ok(a) && !attn_force_flash()) return attention_cross_bwd(g, st);
     hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, g);
     SPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((a.Lk + 63) / 64, a.B * a.H), dim3(256), 0, st, g);

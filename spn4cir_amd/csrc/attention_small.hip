@@ -358,6 +358,319 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     }
 }
 
+// ------------------------------------------------------------------- few queries, many keys (forward)
+// Same shape class as attention_cross_bwd_kernel: one block per (sequence, head), one wave per 16 queries (Q fragments
+// in registers), keys / values streamed in tiles of 64 with the next tile's loads in flight, online softmax, P.V from
+// the row-major V tile through transpose reads (no transposed LDS copy).
+template <int NQ>
+__global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a) {
+    constexpr int KR = 64, PLD2 = KR + 8, NTH = NQ * 64;
+    constexpr int ITER = (KR * 8 + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KR * SLD + NQ * 16 * PLD2];
+    bf16_t* Ks = smem;
+    bf16_t* Vs = smem + KR * SLD;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    bf16_t* Ps = smem + 2 * KR * SLD + w * 16 * PLD2;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const bf16_t* qb = a.q + (size_t)b * Lq * a.ldq + h * SHD;
+    const bf16_t* kb = a.k + (size_t)b * Lk * a.ldk + h * SHD;
+    const bf16_t* vb = a.v + (size_t)b * Lk * a.ldv + h * SHD;
+    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * Lk : nullptr;
+    bf16x8 kreg[ITER], vreg[ITER];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
+            kreg[it] = zero8s();
+            vreg[it] = zero8s();
+            if (i < KR * 8 && j0 + r < Lk) {
+                kreg[it] = *(const bf16x8*)(kb + (size_t)(j0 + r) * a.ldk + ch * 8);
+                vreg[it] = *(const bf16x8*)(vb + (size_t)(j0 + r) * a.ldv + ch * 8);
+            }
+        }
+    };
+    fetch(0);
+    const int q0 = w * 16, qrow = q0 + (lane & 15);
+    const bool row_ok = qrow < Lq;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = zero8s();
+        if (row_ok) qf[ks] = *(const bf16x8*)(qb + (size_t)qrow * a.ldq + ks * 32 + (lane >> 4) * 8);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int j0 = 0; j0 < Lk; j0 += KR) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
+            if (i < KR * 8) {
+                *(bf16x8*)(Ks + r * SLD + ch * 8) = kreg[it];
+                *(bf16x8*)(Vs + r * SLD + ch * 8) = vreg[it];
+            }
+        }
+        __syncthreads();
+        if (j0 + KR < Lk) fetch(j0 + KR);
+        f32x4 s[4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[kt] = mfma16s(rfrag(Ks, SLD, kt * 16, ks * 32, lane), qf[ks], s[kt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j0 + kt * 16 + (lane >> 4) * 4 + r;
+                float v = s[kt][r] * a.scale;
+                if (kbias && key < Lk) v += kbias[key];
+                if (key >= Lk) v = -INFINITY;
+                s[kt][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        }
+        mt = qg_max(mt);
+        const float m_new = fmaxf(m_run, mt);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            bf16x4 pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[kt][r] - m_use);
+                rs += p;
+                pb[r] = f2bf(p);
+            }
+            *(bf16x4*)(Ps + (lane & 15) * PLD2 + kt * 16 + (lane >> 4) * 4) = pb;
+        }
+        rs = qg_sum(rs);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] *= alpha;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pf = rfrag(Ps, PLD2, 0, ks * 32, lane);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = mfma16s(tfrag(Vs, SLD, ks * 32, d * 16, lane, KR), pf, o[d]);
+        }
+    }
+    if (!row_ok) return;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    bf16_t* orow = a.o + ((size_t)b * Lq + qrow) * a.ldo + h * SHD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        bf16x4 ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[d][r] * inv);
+        *(bf16x4*)(orow + d * 16 + (lane >> 4) * 4) = ob;
+    }
+    if (a.lse && (lane >> 4) == 0)
+        a.lse[((size_t)b * a.H + h) * Lq + qrow] = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
+}
+
+int attention_cross_fwd(const AttnArgs& a, hipStream_t st) {
+    const dim3 grid(a.B * a.H);
+    switch ((a.Lq + 15) / 16) {
+        case 1: hipLaunchKernelGGL(attention_cross_fwd_kernel<1>, grid, dim3(64), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(attention_cross_fwd_kernel<2>, grid, dim3(128), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(attention_cross_fwd_kernel<3>, grid, dim3(192), 0, st, a); break;
+        default: hipLaunchKernelGGL(attention_cross_fwd_kernel<4>, grid, dim3(256), 0, st, a); break;
+    }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ------------------------------------------------------------------ few queries, many keys (backward)
+// BERT cross-attention (blip4cir/med.py:161-243): Lq <= 64 text queries over Lk = 577 image keys.  One block per
+// (sequence, head) keeps Q and dO in LDS, streams the keys / values in tiles of 64 (next tile's global loads in flight
+// while the current one is processed) and produces dQ (accumulated over the tiles in registers), dK and dV (complete
+// per tile: all queries of the head live in this block) in ONE pass over K and V - the tiled kernels in attention.hip
+// read K and V twice and re-load the query tile for every key tile.  Needs delta = rowsum(dO * O) and lse.
+template <int NQ>
+__global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArgs g) {
+    const AttnArgs& a = g.f;
+    constexpr int QR = NQ * 16, ZRQ = QR, TRQ = QR + 1;      // query rows, zero row, rows of the query-side tiles
+    constexpr int KR = 64, TRK = KR + 1;
+    constexpr int PLD2 = KR + 8;                             // P / dS row stride (keys of one tile)
+    constexpr int QS = (QR + 31) / 32;
+    constexpr int NTH = NQ * 64;
+    constexpr int ITER = (KR * 8 + NTH - 1) / NTH;           // 16-byte chunks of a K (or V) tile per thread
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* Qs = smem;
+    bf16_t* Os = Qs + TRQ * SLD;
+    bf16_t* Ks = Os + TRQ * SLD;
+    bf16_t* Vs = Ks + TRK * SLD;
+    bf16_t* Pm = Vs + TRK * SLD;
+    bf16_t* Dm = Pm + TRQ * PLD2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const bf16_t* qb = a.q + (size_t)b * Lq * a.ldq + h * SHD;
+    const bf16_t* kb = a.k + (size_t)b * Lk * a.ldk + h * SHD;
+    const bf16_t* vb = a.v + (size_t)b * Lk * a.ldv + h * SHD;
+    const bf16_t* dob = g.d_o + (size_t)b * Lq * g.lddo + h * SHD;
+    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * Lk : nullptr;
+    {
+        const bf16_t* const bases[2] = {qb, dob};
+        const int lds_[2] = {a.ldq, g.lddo};
+        bf16_t* const dsts[2] = {Qs, Os};
+        load_rows_multi<TRQ, NTH, 2>(bases, lds_, Lq, tid, dsts);
+    }
+    for (int i = tid; i < PLD2; i += NTH) {                  // zero rows of P / dS
+        Pm[ZRQ * PLD2 + i] = (bf16_t)0.0f;
+        Dm[ZRQ * PLD2 + i] = (bf16_t)0.0f;
+    }
+    for (int i = tid; i < SLD; i += NTH) {                   // zero rows of the key-side tiles (never addressed by tfrag
+        Ks[KR * SLD + i] = (bf16_t)0.0f;                     // with zrow = KR, kept for symmetry)
+        Vs[KR * SLD + i] = (bf16_t)0.0f;
+    }
+    // first key tile into registers
+    bf16x8 kreg[ITER], vreg[ITER];
+    auto fetch = [&](int j0) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
+            kreg[it] = zero8s();
+            vreg[it] = zero8s();
+            if (i < KR * 8 && j0 + r < Lk) {
+                kreg[it] = *(const bf16x8*)(kb + (size_t)(j0 + r) * a.ldk + ch * 8);
+                vreg[it] = *(const bf16x8*)(vb + (size_t)(j0 + r) * a.ldv + ch * 8);
+            }
+        }
+    };
+    fetch(0);
+    __syncthreads();
+    const int q0 = w * 16, qrow = q0 + (lane & 15);
+    const bool row_ok = qrow < Lq;
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = rfrag(Qs, SLD, q0, ks * 32, lane);
+        dof[ks] = rfrag(Os, SLD, q0, ks * 32, lane);
+    }
+    const size_t srow = ((size_t)b * a.H + h) * Lq + (row_ok ? qrow : 0);
+    const float lse = row_ok ? a.lse[srow] : 0.f, dlt = row_ok ? g.delta[srow] : 0.f;
+    f32x4 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = f32x4{0, 0, 0, 0};
+
+    for (int j0 = 0; j0 < Lk; j0 += KR) {
+        __syncthreads();                                     // the previous tile's phase B is done with Ks / Vs / Pm / Dm
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
+            if (i < KR * 8) {
+                *(bf16x8*)(Ks + r * SLD + ch * 8) = kreg[it];
+                *(bf16x8*)(Vs + r * SLD + ch * 8) = vreg[it];
+            }
+        }
+        __syncthreads();
+        if (j0 + KR < Lk) fetch(j0 + KR);                    // in flight during both phases below
+        // ---- phase A: this wave's 16 queries against the tile's 64 keys
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = mfma16s(rfrag(Ks, SLD, kt * 16, ks * 32, lane), qf[ks], s);
+                dp = mfma16s(rfrag(Vs, SLD, kt * 16, ks * 32, lane), dof[ks], dp);
+            }
+            bf16x4 pb, db;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j0 + kt * 16 + (lane >> 4) * 4 + r;
+                float p = 0.f;
+                if (row_ok && key < Lk) p = __expf(s[r] * a.scale + (kbias ? kbias[key] : 0.f) - lse);
+                pb[r] = f2bf(p);
+                db[r] = f2bf(p * (dp[r] - dlt));
+            }
+            *(bf16x4*)(Pm + (q0 + (lane & 15)) * PLD2 + kt * 16 + (lane >> 4) * 4) = pb;
+            *(bf16x4*)(Dm + (q0 + (lane & 15)) * PLD2 + kt * 16 + (lane >> 4) * 4) = db;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dQ^T[d][q] += sum_key K[key][d] dS[q][key]   (this wave's own dS rows)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 df = rfrag(Dm, PLD2, q0, ks * 32, lane);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = mfma16s(tfrag(Ks, SLD, ks * 32, d * 16, lane, KR), df, dq[d]);
+        }
+        __syncthreads();                                     // every wave's P / dS rows are in LDS
+        // ---- phase B: 16-key subtiles of the tile, dealt round-robin to the waves
+        for (int kt = w; kt < 4; kt += NQ) {
+            const int k0 = kt * 16, key = j0 + k0 + (lane & 15);
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dk[d] = f32x4{0, 0, 0, 0};
+                dv[d] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs) {
+                const bf16x8 pf = tfrag(Pm, PLD2, qs * 32, k0, lane, ZRQ);
+                const bf16x8 df = tfrag(Dm, PLD2, qs * 32, k0, lane, ZRQ);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    dv[d] = mfma16s(tfrag(Os, SLD, qs * 32, d * 16, lane, ZRQ), pf, dv[d]);
+                    dk[d] = mfma16s(tfrag(Qs, SLD, qs * 32, d * 16, lane, ZRQ), df, dk[d]);
+                }
+            }
+            if (key < Lk) {
+                bf16_t* dkrow = g.dk + ((size_t)b * Lk + key) * g.lddk + h * SHD;
+                bf16_t* dvrow = g.dv + ((size_t)b * Lk + key) * g.lddv + h * SHD;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bf16x4 ok, ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ok[r] = f2bf(dk[d][r] * a.scale);
+                        ov[r] = f2bf(dv[d][r]);
+                    }
+                    *(bf16x4*)(dkrow + d * 16 + (lane >> 4) * 4) = ok;
+                    *(bf16x4*)(dvrow + d * 16 + (lane >> 4) * 4) = ov;
+                }
+            }
+        }
+    }
+    if (row_ok) {
+        bf16_t* drow = g.dq + ((size_t)b * Lq + qrow) * g.lddq + h * SHD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bf16x4 ob;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[r] = f2bf(dq[d][r] * a.scale);
+            *(bf16x4*)(drow + d * 16 + (lane >> 4) * 4) = ob;
+        }
+    }
+}
+
+template <int NQ>
+static int launch_cross_bwd(const AttnBwdArgs& g, hipStream_t st) {
+    constexpr int TRQ = NQ * 16 + 1, TRK = 65, PLD2 = 72;
+    constexpr int LDS = (2 * TRQ * SLD + 2 * TRK * SLD + 2 * TRQ * PLD2) * 2;
+    hipLaunchKernelGGL(attention_cross_bwd_kernel<NQ>, dim3(g.f.B * g.f.H), dim3(NQ * 64), LDS, st, g);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+bool attention_cross_ok(const AttnArgs& a) { return !a.causal && !a.cu && a.Lq <= 64 && a.Lk > a.Lq; }
+
+int attention_cross_bwd(const AttnBwdArgs& g, hipStream_t st) {
+    switch ((g.f.Lq + 15) / 16) {
+        case 1: return launch_cross_bwd<1>(g, st);
+        case 2: return launch_cross_bwd<2>(g, st);
+        case 3: return launch_cross_bwd<3>(g, st);
+        default: return launch_cross_bwd<4>(g, st);
+    }
+}
+
 bool attention_small_ok(const AttnArgs& a) { return a.Lq == a.Lk && a.Lq <= 128; }
 
 template <int NT>

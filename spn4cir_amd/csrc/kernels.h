@@ -120,6 +120,10 @@ int attention_bwd(const AttnBwdArgs& a, hipStream_t st);
 bool attention_small_ok(const AttnArgs& a);
 int attention_small_fwd(const AttnArgs& a, hipStream_t st);
 int attention_small_bwd(const AttnBwdArgs& a, hipStream_t st);
+// few queries (Lq <= 64, no causal mask) over many keys: fused dQ / dK / dV in one pass over K and V (needs delta)
+bool attention_cross_ok(const AttnArgs& a);
+int attention_cross_bwd(const AttnBwdArgs& a, hipStream_t st);
+int attention_cross_fwd(const AttnArgs& a, hipStream_t st);
 
 // bank.hip
 int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,

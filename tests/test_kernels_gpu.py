@@ -174,7 +174,9 @@ def attn_ref(q, k, v, B, H, Lq, Lk, causal, key_bias, scale):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal,bias", [(3, 2, 77, 77, True, False), (2, 3, 50, 50, False, False),
                                                    (1, 2, 257, 257, False, False), (2, 2, 9, 577, False, False),
-                                                   (3, 2, 20, 20, False, True), (2, 1, 130, 130, True, False)])
+                                                   (3, 2, 20, 20, False, True), (2, 1, 130, 130, True, False),
+                                                   (2, 2, 32, 577, False, True), (1, 3, 64, 200, False, False),
+                                                   (2, 1, 40, 100, False, True)])
 def test_attention_fwd_bwd(ops, B, H, Lq, Lk, causal, bias):
     g = torch.Generator().manual_seed(B * 1000 + Lq)
     W = H * 64
