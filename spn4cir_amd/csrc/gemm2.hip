@@ -225,6 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     int cur = 0, fill = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most the (STAGES-2) newer stages are still outstanding
+        static_assert(STAGES <= 3, "the counted wait below assumes at most one newer tile in flight");
         if (STAGES >= 3 && kt + 1 < nk) wait_vmcnt<(STAGES - 2) * (GA + GB)>();
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -601,8 +602,6 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
             if (nt_phased()) return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
             return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
-        case 4: return dispatch_nt2<256, 256, 2, 4, 4, 32>(A, B, M, N, K, lda, ldb, mode, e2, st);   // measured slower
-        case 5: return dispatch_nt2<256, 256, 2, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);       // 4 waves x 128x128
         case 6: return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);   // 8-slot staggered
         default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
     }
