@@ -129,6 +129,19 @@ int spn_bank_stats_fwd_fp8(const void* q_bf16, int ldq, const void* bank_fp8, co
 int spn_bank_grad_q_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale, const int64_t* labels,
                         int B, int M, int D, int m_begin, float inv_tau, const float* row_lse, float label_smoothing,
                         int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
+/* Token-max bank (blip24cir/lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py:253-265,
+ * forward_stage2): every target is 32 Q-Former token rows, bank bf16 [n_targets * 32, D] (target t = rows 32t..32t+31),
+ * logit(b, t) = max_k q_b . bank[32t + k] * inv_tau, cross entropy over the targets.  labels / t_begin /
+ * targets_total count TARGETS.  The reference loops over the batch in Python with one [M,32] matmul per sample;
+ * here the bank streams through LDS once per pass, the max is taken per 32-row tile and the gradient goes to the
+ * arg-max row (first index on ties, as torch.max).  Same statistics / finalize contract as above; workspace from
+ * spn_bank_workspace_bytes(B, n_targets * 32, D). */
+int spn_bank_stats_fwd_tokmax(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B,
+                              int n_targets, int D, int t_begin, float inv_tau, float* stats, void* ws, size_t ws_bytes,
+                              void* stream);
+int spn_bank_grad_q_tokmax(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int n_targets,
+                           int D, int t_begin, float inv_tau, const float* row_lse, float label_smoothing,
+                           int64_t targets_total, float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 /* In-batch negatives, BASELINE config 1 (clip4cir/models.py:151-167, wo_bank: labels = arange(B), the target
  * features are trainable too).  Loss and dq come from the three calls above with the normalised target
  * features as the bank; this is the target-side gradient

@@ -73,3 +73,18 @@ def infonce_grad_q(q, bank, labels, tau, grad_scale=None):
     g[torch.arange(B), labels.long()] -= 1.0
     scale = (1.0 / B) if grad_scale is None else grad_scale
     return (g @ bank.double()) * (scale / tau)
+
+
+def tokmax_infonce(fusion_feats, target_feats, target_indexs, temp):
+    """blip24cir/lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py:253-265 (forward_stage2, loss_qtc):
+    per sample i, sim[m, k] = <fusion_feats[i], target_feats[m, k, :]> over the 32 Q-Former tokens of every bank
+    target, logit[m] = max_k sim[m, k] / temp, cross entropy against target_indexs[i]; mean over the batch.
+    PARITY UNPINNED: LAVIS is not importable offline (omegaconf / timm / fairscale absent), so this follows the
+    source by reading; tests cross-check the per-sample loop below against a batched formulation."""
+    bs = target_indexs.shape[0]
+    loss = torch.zeros((), dtype=fusion_feats.dtype)
+    for i in range(bs):
+        sim = torch.matmul(target_feats, fusion_feats[i])          # [M, 32]
+        sim_q2t, _ = sim.max(-1)
+        loss = loss + F.cross_entropy((sim_q2t / temp).unsqueeze(0), target_indexs[i:i + 1].long())
+    return loss / bs

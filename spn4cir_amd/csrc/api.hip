@@ -185,6 +185,24 @@ int spn_bank_grad_q_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const
     return bank_grad_q(a, row_lse, label_smoothing, M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream));
 }
 
+int spn_bank_stats_fwd_tokmax(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B,
+                              int n_targets, int D, int t_begin, float inv_tau, float* stats, void* ws, size_t ws_bytes,
+                              void* stream) {
+    if (!stats || n_targets <= 0 || n_targets > (INT32_MAX >> 5)) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank_bf16, labels, B, n_targets * 32, D, t_begin, inv_tau);
+    a.group = 32;
+    return bank_stats_fwd(a, stats, (float*)ws, ws_bytes, ST(stream));
+}
+
+int spn_bank_grad_q_tokmax(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B, int n_targets,
+                           int D, int t_begin, float inv_tau, const float* row_lse, float label_smoothing,
+                           int64_t targets_total, float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream) {
+    if (n_targets <= 0 || n_targets > (INT32_MAX >> 5)) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank_bf16, labels, B, n_targets * 32, D, t_begin, inv_tau);
+    a.group = 32;
+    return bank_grad_q(a, row_lse, label_smoothing, targets_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream));
+}
+
 int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float inv_scale, const float* found_inf, void* stream) {
     if (!p || !g || !m || !v) return SPN_ERR_ARG;

@@ -127,7 +127,11 @@ static BankChunking bank_chunking(int B, int M) {
     return c;
 }
 
-template <int D, bool BWD, bool FP8>
+// GRP (token-max banks, blip24cir .../blip2_qformer_cir_align_prompt.py:253-265): the bank holds TR = 32 token rows per
+// target, a bank tile is exactly one target, and the logit of (query, target) is the MAX over the tile's 32 rows;
+// labels, m_begin and the statistics count targets.  The gradient flows to the arg-max row only (first index on
+// ties, as torch.max), so G has one non-zero per (query, tile) and the dq GEMM is unchanged.
+template <int D, bool BWD, bool FP8, bool GRP>
 __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChunking ck, const float* __restrict__ row_lse,
                                                             float label_smoothing, float inv_m_total,
                                                             float* __restrict__ ws) {
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     const int mt_o = w >> 1, nt_o = w & 1;
     const int q_o = q0 + mt_o * 16 + (lane & 15);
     const bool q_ok = q_o < a.B;
-    const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;
+    const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;   // GRP: shard-local TARGET id
     float lse = 0.f;
     if constexpr (BWD) lse = q_ok ? row_lse[q_o] : 0.f;
     float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
@@ -277,7 +281,48 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         for (int ww = 0; ww < 4; ++ww) sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
 
         const int key0 = m_lo + t * TR + nt_o * 16 + (lane >> 4) * 4;   // shard-local row of sv[0]
-        if constexpr (!BWD) {
+        if constexpr (GRP) {
+            // both key-half waves of a query row reduce the whole tile (the other half's partial sums are read
+            // as well), so the max and its position are known to each without another barrier
+            f32x4 so = {0, 0, 0, 0};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) so += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + (nt_o ^ 1)) * 64 + lane) * 4);
+            float gm = -INFINITY;
+            int gi = TR;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k_own = nt_o * 16 + (lane >> 4) * 4 + r, k_oth = (nt_o ^ 1) * 16 + (lane >> 4) * 4 + r;
+                if (sv[r] > gm || (sv[r] == gm && k_own < gi)) { gm = sv[r]; gi = k_own; }
+                if (so[r] > gm || (so[r] == gm && k_oth < gi)) { gm = so[r]; gi = k_oth; }
+            }
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float m2 = __shfl_xor(gm, off, 64);
+                const int i2 = __shfl_xor(gi, off, 64);
+                if (m2 > gm || (m2 == gm && i2 < gi)) { gm = m2; gi = i2; }
+            }
+            const int tgt = m_lo / TR + t;                               // shard-local target id of this tile
+            const float z = gm * a.inv_tau;
+            if constexpr (!BWD) {
+                if (nt_o == 0 && (lane >> 4) == 0) {                     // one lane per query row keeps the statistics
+                    const float mn = fmaxf(st_m, z);
+                    st_l = st_l * __expf(st_m - mn) + __expf(z - mn);
+                    st_m = mn;
+                    st_sl += z;
+                    if ((int64_t)tgt == label) st_lab = z;
+                }
+            } else {
+                float gv = 0.f;
+                if (q_ok) {
+                    gv = __expf(z - lse) - label_smoothing * inv_m_total;
+                    if ((int64_t)tgt == label) gv -= 1.0f - label_smoothing;
+                }
+                bf16x4 gb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb[r] = f2bf(nt_o * 16 + (lane >> 4) * 4 + r == gi ? gv : 0.f);
+                *(bf16x4*)(Gs + (mt_o * 16 + (lane & 15)) * LDG + nt_o * 16 + (lane >> 4) * 4) = gb;
+            }
+        } else if constexpr (!BWD) {
             float tm = -INFINITY;
             float v[4];
 #pragma unroll
@@ -311,6 +356,8 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                 gb[r] = f2bf(gv);
             }
             *(bf16x4*)(Gs + (mt_o * 16 + (lane & 15)) * LDG + nt_o * 16 + (lane >> 4) * 4) = gb;
+        }
+        if constexpr (BWD) {
             __syncthreads();
             // ---- dq[q][d] += sum_key G[q][key] bank[key][d]:  D[i = d][j = query], k = key (one 32-step)
             bf16x8 gf[2];
@@ -367,6 +414,222 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                 *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
         }
     }
+}
+
+// ------------------------------------------------------------------ token-max bank, wave-private tiles
+// Same contract as bank_stream_kernel<.., GRP = true>, restructured for small D (the Q-Former's 256): the
+// block kernel above splits D over its four waves and pays three block barriers per 16 KB tile.  Here every wave owns
+// whole tiles (= targets): it DMAs its own tile into its own double-buffered LDS region, computes the 32 x 32 logits
+// over the full D, takes the max / arg-max over the 32 token rows with lane shuffles, and (backward) builds the
+// one-non-zero-per-query G operand directly in registers - no block barrier inside the main loop, the only waits are
+// the wave's own counted vmcnt.  Waves of a block take tiles w, w+4, ... of the block's chunk; their statistics /
+// dq partials are merged through LDS once at the end.
+template <int D, bool BWD>
+__global__ __launch_bounds__(256, 1) void bank_tokmax_kernel(BankArgs a, BankChunking ck, const float* __restrict__ row_lse,
+                                                            float label_smoothing, float inv_m_total,
+                                                            float* __restrict__ ws) {
+    constexpr int ROWB = D * 2, TILE_B = TR * ROWB;
+    constexpr int KS = D / 32, NDT = D / 16, NDMA = TILE_B / 1024;
+    static_assert(2 * TILE_B == BQ * D * 4, "a wave's two tile buffers hold its fp32 dq partial");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    char* my = smem + w * 2 * TILE_B;
+    float* Fin = (float*)(smem + 8 * TILE_B);             // [4 waves][BQ][4]
+    const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
+    const int q0 = qi * BQ;
+    const int m_lo = mi * ck.rows;
+    const int m_hi = min(a.M, m_lo + ck.rows);
+    const int ntiles = m_hi > m_lo ? (m_hi - m_lo) / TR : 0;      // M % TR == 0 (checked by the host)
+    const int nmine = ntiles > w ? (ntiles - w + 3) / 4 : 0;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)ROWB);
+
+    bf16x8 qf[2][KS];
+    int64_t label[2];
+    float lse[2];
+    bool q_ok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int qr = q0 + mt * 16 + (lane & 15);
+        q_ok[mt] = qr < a.B;
+        label[mt] = q_ok[mt] ? a.labels[qr] - (int64_t)a.m_begin : -1;
+        lse[mt] = (BWD && q_ok[mt]) ? row_lse[qr] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (q_ok[mt]) {
+                qf[mt][ks] = *(const bf16x8*)(a.q + (size_t)qr * a.ldq + ks * 32 + (lane >> 4) * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[mt][ks][e] = (bf16_t)0.0f;
+            }
+        }
+    }
+    float st_m[2] = {-INFINITY, -INFINITY}, st_l[2] = {0.f, 0.f}, st_sl[2] = {0.f, 0.f}, st_lab[2] = {-INFINITY, -INFINITY};
+    [[maybe_unused]] f32x4 dq[2][NDT];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[mt][dt] = f32x4{0, 0, 0, 0};
+    }
+    auto stage = [&](int t, int buf) {
+        char* dst = my + buf * TILE_B;
+        const int mrow0 = m_lo + t * TR;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int p = i * 1024 + lane * 16;
+            const int r = p / ROWB, cp = (p % ROWB) >> 4;
+            const int c = cp ^ bank_swz(r & 15);
+            glds16(rs, dst + i * 1024, (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)c * 16u);
+        }
+    };
+    if (nmine > 0) stage(w, 0);
+    for (int i = 0; i < nmine; ++i) {
+        const int t = w + 4 * i, buf = i & 1;
+        if (i + 1 < nmine) {
+            stage(t + 4, buf ^ 1);                 // the other buffer: last read one iteration ago, by this wave only
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        } else {
+            wait_vm0();
+        }
+        const char* T = my + buf * TILE_B;
+        f32x4 s[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int r = nt * 16 + (lane & 15);
+                const int c = ks * 4 + (lane >> 4);
+                const bf16x8 bfrag = *(const bf16x8*)(T + r * ROWB + ((c ^ bank_swz(r & 15)) << 4));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) s[mt][nt] = mfma16b(bfrag, qf[mt][ks], s[mt][nt]);
+            }
+        }
+        const int tgt = m_lo / TR + t;             // shard-local target id of this tile
+        [[maybe_unused]] bf16x8 gf[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            // lane holds keys nt*16 + (lane>>4)*4 + r of query lane&15: max + FIRST arg-max over the 32 keys
+            float gm = -INFINITY;
+            int gi = TR;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = nt * 16 + (lane >> 4) * 4 + r;
+                    const float v = s[mt][nt][r];
+                    if (v > gm || (v == gm && k < gi)) { gm = v; gi = k; }
+                }
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float m2 = __shfl_xor(gm, off, 64);
+                const int i2 = __shfl_xor(gi, off, 64);
+                if (m2 > gm || (m2 == gm && i2 < gi)) { gm = m2; gi = i2; }
+            }
+            const float z = gm * a.inv_tau;
+            if constexpr (!BWD) {
+                const float mn = fmaxf(st_m[mt], z);
+                st_l[mt] = st_l[mt] * __expf(st_m[mt] - mn) + __expf(z - mn);
+                st_m[mt] = mn;
+                st_sl[mt] += z;
+                if ((int64_t)tgt == label[mt]) st_lab[mt] = z;
+            } else {
+                float gv = 0.f;
+                if (q_ok[mt]) {
+                    gv = __expf(z - lse[mt]) - label_smoothing * inv_m_total;
+                    if ((int64_t)tgt == label[mt]) gv -= 1.0f - label_smoothing;
+                }
+                // B operand of the dq MFMA: j = query (lane&15), k = key (lane>>4)*8 + e
+                const bf16_t gvb = f2bf(gv), zb = (bf16_t)0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gf[mt][e] = ((lane >> 4) * 8 + e == gi) ? gvb : zb;
+            }
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                union { s16x4 h[2]; bf16x8 v; } u;
+                const int cb = dt * 16;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
+                    const int col = cb + (lane & 3) * 4;
+                    u.h[h] = lds_tr16_b64(T + r * ROWB + (((col >> 3) ^ bank_swz(r & 15)) << 4) + (col & 7) * 2);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) dq[mt][dt] = mfma16b(u.v, gf[mt], dq[mt][dt]);
+            }
+        }
+    }
+    if constexpr (!BWD) {
+        if (lane < 16) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *(f32x4*)(Fin + ((w * BQ + mt * 16 + lane) * 4)) = f32x4{st_m[mt], st_l[mt], st_sl[mt], st_lab[mt]};
+        }
+        __syncthreads();
+        if (tid < BQ) {
+            float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+            for (int ww = 0; ww < 4; ++ww) {
+                const f32x4 p = *(const f32x4*)(Fin + ((ww * BQ + tid) * 4));
+                const float mn = fmaxf(m, p[0]);
+                if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+                m = mn;
+                sl += p[2];
+                lab = fmaxf(lab, p[3]);
+            }
+            const int q = q0 + tid;
+            if (q < a.B) *(f32x4*)(ws + ((size_t)mi * a.B + q) * 4) = f32x4{m, l, sl, lab};
+        }
+    } else {
+        // this wave's dq partial -> its own (now idle) tile buffers as fp32 [BQ][D]; then all threads add the 4 partials
+        float* mine = (float*)my;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+                *(f32x4*)(mine + (mt * 16 + (lane & 15)) * D + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
+        __syncthreads();
+        for (int e = tid * 4; e < BQ * D; e += 256 * 4) {
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) acc += *(const f32x4*)((const float*)(smem + ww * 2 * TILE_B) + e);
+            const int q = q0 + e / D;
+            if (q < a.B) *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + e % D) = acc;
+        }
+    }
+}
+
+template <int D, bool BWD>
+static int launch_tokmax(const BankArgs& a, const BankChunking& c, const float* row_lse, float ls, float inv_m,
+                         float* ws, hipStream_t st) {
+    const size_t lds = 8 * (size_t)TR * D * 2 + 4 * BQ * 4 * sizeof(float);
+    auto kern = bank_tokmax_kernel<D, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        const double bytes = (double)a.M * D * 2 + (double)a.B * D * (BWD ? 6 : 2) + (double)a.B * 16;
+        ProfScope prof(BWD ? PK_BANK_BWD : PK_BANK_FWD, bytes, st);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
+    }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// SPN_TOKMAX_BLOCK=1 keeps the block-cooperative kernel for D <= 256 too (A/B switch for the tests)
+static bool tokmax_wave_path(const BankArgs& a) {
+    static const bool off = [] {
+        const char* e = getenv("SPN_TOKMAX_BLOCK");
+        return e && e[0] == '1';
+    }();
+    return a.group && !off && (a.D == 128 || a.D == 256);
 }
 
 // fold per-chunk statistics [n][B][4] -> [B][4]
@@ -435,11 +698,11 @@ size_t bank_workspace_bytes(int B, int M, int D) {
     return a > b ? a : b;
 }
 
-template <int D, bool BWD, bool FP8>
+template <int D, bool BWD, bool FP8, bool GRP = false>
 static int launch_bank(const BankArgs& a, const BankChunking& c, const float* row_lse, float ls, float inv_m,
                        float* ws, hipStream_t st) {
     const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2;
-    auto kern = bank_stream_kernel<D, BWD, FP8>;
+    auto kern = bank_stream_kernel<D, BWD, FP8, GRP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -459,7 +722,8 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
 
 #define SPN_BANK_CASE(D_, BWD_, ...)                                                                  \
     case D_:                                                                                          \
-        rc = a.bank_scale ? launch_bank<D_, BWD_, true>(__VA_ARGS__) : launch_bank<D_, BWD_, false>(__VA_ARGS__); \
+        rc = a.group ? launch_bank<D_, BWD_, false, true>(__VA_ARGS__)                                   \
+             : a.bank_scale ? launch_bank<D_, BWD_, true>(__VA_ARGS__) : launch_bank<D_, BWD_, false>(__VA_ARGS__); \
         break;
 #define SPN_BANK_DISPATCH(BWD_, ...)               \
     switch (a.D) {                                 \
@@ -476,6 +740,7 @@ static int bank_check(const BankArgs& a) {
     if (a.B <= 0 || a.M <= 0 || !a.q || !a.bank || !a.labels) return SPN_ERR_ARG;
     if (a.ldq % 8 || a.ldq < a.D) return SPN_ERR_SHAPE;
     if ((uint64_t)a.M * a.D * (a.bank_scale ? 1 : 2) >= (1ull << 32)) return SPN_ERR_SHAPE;
+    if (a.group && (a.group != TR || a.M % TR || a.bank_scale)) return SPN_ERR_SHAPE;   // token-max: 32 bf16 rows per target
     return SPN_OK;
 }
 
@@ -489,7 +754,7 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
         const char* e = getenv("SPN_BANK_GEMM");
         return !(e && e[0] == '0');
     }();
-    if (use_gemm && !a.bank_scale && a.B >= 128 && a.D % 64 == 0) {
+    if (use_gemm && !a.bank_scale && !a.group && a.B >= 128 && a.D % 64 == 0) {
         const int nt = gemm_bank_stats_tiles(a.M);
         if (ws_bytes < (size_t)nt * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
         {
@@ -504,7 +769,12 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     }
     const BankChunking c = bank_chunking(a.B, a.M);
     if (ws_bytes < (size_t)c.nchunks * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
-    SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)
+    if (tokmax_wave_path(a)) {
+        rc = a.D == 128 ? launch_tokmax<128, false>(a, c, nullptr, 0.f, 0.f, ws, st)
+                        : launch_tokmax<256, false>(a, c, nullptr, 0.f, 0.f, ws, st);
+    } else {
+        SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)
+    }
     if (rc) return rc;
     hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, ws, c.nchunks, a.B, stats);
     SPN_CHECK_LAUNCH();
@@ -527,7 +797,12 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     if (!row_lse || !dq || M_total <= 0) return SPN_ERR_ARG;
     const BankChunking c = bank_chunking(a.B, a.M);
     if (ws_bytes < (size_t)c.nchunks * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
-    SPN_BANK_DISPATCH(true, a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
+    if (tokmax_wave_path(a)) {
+        rc = a.D == 128 ? launch_tokmax<128, true>(a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
+                        : launch_tokmax<256, true>(a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st);
+    } else {
+        SPN_BANK_DISPATCH(true, a, c, row_lse, label_smoothing, 1.0f / (float)M_total, ws, st)
+    }
     if (rc) return rc;
     return fold_rows(ws, (size_t)a.B * a.D, c.nchunks, (size_t)a.B * a.D, dq, grad_scale * a.inv_tau, 0, st);
 }

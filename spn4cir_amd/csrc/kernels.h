@@ -138,6 +138,8 @@ struct BankArgs {
     int m_begin;                     // global id of row 0 of this shard
     float inv_tau;
     const float* bank_scale = nullptr;   // fp8 bank: per-row dequantisation scale [M_local]
+    int group = 0;                       // 32: token-max bank - 32 rows per target, logit = max over them; labels,
+                                         // m_begin and the softmax run over TARGETS (M stays the row count)
 };
 // fp32 [M, D] -> OCP e4m3 [M, Dp] (zero padded) with one fp32 scale per row (row max -> 448)
 int bank_quantize_fp8(const float* bank, int M, int D, int Dp, uint8_t* out, float* scale, hipStream_t st);

@@ -278,6 +278,31 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
 
 
 # -------------------------------------------------------------------------------- AdamW
+def bank_stats_fwd_tokmax(q_bf16, bank_tok_bf16, labels, inv_tau, t_begin=0):
+    """Token-max bank (spn_bank_stats_fwd_tokmax): bank_tok_bf16 [n_targets, 32, Dp] bf16, labels = target ids."""
+    B, Dp = q_bf16.shape
+    n, g, Db = bank_tok_bf16.shape
+    if g != 32 or Db != Dp or not bank_tok_bf16.is_contiguous():
+        raise ValueError("token-max bank must be contiguous [n_targets, 32, %d]" % Dp)
+    stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
+    ws = workspace(lib().spn_bank_workspace_bytes(B, n * 32, Dp), q_bf16.device, "bank")
+    check(lib().spn_bank_stats_fwd_tokmax(_p(q_bf16), Dp, _p(bank_tok_bf16), _p(labels), B, n, Dp, t_begin, inv_tau,
+                                          _p(stats), _p(ws), ws.numel(), _stream()), "bank_stats_fwd_tokmax")
+    return stats
+
+
+def bank_grad_q_tokmax(q_bf16, bank_tok_bf16, labels, inv_tau, row_lse, grad_scale, targets_total=None,
+                       label_smoothing=0.0, t_begin=0):
+    B, Dp = q_bf16.shape
+    n = bank_tok_bf16.shape[0]
+    dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
+    ws = workspace(lib().spn_bank_workspace_bytes(B, n * 32, Dp), q_bf16.device, "bank")
+    check(lib().spn_bank_grad_q_tokmax(_p(q_bf16), Dp, _p(bank_tok_bf16), _p(labels), B, n, Dp, t_begin, inv_tau,
+                                       _p(row_lse), label_smoothing, targets_total or n, grad_scale, _p(dq), _p(ws),
+                                       ws.numel(), _stream()), "bank_grad_q_tokmax")
+    return dq
+
+
 def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, inv_scale=1.0, found_inf=None):
     check(lib().spn_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step,
                                inv_scale, _p(found_inf), _stream()), "adamw_step")

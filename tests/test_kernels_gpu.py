@@ -295,6 +295,71 @@ def test_bank_matches_golden_loss_cases(ops, golden_dir):
         assert rel_err(dtext, torch.from_numpy(z[f"c{ci}_dtext"])) < 3e-2
 
 
+@pytest.mark.parametrize("B,M,D,temp", [(4, 7, 256, 0.07), (32, 999, 256, 0.07), (128, 6000, 256, 0.05),
+                                         (45, 300, 128, 0.03), (1, 1, 256, 0.07)])
+def test_bank_tokmax(ops, B, M, D, temp):
+    """SURVEY 8f-4 (BLIP-2 head): logit = max over the 32 token rows of a target; first-index ties as torch.max."""
+    from oracle import bank_loss
+    g = torch.Generator().manual_seed(B * 7 + M)
+    bank = torch.nn.functional.normalize(torch.randn(M, 32, D, generator=g), dim=-1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    labels = torch.randint(0, M, (B,), generator=g)
+    labels[0], labels[-1] = 0, M - 1
+    bank_b = bank.to(torch.bfloat16).cuda().contiguous()
+    qb = q.to(torch.bfloat16).cuda().contiguous()
+    qr, br = qb.cpu().double(), bank_b.cpu().double()
+    # reference on the same bf16-rounded operands (fp64): the oracle's per-sample loop
+    qd = qr.clone().requires_grad_(True)
+    ref = bank_loss.tokmax_infonce(qd, br, labels, temp)
+    ref.backward()
+    stats = ops.bank_stats_fwd_tokmax(qb, bank_b, dev(labels), 1.0 / temp)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    assert abs(mean.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item()))
+    sim = torch.einsum("bd,mkd->bmk", qr, br).amax(-1) / temp
+    assert (lse.cpu().double() - torch.logsumexp(sim, 1)).abs().max() < 2e-4
+    assert (stats[:, 3].cpu().double() - sim[torch.arange(B), labels]).abs().max() < 2e-4
+    dq = ops.bank_grad_q_tokmax(qb, bank_b, dev(labels), 1.0 / temp, lse, 1.0 / B)
+    assert rel_err(dq, qd.grad) < 1.5e-2
+    # shards of targets, as two ranks would hold them
+    if M >= 4:
+        cut = M // 3
+        s0 = ops.bank_stats_fwd_tokmax(qb, bank_b[:cut].contiguous(), dev(labels), 1.0 / temp, t_begin=0)
+        s1 = ops.bank_stats_fwd_tokmax(qb, bank_b[cut:].contiguous(), dev(labels), 1.0 / temp, t_begin=cut)
+        lse2, _, mean2 = ops.bank_loss_finalize(torch.stack([s0, s1]), M)
+        assert abs(mean2.item() - mean.item()) < 1e-5 and (lse2 - lse).abs().max() < 1e-5
+        d0 = ops.bank_grad_q_tokmax(qb, bank_b[:cut].contiguous(), dev(labels), 1.0 / temp, lse, 1.0 / B,
+                                    targets_total=M, t_begin=0)
+        d1 = ops.bank_grad_q_tokmax(qb, bank_b[cut:].contiguous(), dev(labels), 1.0 / temp, lse, 1.0 / B,
+                                    targets_total=M, t_begin=cut)
+        assert rel_err(d0 + d1, dq) < 1e-5
+
+
+def test_bank_tokmax_ties_and_head(ops):
+    """Exact ties (duplicated token rows) send the gradient to the FIRST arg-max row; loss_qtc wires the autograd
+    graph incl. the learnable temperature (blip2_qformer_cir_align_prompt.py:253-268)."""
+    from oracle import bank_loss
+    from spn4cir_amd import blip2_head
+    g = torch.Generator().manual_seed(5)
+    B, M, D, temp = 8, 40, 256, 0.07
+    bank = torch.nn.functional.normalize(torch.randn(M, 32, D, generator=g), dim=-1).to(torch.bfloat16).float()
+    bank[:, 17] = bank[:, 3]                     # every target: rows 3 and 17 identical
+    bank[:, 29] = bank[:, 3]
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1).to(torch.bfloat16).float()
+    labels = torch.randint(0, M, (B,), generator=g)
+    qd = q.double().requires_grad_(True)
+    td = torch.tensor(temp, dtype=torch.float64, requires_grad=True)
+    ref = bank_loss.tokmax_infonce(qd, bank.double(), labels, td)
+    ref.backward()
+    qg = q.cuda().requires_grad_(True)
+    tg = torch.tensor(temp, device="cuda", requires_grad=True)
+    out = blip2_head.loss_qtc(qg, blip2_head.prepare_token_bank(bank), labels, tg)
+    assert set(out) == {"loss_qtc"} and out["loss_qtc"].dim() == 0
+    out["loss_qtc"].backward()
+    assert abs(out["loss_qtc"].item() - ref.item()) < 2e-4
+    assert rel_err(qg.grad, qd.grad) < 1.5e-2
+    assert abs(tg.grad.item() - td.grad.item()) < 2e-2 * abs(td.grad.item()) + 1e-4
+
+
 @pytest.mark.parametrize("B,M,D,tau", [(32, 4099, 512, 0.02), (16, 100000, 768, 0.02), (256, 40000, 768, 0.02),
                                         (33, 1500, 640, 0.03)])
 def test_bank_fp8(ops, B, M, D, tau):

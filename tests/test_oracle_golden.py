@@ -188,3 +188,15 @@ def test_resnet_tower_matches_reference(golden_dir):
     out = clip_resnet.encode_image(sd, torch.from_numpy(z["image"]))
     ref = torch.from_numpy(z["image_feats"])
     assert (out - ref).abs().max() < 1e-5 * ref.abs().max().clamp_min(1.0)
+
+
+def test_tokmax_oracle_loop_equals_batched_form():
+    """oracle.bank_loss.tokmax_infonce (per-sample loop, as the reference writes it) == einsum + amax + CE."""
+    from oracle import bank_loss
+    g = torch.Generator().manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(6, 32, generator=g), dim=-1).double()
+    bank = torch.nn.functional.normalize(torch.randn(50, 32, 32, generator=g), dim=-1).double()
+    labels = torch.randint(0, 50, (6,), generator=g)
+    a = bank_loss.tokmax_infonce(q, bank, labels, 0.07)
+    b = torch.nn.functional.cross_entropy(torch.einsum("bd,mkd->bmk", q, bank).amax(-1) / 0.07, labels)
+    assert abs(a.item() - b.item()) < 1e-12
