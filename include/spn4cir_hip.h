@@ -206,6 +206,46 @@ int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void*
 int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
 
+/* Token output for TG-CIR (tgcir/models.py:127-151, Backbone.extract_text_fea): as spn_text_fwd, plus
+ * tokens [B*L, W] fp32 (and an optional bf16 copy) = ln_final of EVERY row - TG-CIR feeds all 77 positions, padding
+ * included, to text_fc + TokenLearner - with the per-row statistics tok_mean / tok_rstd [B*L] the backward needs.
+ * Dense layout only (cfg->T == 0).  spn_text_bwd_tokens takes the gradients of both outputs. */
+int spn_text_fwd_tokens(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        void* acts, float* feats, float* tokens, void* tokens_bf16, float* tok_mean, float* tok_rstd,
+                        void* stream);
+int spn_text_bwd_tokens(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        void* acts, const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd,
+                        float* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* TG-CIR second-stage head (tgcir/models.py): the per-sample glue between spn_text_fwd_tokens and the
+ * bank InfoNCE calls.  All buffers fp32 unless named *_bf16; S = 8 local tokens, G global tokens, NT = G + S <= 16,
+ * L <= 128.  The two Linear layers with a GEMM shape (Backbone.text_fc, s_remain_map[0]) are spn_gemm_nt / spn_gemm_tn
+ * calls made by the host between these (s_remain_map[0] on spn_gemm_f32: its gradient sums cancel heavily across
+ * tokens and do not survive bf16 operands).  ws: spn_tg_ws_bytes(B, C).
+ *   tokenlearn (models.py:21-49 SpatialAttention / TokenLearner, applied to z = text_fc(tokens) at :149):
+ *       attn[b,l,s] = sigmoid(<z[b,l,:], w[s,:]> + bias[s]);  mod_tokens[b, G+s, :] = mean_l attn[b,l,s] z[b,l,:]
+ *   fuse_prep (models.py:136-148 + the cat of :200): mod_tokens[b, i<G, :] = feats[b,:] * relu(masks[i,:]);
+ *       x_bf16 / x_f32[b*NT+t, :] = cat(ref_tokens[b,t,:], mod_tokens[b,t,:])
+ *   gate (models.py:198-204, img_txt_fusion): remain = sigmoid(<relu(hpre), w2> + b2), hpre = s_remain_map[0](x);
+ *       pooled[b,:] = mean_t remain * ref + (1 - remain) * mod     (the caller L2-normalises: spn_combine_l2norm_fwd)
+ *   the *_bwd calls return the gradients of every input named d*. */
+size_t spn_tg_ws_bytes(int B, int C);
+int spn_tg_tokenlearn_fwd(const float* z, const float* w, const float* bias, float* attn, float* mod_tokens, int B, int L,
+                          int C, int S, int G, void* stream);
+int spn_tg_tokenlearn_bwd(const float* z, const float* w, const float* attn, const float* dmod_tokens, void* dz_bf16,
+                          float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int L, int C, int S, int G,
+                          void* stream);
+int spn_tg_fuse_prep(const float* feats, const float* masks, const float* ref_tokens, float* mod_tokens, void* x_bf16,
+                     float* x_f32 /* either may be NULL */, int B, int C, int S, int G, void* stream);
+int spn_tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref_tokens, const float* mod_tokens,
+                    float* remain, float* pooled, int B, int NT, int C, void* stream);
+int spn_tg_gate_bwd(const float* dpooled, const float* ref_tokens, const float* mod_tokens, const float* remain,
+                    const float* hpre, const float* w2, float* dmod_tokens, float* dh /* [B*NT, C] */,
+                    float* dh_t /* [C, B*NT] */, float* dw2, float* db1, float* db2, void* ws, size_t ws_bytes, int B, int NT,
+                    int C, void* stream);
+int spn_tg_mod_bwd(const float* dx, float* dmod_tokens, const float* feats, const float* masks, float* dfeats, float* dmasks,
+                   void* ws, size_t ws_bytes, int B, int C, int S, int G, void* stream);
+
 /* ---------------------------------------------------------------- image preprocessing
  * targetpad_transform (clip4cir/data_utils.py:42-65,84-98): TargetPad -> Resize(dim, BICUBIC) -> CenterCrop(dim) ->
  * ToTensor -> Normalize on a decoded RGB image, bit-identical to the Pillow/torchvision pipeline the reference

@@ -89,6 +89,15 @@ _SIGS = {
     "spn_text_fwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp]),
     "spn_text_fwd_packed": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp]),
     "spn_text_bwd": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_text_fwd_tokens": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "spn_text_bwd_tokens": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_tg_ws_bytes": (sz, [i32, i32]),
+    "spn_tg_tokenlearn_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "spn_tg_tokenlearn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]),
+    "spn_tg_fuse_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spn_tg_gate_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "spn_tg_gate_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "spn_tg_mod_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
     "spn_text_bwd_tail": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),

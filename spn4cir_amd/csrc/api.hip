@@ -266,6 +266,59 @@ int spn_text_bwd(const spn_text_cfg* cfg, const float* params, const void* weigh
                     ST(stream));
 }
 
+int spn_text_fwd_tokens(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        void* acts, float* feats, float* tokens, void* tokens_bf16, float* tok_mean, float* tok_rstd,
+                        void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !feats || !tokens || !tok_mean || !tok_rstd) return SPN_ERR_ARG;
+    return text_fwd_tokens(tc(cfg), params, CBF(weights_bf16), ids, (char*)acts, feats, tokens, BF(tokens_bf16), tok_mean,
+                           tok_rstd, ST(stream));
+}
+
+int spn_text_bwd_tokens(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        void* acts, const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd,
+                        float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !dfeats || !dtokens || !tok_mean || !tok_rstd || !grads || !ws)
+        return SPN_ERR_ARG;
+    return text_bwd_tokens(tc(cfg), params, CBF(weights_bf16), ids, (char*)acts, dfeats, dtokens, tok_mean, tok_rstd, grads,
+                           (char*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_tg_ws_bytes(int B, int C) { return tg_ws_bytes(B, C); }
+
+int spn_tg_tokenlearn_fwd(const float* z, const float* w, const float* bias, float* attn, float* mod_tokens, int B, int L,
+                          int C, int S, int G, void* stream) {
+    return tg_tokenlearn_fwd(z, w, bias, attn, mod_tokens, B, L, C, S, G, ST(stream));
+}
+
+int spn_tg_tokenlearn_bwd(const float* z, const float* w, const float* attn, const float* dmod_tokens, void* dz_bf16,
+                          float* dw, float* dbias, void* ws, size_t ws_bytes, int B, int L, int C, int S, int G,
+                          void* stream) {
+    return tg_tokenlearn_bwd(z, w, attn, dmod_tokens, BF(dz_bf16), dw, dbias, (float*)ws, ws_bytes, B, L, C, S, G,
+                             ST(stream));
+}
+
+int spn_tg_fuse_prep(const float* feats, const float* masks, const float* ref_tokens, float* mod_tokens, void* x_bf16,
+                     float* x_f32, int B, int C, int S, int G, void* stream) {
+    return tg_fuse_prep(feats, masks, ref_tokens, mod_tokens, BF(x_bf16), x_f32, B, C, S, G, ST(stream));
+}
+
+int spn_tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref_tokens, const float* mod_tokens,
+                    float* remain, float* pooled, int B, int NT, int C, void* stream) {
+    return tg_gate_fwd(hpre, w2, b2, ref_tokens, mod_tokens, remain, pooled, B, NT, C, ST(stream));
+}
+
+int spn_tg_gate_bwd(const float* dpooled, const float* ref_tokens, const float* mod_tokens, const float* remain,
+                    const float* hpre, const float* w2, float* dmod_tokens, float* dh, float* dh_t, float* dw2, float* db1,
+                    float* db2, void* ws, size_t ws_bytes, int B, int NT, int C, void* stream) {
+    return tg_gate_bwd(dpooled, ref_tokens, mod_tokens, remain, hpre, w2, dmod_tokens, dh, dh_t, dw2, db1, db2, (float*)ws,
+                       ws_bytes, B, NT, C, ST(stream));
+}
+
+int spn_tg_mod_bwd(const float* dx, float* dmod_tokens, const float* feats, const float* masks, float* dfeats, float* dmasks,
+                   void* ws, size_t ws_bytes, int B, int C, int S, int G, void* stream) {
+    return tg_mod_bwd(dx, dmod_tokens, feats, masks, dfeats, dmasks, (float*)ws, ws_bytes, B, C, S, G, ST(stream));
+}
+
 static_assert(sizeof(spn_vision_cfg) == sizeof(VisionCfg), "spn_vision_cfg layout");
 static_assert(sizeof(spn_vision_layout_t) == sizeof(VisionLayout), "spn_vision_layout_t layout");
 

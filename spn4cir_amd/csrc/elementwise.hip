@@ -223,7 +223,7 @@ int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, fl
 // the causal mask and are skipped); dtok must be zero on entry.  dpos[l,:] = sum_b dx[b,l,:].
 __global__ void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ eot,
                                      const float* __restrict__ dx, float* __restrict__ dtok, int BL, int L, int W,
-                                     int vocab) {
+                                     int vocab, int skip_id) {
     const int w4 = W >> 2;
     const size_t total = (size_t)BL * w4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -232,6 +232,7 @@ __global__ void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int3
         if (eot && l > eot[b]) continue;
         int id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        if (id == skip_id) continue;
         const f32x4 g = *(const f32x4*)(dx + (size_t)row * W + c);
         float* d = dtok + (size_t)id * W + c;
         atomicAdd(d + 0, g[0]);
@@ -255,7 +256,7 @@ int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dt
     if (W % 4) return SPN_ERR_SHAPE;
     if (dtok) {
         hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, eot, dx,
-                           dtok, B * L, L, W, vocab);
+                           dtok, B * L, L, W, vocab, -1);
         SPN_CHECK_LAUNCH();
     }
     if (dpos) {
@@ -265,6 +266,39 @@ int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dt
         if (rc) return rc;
     }
     return SPN_OK;
+}
+
+// All rows live (TG-CIR's token output: the padding rows carry gradient too).  Most of the B*L rows then hold the SAME
+// id (the zero padding), and their atomics on one dtok row serialise (1.4 ms at B = 256); those rows are summed by a
+// slab reduction instead: partial[s, :] = sum of dx over the rows of slab s whose id is `hot_id`, folded into dtok[hot_id].
+static constexpr int EB_SLAB = 64;
+
+__global__ __launch_bounds__(256) void embed_bwd_hot_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dx,
+                                                           float* __restrict__ part, int BL, int W, int hot_id) {
+    const int r0 = blockIdx.x * EB_SLAB, r1 = min(BL, r0 + EB_SLAB);
+    for (int c = threadIdx.x * 4; c < W; c += 256 * 4) {
+        f32x4 s = {0, 0, 0, 0};
+        for (int r = r0; r < r1; ++r)
+            if (ids[r] == hot_id) s += *(const f32x4*)(dx + (size_t)r * W + c);
+        *(f32x4*)(part + (size_t)blockIdx.x * W + c) = s;
+    }
+}
+
+size_t embed_bwd_all_ws_bytes(int B, int L, int W) { return (size_t)((B * L + EB_SLAB - 1) / EB_SLAB) * W * sizeof(float); }
+
+int embed_bwd_all(const int32_t* ids, const float* dx, float* dtok, float* dpos, int B, int L, int W, int vocab, int hot_id,
+                  float* ws, size_t ws_bytes, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    if (ws_bytes < embed_bwd_all_ws_bytes(B, L, W)) return SPN_ERR_WORKSPACE;
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, nullptr, dx, dtok,
+                       B * L, L, W, vocab, hot_id);
+    SPN_CHECK_LAUNCH();
+    const int slabs = (B * L + EB_SLAB - 1) / EB_SLAB;
+    hipLaunchKernelGGL(embed_bwd_hot_kernel, dim3(slabs), dim3(256), 0, st, ids, dx, ws, B * L, W, hot_id);
+    SPN_CHECK_LAUNCH();
+    int rc = fold_rows(ws, (size_t)W, slabs, (size_t)W, dtok + (size_t)hot_id * W, 1.0f, 0, st);
+    if (rc) return rc;
+    return fold_rows(dx, (size_t)L * W, B, (size_t)L * W, dpos, 1.0f, 0, st);
 }
 
 // eot[b] = argmax_l ids[b,l] (first maximum), clip/model.py:356

@@ -71,6 +71,9 @@ int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, fl
               hipStream_t st);
 int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,
               int vocab, hipStream_t st);
+size_t embed_bwd_all_ws_bytes(int B, int L, int W);
+int embed_bwd_all(const int32_t* ids, const float* dx, float* dtok, float* dpos, int B, int L, int W, int vocab, int hot_id,
+                  float* ws, size_t ws_bytes, hipStream_t st);
 int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st);
 int gather_rows_f32(const float* x, const int32_t* eot, float* out, int B, int L, int W, hipStream_t st);
 int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx_bf16, int B, int L, int W,
@@ -161,6 +164,22 @@ int inbatch_grad_t(const bf16_t* q, const bf16_t* t, int ldq, const float* row_l
 int preprocess_image(const uint8_t* src, int H, int W, int hp, int vp, const int32_t* kx, const int32_t* bx, int ksize_x,
                      const int32_t* ky, const int32_t* by, int ksize_y, int crop_left, int crop_top, int dim,
                      const float* mean3, const float* std3, uint8_t* tmp, float* out, uint8_t* out_u8, hipStream_t st);
+
+// tgcir.hip (TG-CIR head, tgcir/models.py:21-49,127-151,198-205)
+size_t tg_ws_bytes(int B, int C);
+int tg_tokenlearn_fwd(const float* z, const float* w, const float* bias, float* A, float* mod, int B, int L, int C, int S,
+                      int G, hipStream_t st);
+int tg_tokenlearn_bwd(const float* z, const float* w, const float* A, const float* dmod, bf16_t* dz, float* dw, float* dbias,
+                      float* ws, size_t ws_bytes, int B, int L, int C, int S, int G, hipStream_t st);
+int tg_fuse_prep(const float* feats, const float* masks, const float* ref, float* mod, bf16_t* X, float* Xf, int B, int C,
+                 int S, int G, hipStream_t st);
+int tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref, const float* mod, float* r,
+                float* pooled, int B, int NT, int C, hipStream_t st);
+int tg_gate_bwd(const float* dpooled, const float* ref, const float* mod, const float* r, const float* hpre, const float* w2,
+                float* dmod, float* dh, float* dhT, float* dw2, float* db1, float* db2, float* ws, size_t ws_bytes, int B,
+                int NT, int C, hipStream_t st);
+int tg_mod_bwd(const float* dX, float* dmod, const float* feats, const float* masks, float* dfeats, float* dmasks, float* ws,
+               size_t ws_bytes, int B, int C, int S, int G, hipStream_t st);
 
 // topk.hip
 int cosine_scores_f64(const float* q, const float* gallery, int Nq, int Ng, int D, double* out, hipStream_t st);

@@ -404,6 +404,8 @@ size_t text_ws_bytes(const TextCfg& c) {
     if (tp > op) op = tp;
     const size_t lb = align256(layernorm_bwd_workspace_bytes(c.B, c.W));
     if (lb > op) op = lb;
+    const size_t eb = align256(embed_bwd_all_ws_bytes(c.B, c.L, c.W));   // text_bwd_tokens' embedding backward
+    if (eb > op) op = eb;
     return b + op;
 }
 
@@ -460,6 +462,20 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
     e.out_f32 = feats; e.ldc = c.D;
     SPN_TRY(gemm_nt(A.ln_e, wb + t.bf16_text_proj_t, c.B, c.D, c.W, c.W, c.W, GEMM_STORE, e, st));
     return SPN_OK;
+}
+
+// Token output (tgcir/models.py:127-151, Backbone.extract_text_fea): ln_final over EVERY row - TG-CIR feeds all 77
+// positions, padding included, to text_fc + TokenLearner - next to the pooled feature.  Dense layout only: the rows
+// after the EOT token are live here.
+int text_fwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
+                    float* tokens, bf16_t* tokens_bf16, float* tok_mean, float* tok_rstd, hipStream_t st) {
+    if (c.T > 0) return SPN_ERR_ARG;
+    SPN_TRY(text_fwd(c, params, wb, ids, nullptr, acts, feats, st));
+    TextLayout t;
+    text_layout(c, &t);
+    TextActs A = text_acts_at(acts, c);
+    return layernorm_fwd(A.x_final, params + t.lnf_g, params + t.lnf_b, tokens_bf16, tokens, tok_mean, tok_rstd, c.B * c.L,
+                         c.W, 1e-5f, st);
 }
 
 // backward workspace carve-up (identical in every phase, so dx survives between the calls)
@@ -540,8 +556,8 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
 }
 
 // phase 3: token / positional embedding gradients
-int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
-                  hipStream_t st) {
+static int text_bwd_tail_impl(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                              bool all_rows, hipStream_t st) {
     SPN_TRY(text_check(c));
     TextBwdWs w;
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
@@ -553,12 +569,37 @@ int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads
     if (c.T > 0)
         SPN_TRY(embed_bwd_packed(ids, A.row_b, A.row_l, A.cu, w.dx, grads + t.tok, grads + t.pos, c.T, c.B, c.L, c.W, c.vocab,
                                  st));
+    else if (all_rows)   // id 0 = CLIP's padding (clip/clip.py:236: zeros): the hot row
+        SPN_TRY(embed_bwd_all(ids, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, 0, w.opws, w.opws_bytes, st));
     else SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
     if (c.L < c.L_ctx) {
         he = hipMemsetAsync(grads + t.pos + (size_t)c.L * c.W, 0, (size_t)(c.L_ctx - c.L) * c.W * sizeof(float), st);
         if (he != hipSuccess) return (int)he;
     }
     return SPN_OK;
+}
+
+int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                  hipStream_t st) {
+    return text_bwd_tail_impl(c, ids, acts, grads, ws, ws_bytes, false, st);
+}
+
+// backward of text_fwd_tokens: dfeats [B, D] (pooled feature) and dtokens [B*L, W] (ln_final output of every row)
+int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                    const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads,
+                    char* ws, size_t ws_bytes, hipStream_t st) {
+    if (c.T > 0) return SPN_ERR_ARG;
+    SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));   // dx = scatter of the EOT-row gradient
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    TextLayout t;
+    text_layout(c, &t);
+    TextActs A = text_acts_at(acts, c);
+    // + ln_final backward of every row, accumulated into dx (and its bf16 mirror) and into ln_final's gradients
+    SPN_TRY(layernorm_bwd(nullptr, dtokens, A.x_final, params + t.lnf_g, tok_mean, tok_rstd, w.dx, 1, w.dxb, grads + t.lnf_g,
+                          grads + t.lnf_b, 1, c.B * c.L, c.W, w.opws, w.opws_bytes, st));
+    for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    return text_bwd_tail_impl(c, ids, acts, grads, ws, ws_bytes, true, st);
 }
 
 int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,

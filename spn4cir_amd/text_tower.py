@@ -172,6 +172,41 @@ class TextTower:
                                  _p(self.grads), _p(self._ws), self._ws.numel(), _stream()), "text_bwd")
         return self.grads
 
+    def forward_tokens(self, ids):
+        """TG-CIR's text side (tgcir/models.py:127-137): -> (feats fp32 [B, D], tokens fp32 [B, L, W], tokens bf16):
+        the pooled feature plus ln_final of EVERY position (padding rows included - dense layout only)."""
+        if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
+            raise ValueError("ids must be a contiguous int32 device tensor")
+        B, L = ids.shape
+        if self._stale:
+            self.refresh()
+        cfg = self._buffers(B, L, False, 0)
+        feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
+        tokens = torch.empty(B, L, self.width, dtype=torch.float32, device=self.device)
+        tokens_b = torch.empty(B, L, self.width, dtype=torch.bfloat16, device=self.device)
+        self._tok_stats = torch.empty(2, B * L, dtype=torch.float32, device=self.device)
+        check(lib().spn_text_fwd_tokens(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(feats),
+                                        _p(tokens), _p(tokens_b), _p(self._tok_stats[0]), _p(self._tok_stats[1]),
+                                        _stream()), "text_fwd_tokens")
+        self._last = ids
+        self._last_T = 0
+        return feats, tokens, tokens_b
+
+    def backward_tokens(self, dfeats, dtokens):
+        """Gradients of both outputs of forward_tokens -> fills self.grads (overwrites) and returns it."""
+        ids = self._last
+        if ids is None or getattr(self, "_tok_stats", None) is None:
+            raise RuntimeError("backward_tokens() without a preceding forward_tokens()")
+        B, L = ids.shape
+        cfg = self._buffers(B, L, True, 0)
+        dfeats, dtokens = dfeats.contiguous(), dtokens.contiguous()
+        if dtokens.dtype != torch.float32 or dtokens.numel() != B * L * self.width:
+            raise ValueError("dtokens must be fp32 [B, L, W]")
+        check(lib().spn_text_bwd_tokens(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(dfeats),
+                                        _p(dtokens), _p(self._tok_stats[0]), _p(self._tok_stats[1]), _p(self.grads),
+                                        _p(self._ws), self._ws.numel(), _stream()), "text_bwd_tokens")
+        return self.grads
+
     def backward_phased(self, dfeats, on_span_ready):
         """Same as backward(), but calls on_span_ready(start, end) right after the launches that
         finish the flat-gradient range [start, end) have been enqueued (tail+head params first, then

@@ -19,3 +19,39 @@ def loss_case_inputs(ci):
     if ci == 1:   # label at the first row, the last row, and a duplicate label
         labels[0], labels[1], labels[2] = 0, m - 1, labels[3]
     return text, refer_bank, bank, ridx, labels, tau
+
+
+# ----------------------------------------------------------------------------- TG-CIR step (tgcir_step.npz)
+# Weights come from oracle.clip_text.synthetic_text_state_dict(C, LAYERS, C, VOCAB, L, seed=7) and
+# oracle.tgcir_head.synthetic_head(C, 8, 4, seed=11); large gradients are stored as every SAMPLE-th element + L2 norm.
+TGCIR = dict(B=6, L=77, C=512, VOCAB=1024, LAYERS=2, M=300, TAU=0.02, SAMPLE=97, TEXT_SEED=7, HEAD_SEED=11)
+
+
+def tgcir_inputs():
+    from oracle import clip_text
+    t = TGCIR
+    g = torch.Generator().manual_seed(31)
+    ids = clip_text.synthetic_token_ids(t["B"], ctx=t["L"], vocab=t["VOCAB"], seed=5, min_len=3, max_len=20)
+    ref = torch.randn(t["B"], 12, t["C"], generator=g) * 0.5
+    bank = torch.nn.functional.normalize(torch.randn(t["M"], t["C"], generator=g), dim=-1)
+    labels = torch.randint(0, t["M"], (t["B"],), generator=g)
+    return ids, ref, bank, labels
+
+
+def tgcir_weights():
+    from oracle import clip_text, tgcir_head
+    t = TGCIR
+    sd = clip_text.synthetic_text_state_dict(t["C"], t["LAYERS"], t["C"], vocab=t["VOCAB"], ctx=t["L"], seed=t["TEXT_SEED"])
+    return sd, tgcir_head.synthetic_head(t["C"], 8, 4, seed=t["HEAD_SEED"])
+
+
+def tgcir_grad_check(z, name, g, tol):
+    """Compare a gradient with its stored summary: L2 norm + every SAMPLE-th element (all of it when small)."""
+    g = g.detach().reshape(-1).double().cpu()
+    ref = torch.from_numpy(z["grad::" + name]).double()
+    got = g if g.numel() <= 8192 else g[::TGCIR["SAMPLE"]]
+    gn = float(z["gnorm::" + name])
+    assert abs(g.norm().item() - gn) <= tol * gn + 1e-12, (name, g.norm().item(), gn)
+    floor = gn * (got.numel() / max(1, g.numel())) ** 0.5          # expected norm of the sample
+    err = (got - ref).norm().item()
+    assert err <= tol * max(ref.norm().item(), floor) + 1e-12, (name, err, ref.norm().item())

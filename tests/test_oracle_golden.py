@@ -200,3 +200,26 @@ def test_tokmax_oracle_loop_equals_batched_form():
     a = bank_loss.tokmax_infonce(q, bank, labels, 0.07)
     b = torch.nn.functional.cross_entropy(torch.einsum("bd,mkd->bmk", q, bank).amax(-1) / 0.07, labels)
     assert abs(a.item() - b.item()) < 1e-12
+
+
+def test_tgcir_oracle_matches_reference(golden_dir):
+    """oracle.tgcir_head == tgcir/models.py CIRPlus.forward on CPU: loss, query, mod tokens, every gradient."""
+    import os
+    from oracle import tgcir_head
+    from cases import TGCIR, tgcir_grad_check, tgcir_inputs, tgcir_weights
+    sd, head = tgcir_weights()
+    ids, ref, bank, labels = tgcir_inputs()
+    z = np.load(os.path.join(golden_dir, "tgcir_step.npz"))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    head = {k: v.clone().requires_grad_(True) for k, v in head.items()}
+    loss, q = tgcir_head.bank_step(sd, head, ids, ref, bank, labels, TGCIR["TAU"])
+    tokens, feats = tgcir_head.text_tokens(sd, ids)
+    mod = tgcir_head.extract_text_fea(tokens, feats, head)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    assert (q.detach() - torch.from_numpy(z["q"])).abs().max() < 1e-5
+    assert (mod.detach() - torch.from_numpy(z["mod_token"])).abs().max() < 1e-5
+    loss.backward()
+    for k in tgcir_head.HEAD_KEYS:
+        tgcir_grad_check(z, k, head[k].grad, 2e-4)
+    for k, v in sd.items():
+        tgcir_grad_check(z, "clip." + k, v.grad, 2e-4)
