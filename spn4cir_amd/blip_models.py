@@ -121,6 +121,56 @@ class CIRPlus(nn.Module):
     def load_refer_bank(self, bank_path):
         self.refer_bank = torch.load(bank_path)
 
+    @staticmethod
+    def _image_batches(dataset, bs=32):
+        n = len(dataset)
+        for s in range(0, n, bs):
+            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
+            if items:
+                yield items
+
+    def _embed(self, images):
+        """img_embed + normalised vision_proj of token 0 for a list of [3, H, H] tensors."""
+        tokens, pooled = self.img_embed(torch.stack(images).to(self.device, torch.float32), return_pool_and_normalized=True)
+        return tokens, pooled
+
+    def extract_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """blip4cir/models.py:45-71: per-triplet reference TOKEN bank [len, S, W] (577 x 768 for ViT-B/16@384) and
+        the normalised pooled target bank [image_id, output_dim]; same `torch.save([refer_bank, target_bank])` file."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            self.refer_bank, self.target_bank = torch.load(bank_path)
+            return
+        refer, target = None, torch.zeros(cirDataset.image_id, self.output_dim)
+        for items in self._image_batches(cirDataset):
+            rtok, rpool = self._embed([it[0] for it in items])
+            _, tpool = self._embed([it[2] for it in items])
+            if refer is None:
+                refer = torch.zeros(len(cirDataset), rtok.shape[1], rtok.shape[2])
+            refer[torch.tensor([int(it[3]) for it in items])] = rtok.cpu()
+            target[torch.tensor([int(it[5]) for it in items])] = rpool.cpu()
+            target[torch.tensor([int(it[6]) for it in items])] = tpool.cpu()
+        self.refer_bank, self.target_bank = refer, target
+        if bank_path:
+            torch.save([refer, target], bank_path)
+
+    def extract_refer_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """blip4cir/models.py:73-89 (--plus): token bank per unique image id; written to bank_path, read back with
+        load_refer_bank (the reference never loads it here either)."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            return
+        refer = None
+        for items in self._image_batches(cirDataset):
+            rtok, _ = self._embed([it[0] for it in items])
+            ttok, _ = self._embed([it[2] for it in items])
+            if refer is None:
+                refer = torch.zeros(cirDataset.image_id, rtok.shape[1], rtok.shape[2])
+            refer[torch.tensor([int(it[5]) for it in items])] = rtok.cpu()
+            refer[torch.tensor([int(it[6]) for it in items])] = ttok.cpu()
+        self.refer_bank = refer
+        if bank_path:
+            torch.save(refer, bank_path)
+
     def img_embed(self, image, return_pool_and_normalized=False):
         """BLIP_Retrieval.img_embed (blip_cir.py:54-70): token sequence [B, S, W] (and normalised vision_proj of token 0)."""
         if self.vision is None:

@@ -179,3 +179,61 @@ def test_blip_cirplus_protocol(golden_dir):
     cos = torch.nn.functional.cosine_similarity(q.cpu().double(), torch.from_numpy(z["q"]).double(), dim=-1)
     assert (1 - cos).max() < 1e-3
     assert any(k.startswith("blip.text_encoder.encoder.layer.0.") for k in model.state_dict()) and "tau" in model.state_dict()
+
+
+def test_blip_bank_builders(golden_dir, tmp_path):
+    """blip4cir/models.py:45-92 bank builders on the GPU towers: same file formats, rows and indexing as the loop the
+    reference runs (token bank per triplet / per unique image, normalised pooled target bank)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import blip_vit
+    from spn4cir_amd.blip_models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "blip_fusion.npz"))
+    sd = {}
+    for k in z.files:
+        if k.startswith("sd::"):
+            name = k[4:]
+            sd[name if name.startswith("text_proj.") else "text_encoder." + name] = torch.from_numpy(z[k])
+    W, out_dim, res, patch = z["enc"].shape[2], z["bank"].shape[1], 64, 16
+    vsd = blip_vit.synthetic_state_dict(W, 2, patch, res, out_dim)
+    sd.update(vsd)
+    model = CIRPlus(sd, tau=0.03, device=torch.device("cuda"), plus=True)
+    assert model.input_dim == res
+
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.randn(7, 3, res, res, generator=g)            # 7 unique images
+
+    class DS:                                                  # duck-typed CIRDataset items (data_utils: 7-tuples)
+        image_id = 7
+        trip = [(0, 1), (2, 3), (0, 4), (5, 6), (6, 1)]        # (reference image id, target image id)
+
+        def __len__(self):
+            return len(self.trip)
+
+        def __getitem__(self, i):
+            r, t = self.trip[i]
+            return imgs[r], "cap", imgs[t], i, t, r, t
+
+    ds = DS()
+    path = str(tmp_path / "bank.pt")
+    model.extract_bank_features(ds, torch.device("cuda"), path)
+    tok_ref, pool_ref = blip_vit.img_embed(vsd, imgs, W // 64)
+    S = (res // patch) ** 2 + 1
+    assert model.refer_bank.shape == (5, S, W) and model.target_bank.shape == (7, out_dim)
+    for i, (r, t) in enumerate(ds.trip):
+        cos = torch.nn.functional.cosine_similarity(model.refer_bank[i].double(), tok_ref[r].double(), dim=-1)
+        assert (1 - cos).max() < 1e-3
+    cos = torch.nn.functional.cosine_similarity(model.target_bank.double(), pool_ref.double(), dim=-1)
+    assert (1 - cos).max() < 1e-3
+    saved = torch.load(path)
+    assert isinstance(saved, list) and torch.equal(saved[0], model.refer_bank) and torch.equal(saved[1], model.target_bank)
+    m2 = CIRPlus(sd, tau=0.03, device=torch.device("cuda"), plus=True)
+    m2.extract_bank_features(ds, torch.device("cuda"), path)               # load branch
+    assert torch.equal(m2.refer_bank, model.refer_bank)
+    p2 = str(tmp_path / "refer.pt")
+    model.extract_refer_bank_features(ds, torch.device("cuda"), p2)
+    assert model.refer_bank.shape == (7, S, W)
+    cos = torch.nn.functional.cosine_similarity(model.refer_bank.double().flatten(0, 1), tok_ref.double().flatten(0, 1), dim=-1)
+    assert (1 - cos).max() < 1e-3
+    m2.load_refer_bank(p2)
+    assert torch.equal(m2.refer_bank, model.refer_bank)
