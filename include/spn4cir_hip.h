@@ -219,7 +219,7 @@ int spn_text_bwd_tokens(const spn_text_cfg* cfg, const float* params, const void
 
 /* TG-CIR second-stage head (tgcir/models.py): the per-sample glue between spn_text_fwd_tokens and the
  * bank InfoNCE calls.  All buffers fp32 unless named *_bf16; S = 8 local tokens, G global tokens, NT = G + S <= 16,
- * L <= 128.  The two Linear layers with a GEMM shape (Backbone.text_fc, s_remain_map[0]) are spn_gemm_nt / spn_gemm_tn
+ * L <= 640.  The two Linear layers with a GEMM shape (Backbone.text_fc, s_remain_map[0]) are spn_gemm_nt / spn_gemm_tn
  * calls made by the host between these (s_remain_map[0] on spn_gemm_f32: its gradient sums cancel heavily across
  * tokens and do not survive bf16 operands).  ws: spn_tg_ws_bytes(B, C).
  *   tokenlearn (models.py:21-49 SpatialAttention / TokenLearner, applied to z = text_fc(tokens) at :149):
@@ -237,6 +237,10 @@ int spn_tg_tokenlearn_bwd(const float* z, const float* w, const float* attn, con
                           void* stream);
 int spn_tg_fuse_prep(const float* feats, const float* masks, const float* ref_tokens, float* mod_tokens, void* x_bf16,
                      float* x_f32 /* either may be NULL */, int B, int C, int S, int G, void* stream);
+/* image side (models.py:84-125,183-196): tokens[b, i<G, :] = feats[b,:] * relu(masks[i,:]) next to the local tokens
+ * spn_tg_tokenlearn_fwd wrote at G.., pooled[b,:] = mean_t tokens[b,t,:] (the caller L2-normalises) */
+int spn_tg_img_finish(const float* feats, const float* masks, float* tokens, float* pooled, int B, int C, int S, int G,
+                      void* stream);
 int spn_tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref_tokens, const float* mod_tokens,
                     float* remain, float* pooled, int B, int NT, int C, void* stream);
 int spn_tg_gate_bwd(const float* dpooled, const float* ref_tokens, const float* mod_tokens, const float* remain,

@@ -70,3 +70,34 @@ def bank_step(sd, head, ids, ref_token, target_bank, labels, tau):
     tokens, feats = text_tokens(sd, ids)
     q = img_txt_fusion(ref_token, extract_text_fea(tokens, feats, head), head)
     return F.cross_entropy((q @ target_bank.t()) / tau, labels.long()), q
+
+
+# ------------------------------------------------------------------------------------- image side (frozen in stage 2)
+IMG_HEAD_KEYS = ("fc.weight", "fc.bias", "tokenlearn.weight", "tokenlearn.bias", "masks.weight")
+
+
+def synthetic_img_head(C=512, Wv=768, S=8, G=4, seed=13):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    n = lambda shape, std: torch.randn(shape, generator=g) * std
+    m = torch.full((G, C), 0.1)
+    for i in range(G):
+        m[i, i * (C // G):(i + 1) * (C // G)] = 1.0
+    return {"fc.weight": n((C, Wv), Wv ** -0.5), "fc.bias": n((C,), 0.02), "tokenlearn.weight": n((S, C), C ** -0.5),
+            "tokenlearn.bias": n((S,), 0.1), "masks.weight": m + n((G, C), 0.2)}
+
+
+def extract_img_fea(vis_tokens, global_fea, ihead):
+    """Backbone.extract_img_fea (tgcir/models.py:84-125) after the ViT: vis_tokens = transformer output of every
+    token (class token included, before ln_post) [B, S, Wv]; global_fea = ln_post(cls) @ proj [B, C]."""
+    g = global_fea.unsqueeze(1) * F.relu(ihead["masks.weight"]).unsqueeze(0)
+    z = vis_tokens @ ihead["fc.weight"].t() + ihead["fc.bias"]
+    loc = token_learner(z, ihead["tokenlearn.weight"], ihead["tokenlearn.bias"])
+    return torch.cat([g, loc], dim=1)
+
+
+def img_embed(vsd, ihead, image):
+    """CIRPlus.img_embed(image, return_pool_and_normalized=True) (models.py:183-196): (tokens [B, 12, C], pooled)."""
+    from . import clip_vision
+    feats, tokens = clip_vision.encode_image(vsd, image, return_tokens=True)
+    emb = extract_img_fea(tokens, feats, ihead)
+    return emb, F.normalize(emb.mean(dim=1), p=2, dim=-1)

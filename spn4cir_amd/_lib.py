@@ -95,6 +95,7 @@ _SIGS = {
     "spn_tg_tokenlearn_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "spn_tg_tokenlearn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]),
     "spn_tg_fuse_prep": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "spn_tg_img_finish": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spn_tg_gate_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_tg_gate_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "spn_tg_mod_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),

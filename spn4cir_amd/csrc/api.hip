@@ -302,6 +302,11 @@ int spn_tg_fuse_prep(const float* feats, const float* masks, const float* ref_to
     return tg_fuse_prep(feats, masks, ref_tokens, mod_tokens, BF(x_bf16), x_f32, B, C, S, G, ST(stream));
 }
 
+int spn_tg_img_finish(const float* feats, const float* masks, float* tokens, float* pooled, int B, int C, int S, int G,
+                      void* stream) {
+    return tg_img_finish(feats, masks, tokens, pooled, B, C, S, G, ST(stream));
+}
+
 int spn_tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref_tokens, const float* mod_tokens,
                     float* remain, float* pooled, int B, int NT, int C, void* stream) {
     return tg_gate_fwd(hpre, w2, b2, ref_tokens, mod_tokens, remain, pooled, B, NT, C, ST(stream));

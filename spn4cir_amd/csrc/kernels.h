@@ -173,6 +173,8 @@ int tg_tokenlearn_bwd(const float* z, const float* w, const float* A, const floa
                       float* ws, size_t ws_bytes, int B, int L, int C, int S, int G, hipStream_t st);
 int tg_fuse_prep(const float* feats, const float* masks, const float* ref, float* mod, bf16_t* X, float* Xf, int B, int C,
                  int S, int G, hipStream_t st);
+int tg_img_finish(const float* feats, const float* masks, float* mod, float* pooled, int B, int C, int S, int G,
+                  hipStream_t st);
 int tg_gate_fwd(const float* hpre, const float* w2, const float* b2, const float* ref, const float* mod, float* r,
                 float* pooled, int B, int NT, int C, hipStream_t st);
 int tg_gate_bwd(const float* dpooled, const float* ref, const float* mod, const float* r, const float* hpre, const float* w2,

@@ -24,7 +24,7 @@
 namespace spn {
 
 static constexpr int TG_S = 8;        // local tokens (TokenLearner heads)
-static constexpr int TG_MAXL = 128;   // text positions
+static constexpr int TG_MAXL = 640;   // positions per sample (77 text tokens; 197 / 257 / 577 image tokens)
 static constexpr int TG_MAXNT = 16;   // tokens per sample
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -192,6 +192,38 @@ int tg_fuse_prep(const float* feats, const float* masks, const float* ref, float
     if (B <= 0 || !feats || !masks || !ref || !mod || (!X && !Xf)) return SPN_ERR_ARG;
     if (G + S > TG_MAXNT) return SPN_ERR_SHAPE;
     hipLaunchKernelGGL(tg_fuse_prep_kernel, dim3(B), dim3(256), 0, st, feats, masks, ref, mod, X, Xf, C, G, G + S);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// image side (frozen): mod[b, i<G, :] = feats[b] relu(masks[i]) next to the local tokens already in mod, and
+// pooled[b] = mean_t mod[b, t]   (img_embed(return_pool_and_normalized), models.py:183-196; the caller normalises)
+__global__ __launch_bounds__(256) void tg_img_finish_kernel(const float* __restrict__ feats, const float* __restrict__ masks,
+                                                           float* __restrict__ mod, float* __restrict__ pooled, int C, int G,
+                                                           int NT) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < NT; ++t) {
+            const size_t o = ((size_t)b * NT + t) * C + c;
+            float m;
+            if (t < G) {
+                m = feats[(size_t)b * C + c] * fmaxf(masks[t * C + c], 0.f);
+                mod[o] = m;
+            } else {
+                m = mod[o];
+            }
+            acc += m;
+        }
+        pooled[(size_t)b * C + c] = acc / (float)NT;
+    }
+}
+
+int tg_img_finish(const float* feats, const float* masks, float* mod, float* pooled, int B, int C, int S, int G,
+                  hipStream_t st) {
+    if (B <= 0 || !feats || !masks || !mod || !pooled) return SPN_ERR_ARG;
+    if (G + S > TG_MAXNT) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(tg_img_finish_kernel, dim3(B), dim3(256), 0, st, feats, masks, mod, pooled, C, G, G + S);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

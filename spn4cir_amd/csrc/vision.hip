@@ -190,9 +190,14 @@ int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const 
     SPN_TRYV(gather_rows_f32(cur, zero_idx, cls_rows, c.B, S, c.W, st));
     SPN_TRYV(layernorm_fwd(cls_rows, params + t.ln_post_g, params + t.ln_post_b, ln_cls, nullptr, nullptr, nullptr, c.B, c.W,
                            bc.eps, st));
-    if (tokens_out)   // vit.py:195: x = self.norm(x) over every token
+    if (tokens_out && c.kind == 1)   // vit.py:195: x = self.norm(x) over every token
         SPN_TRYV(layernorm_fwd(cur, params + t.ln_post_g, params + t.ln_post_b, nullptr, tokens_out, nullptr, nullptr, (int)T,
                                c.W, bc.eps, st));
+    else if (tokens_out) {           // CLIP: the transformer output itself (ln_post only touches the class token,
+        // clip/model.py:237); TG-CIR's extract_img_fea (tgcir/models.py:99-123) consumes these rows
+        he = hipMemcpyAsync(tokens_out, cur, T * c.W * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (he != hipSuccess) return (int)he;
+    }
     GemmEpilogue e;
     e.out_f32 = feats; e.ldc = c.D;
     if (c.kind == 1) e.bias = params + t.proj_b;

@@ -10,8 +10,9 @@ and enters only through the token bank `refer_bank` [N, 12, 512] and the pooled 
 
 Compute: spn_text_fwd_tokens / spn_text_bwd_tokens (text tower with ln_final of every position), bf16 MFMA GEMMs
 for text_fc and s_remain_map[0], the spn_tg_* kernels (csrc/tgcir.hip) for TokenLearner / gating / pooling, and the
-bank InfoNCE kernels.  The image-side token extractor (extract_img_fea: ViT + fc + TokenLearner) is NOT built: banks
-come from files written by the reference (`torch.save([refer_bank, target_bank])`) or are assigned directly.
+bank InfoNCE kernels.  The frozen image side (extract_img_fea / img_embed, :84-125,183-196: CLIP ViT tokens -> fc ->
+TokenLearner + masked global tokens) runs on spn_vision_fwd's token output, a bf16 GEMM and the same TokenLearner
+kernel; it serves the bank builders (:223-270), inference only.
 """
 import os
 
@@ -22,6 +23,7 @@ from . import ops
 from ._lib import check, lib
 from .ops import _p, _stream
 from .text_tower import TextTower, text_cfg_from_state_dict
+from .vision_tower import VisionTower, vision_cfg_from_state_dict
 
 S_LOCAL = 8
 
@@ -230,6 +232,16 @@ class CIRPlus(nn.Module):
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.refer_bank = None
         self._target_bank = self._target_bank_dev = None
+        # frozen image side: CLIP ViT + fc (Linear(768, 512)) + TokenLearner + masks (models.py:55-75)
+        self.vision, self.img_head, self.input_dim = None, None, None
+        if "visual.proj" in sd and "visual.conv1.weight" in sd:
+            vc = vision_cfg_from_state_dict(sd)
+            self.vision = VisionTower(vc["width"], vc["layers"], vc["heads"], vc["patch"], vc["res"], vc["embed_dim"],
+                                      self.device)
+            self.vision.load_clip_state_dict(sd)
+            self.input_dim = vc["res"]
+            for key, view in self.vision.named_views().items():
+                self._register(self.backbone, "clip.visual." + key, nn.Parameter(view, requires_grad=False))
 
     @staticmethod
     def _register(root, dotted, param):
@@ -245,6 +257,13 @@ class CIRPlus(nn.Module):
         """head: dict with the keys of oracle.tgcir_head.HEAD_KEYS (stacked TokenLearner weights)."""
         self.head.load(head)
 
+    def load_img_head(self, ihead):
+        """Frozen image-side head: dict with fc.weight [C, Wv], fc.bias, tokenlearn.weight [S, C] (stacked Conv1d
+        kernels), tokenlearn.bias [S], masks.weight [G, C] (oracle.tgcir_head.IMG_HEAD_KEYS)."""
+        h = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in ihead.items()}
+        h["fc.weight_bf16"] = ops.cast_bf16(h["fc.weight"])
+        self.img_head = h
+
     def load_reference_state_dict(self, sd):
         """Accepts tgcir's own `state_dict()` naming (checkpoint['state_dict'], models.py:207-209)."""
         C, S = self.head.C, self.head.S
@@ -258,6 +277,15 @@ class CIRPlus(nn.Module):
             head[k] = sd[k]
         self.head.load(head)
         self.text.load_clip_state_dict(sd, prefix="backbone.clip.")
+        if "backbone.fc.weight" in sd:
+            self.load_img_head({"fc.weight": sd["backbone.fc.weight"], "fc.bias": sd["backbone.fc.bias"],
+                                "masks.weight": sd["backbone.masks.weight"],
+                                "tokenlearn.weight": torch.stack([sd[f"backbone.tokenlearn.tokenizers.{s}.conv.0.weight"].reshape(C)
+                                                                  for s in range(S)]),
+                                "tokenlearn.bias": torch.cat([sd[f"backbone.tokenlearn.tokenizers.{s}.conv.0.bias"].reshape(1)
+                                                              for s in range(S)])})
+            if self.vision is not None and "backbone.clip.visual.proj" in sd:
+                self.vision.load_clip_state_dict(sd, prefix="backbone.clip.visual.")
 
     def load_ckpt(self, model_path, is_origin=False):
         saved = torch.load(model_path, map_location="cpu")
@@ -286,11 +314,65 @@ class CIRPlus(nn.Module):
         self._target_bank = bank
         self._target_bank_dev = None if bank is None else ops.prepare_bank(bank.to(self.device, torch.float32))
 
-    def extract_bank_features(self, cirDataset, device, bank_path, reload_bank=False):
-        """models.py:223-250, load branch only: the image-side token extractor is not built here."""
-        if not os.path.exists(bank_path) or reload_bank:
-            raise RuntimeError("bank extraction needs TG-CIR's image tower (not built): write the bank with the reference")
-        self.refer_bank, self.target_bank = torch.load(bank_path)
+    def img_embed(self, image, return_pool_and_normalized=False):
+        """models.py:183-196: image tokens [B, 12, C] (4 masked global + 8 TokenLearner tokens); with the flag also the
+        normalised mean over the tokens (the target-bank row)."""
+        if self.vision is None or self.img_head is None:
+            raise RuntimeError("image side needs a ViT state dict (visual.*) and load_img_head() / a reference checkpoint")
+        h, C, S, G = self.img_head, self.head.C, self.head.S, self.head.G
+        with torch.no_grad():
+            feats, vt = self.vision.forward(image.to(self.device, torch.float32), return_tokens=True)
+            B, L, Wv = vt.shape
+            z = ops.gemm_nt(ops.cast_bf16(vt.view(B * L, Wv)), h["fc.weight_bf16"], bias=h["fc.bias"], out_dtype=torch.float32)
+            attn = torch.empty(B, L, S, dtype=torch.float32, device=self.device)
+            tokens = torch.empty(B, G + S, C, dtype=torch.float32, device=self.device)
+            pooled = torch.empty(B, C, dtype=torch.float32, device=self.device)
+            check(lib().spn_tg_tokenlearn_fwd(_p(z), _p(h["tokenlearn.weight"]), _p(h["tokenlearn.bias"]), _p(attn), _p(tokens),
+                                              B, L, C, S, G, _stream()), "tg_tokenlearn_fwd")
+            check(lib().spn_tg_img_finish(_p(feats), _p(h["masks.weight"]), _p(tokens), _p(pooled), B, C, S, G, _stream()),
+                  "tg_img_finish")
+            if return_pool_and_normalized:
+                return [tokens, ops.combine_l2norm_fwd(None, None, pooled)[0]]
+        return tokens
+
+    @staticmethod
+    def _image_batches(dataset, bs=32):
+        n = len(dataset)
+        for s in range(0, n, bs):
+            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
+            if items:
+                yield items
+
+    def extract_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """models.py:223-250: per-triplet reference token bank [len, 12, 512] + normalised pooled target bank."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            self.refer_bank, self.target_bank = torch.load(bank_path)
+            return
+        NT, C = self.head.NT, self.head.C
+        refer, target = torch.zeros(len(cirDataset), NT, C), torch.zeros(cirDataset.image_id, C)
+        for items in self._image_batches(cirDataset):
+            rtok, rpool = self.img_embed(torch.stack([it[0] for it in items]), True)
+            _, tpool = self.img_embed(torch.stack([it[2] for it in items]), True)
+            refer[torch.tensor([int(it[3]) for it in items])] = rtok.cpu()
+            target[torch.tensor([int(it[5]) for it in items])] = rpool.cpu()
+            target[torch.tensor([int(it[6]) for it in items])] = tpool.cpu()
+        self.refer_bank, self.target_bank = refer, target
+        if bank_path:
+            torch.save([refer, target], bank_path)
+
+    def extract_refer_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
+        """models.py:252-267 (--plus): token bank per unique image id, written to bank_path (read back by
+        load_refer_bank, as in the reference)."""
+        if bank_path and os.path.exists(bank_path) and not reload_bank:
+            return
+        refer = torch.zeros(cirDataset.image_id, self.head.NT, self.head.C)
+        for items in self._image_batches(cirDataset):
+            refer[torch.tensor([int(it[5]) for it in items])] = self.img_embed(torch.stack([it[0] for it in items])).cpu()
+            refer[torch.tensor([int(it[6]) for it in items])] = self.img_embed(torch.stack([it[2] for it in items])).cpu()
+        self.refer_bank = refer
+        if bank_path:
+            torch.save(refer, bank_path)
 
     def load_refer_bank(self, bank_path):
         self.refer_bank = torch.load(bank_path)

@@ -159,8 +159,8 @@ class VisionTower:
         self._stale = True
 
     def forward(self, image, return_tokens=False):
-        """fp32 [B, 3, res, res] (device) -> un-normalised features fp32 [B, D] (and, for the BLIP ViT, the
-        normalised token sequence [B, S, W])."""
+        """fp32 [B, 3, res, res] (device) -> un-normalised features fp32 [B, D] (and the token sequence [B, S, W]:
+        after the final norm for the BLIP ViT, the raw transformer output for CLIP - what TG-CIR's extract_img_fea reads)."""
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.res or image.shape[3] != self.res:
             raise ValueError(f"expected [B,3,{self.res},{self.res}], got {tuple(image.shape)}")
         image = image.to(self.device, torch.float32).contiguous()

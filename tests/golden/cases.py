@@ -45,6 +45,15 @@ def tgcir_weights():
     return sd, tgcir_head.synthetic_head(t["C"], 8, 4, seed=t["HEAD_SEED"])
 
 
+def tgcir_image_side():
+    """Seeded vision tower (res 32, patch 16, width 768 - TG-CIR's fc is Linear(768, 512)), image-side head, images."""
+    from oracle import clip_vision, tgcir_head
+    vsd = clip_vision.synthetic_vision_state_dict(768, 2, 16, 32, TGCIR["C"], seed=17)
+    ihead = tgcir_head.synthetic_img_head(TGCIR["C"], 768, 8, 4, seed=13)
+    images = torch.randn(5, 3, 32, 32, generator=torch.Generator().manual_seed(19))
+    return vsd, ihead, images
+
+
 def tgcir_grad_check(z, name, g, tol):
     """Compare a gradient with its stored summary: L2 norm + every SAMPLE-th element (all of it when small)."""
     g = g.detach().reshape(-1).double().cpu()

@@ -20,7 +20,7 @@ sys.path.insert(0, OUT)
 sys.path.insert(0, ROOT)
 from make_golden import REF, install_stubs  # noqa: E402
 
-from cases import TGCIR, tgcir_inputs, tgcir_weights  # noqa: E402
+from cases import TGCIR, tgcir_image_side, tgcir_inputs, tgcir_weights  # noqa: E402
 
 B, L, C, VOCAB, LAYERS, M, TAU, SAMPLE = (TGCIR[k] for k in ("B", "L", "C", "VOCAB", "LAYERS", "M", "TAU", "SAMPLE"))
 
@@ -36,6 +36,9 @@ def main():
     torch.manual_seed(0)
     tiny = CLIP(C, 32, 2, 768, 16, L, VOCAB, C, 8, LAYERS).float()     # vision side: whatever the constructor draws
     tiny.load_state_dict(text_sd, strict=False)
+    vsd, ihead, images = tgcir_image_side()
+    missing = tiny.load_state_dict(vsd, strict=False)
+    assert not [k for k in missing.unexpected_keys], missing.unexpected_keys
     clip.load = lambda name, device=None, jit=False: (tiny, None)
 
     sys.modules.pop("data_utils", None)
@@ -52,6 +55,12 @@ def main():
         bb.masks_text.weight.copy_(head["masks_text.weight"])
         model.s_remain_map[0].weight.copy_(head["s_remain_map.0.weight"]); model.s_remain_map[0].bias.copy_(head["s_remain_map.0.bias"])
         model.s_remain_map[2].weight.copy_(head["s_remain_map.2.weight"]); model.s_remain_map[2].bias.copy_(head["s_remain_map.2.bias"])
+        bb.fc.weight.copy_(ihead["fc.weight"]); bb.fc.bias.copy_(ihead["fc.bias"])
+        for s in range(8):
+            conv = bb.tokenlearn.tokenizers[s].conv[0]
+            conv.weight.copy_(ihead["tokenlearn.weight"][s].reshape(1, C, 1))
+            conv.bias.copy_(ihead["tokenlearn.bias"][s:s + 1])
+        bb.masks.weight.copy_(ihead["masks.weight"])
     ids, ref, bank, labels = tgcir_inputs()
     clip.tokenize = lambda text, *a, **k: ids.long()
     model.refer_bank = ref.clone()          # plus=True: rows picked by refer_indexs
@@ -64,7 +73,9 @@ def main():
     with torch.no_grad():
         mod = bb.extract_text_fea(["x"] * B)
         q = model.img_txt_fusion(ref, ["x"] * B)
-    out = {"loss": loss.detach().numpy(), "q": q.numpy(), "mod_token": mod.numpy()}
+        img_tokens, img_pooled = model.img_embed(images, return_pool_and_normalized=True)
+    out = {"loss": loss.detach().numpy(), "q": q.numpy(), "mod_token": mod.numpy(),
+           "img_tokens": img_tokens.numpy(), "img_pooled": img_pooled.numpy()}
 
     def put(name, g):
         g = g.detach().reshape(-1)

@@ -223,3 +223,15 @@ def test_tgcir_oracle_matches_reference(golden_dir):
         tgcir_grad_check(z, k, head[k].grad, 2e-4)
     for k, v in sd.items():
         tgcir_grad_check(z, "clip." + k, v.grad, 2e-4)
+
+
+def test_tgcir_oracle_image_side_matches_reference(golden_dir):
+    """oracle.tgcir_head.img_embed == tgcir CIRPlus.img_embed(return_pool_and_normalized=True) on CPU."""
+    import os
+    from oracle import tgcir_head
+    from cases import tgcir_image_side
+    vsd, ihead, images = tgcir_image_side()
+    z = np.load(os.path.join(golden_dir, "tgcir_step.npz"))
+    emb, pooled = tgcir_head.img_embed(vsd, ihead, images)
+    assert (emb - torch.from_numpy(z["img_tokens"])).abs().max() < 2e-5
+    assert (pooled - torch.from_numpy(z["img_pooled"])).abs().max() < 2e-6

@@ -119,3 +119,57 @@ def test_tgcir_step_matches_reference(golden_dir):
     # state-dict names follow the reference's modules
     names = dict(m.named_parameters())
     assert "backbone.clip.ln_final.weight" in names and "backbone.text_fc.weight" in names and "s_remain_map.0.weight" in names
+
+
+def test_tgcir_image_side_and_bank_builders(golden_dir, tmp_path):
+    """Frozen image side (tgcir/models.py:84-125,183-196) vs the reference's img_embed on CPU, and the bank builders
+    (:223-267) built on it: files, shapes and row placement."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cases import TGCIR, tgcir_image_side, tgcir_weights
+    from spn4cir_amd.tgcir_models import CIRPlus
+    sd, head = tgcir_weights()
+    vsd, ihead, images = tgcir_image_side()
+    full = dict(sd)
+    full.update(vsd)
+    m = CIRPlus(full, tau=TGCIR["TAU"], plus=True)
+    m.load_head(head)
+    m.load_img_head(ihead)
+    assert m.input_dim == 32
+    z = np.load(os.path.join(golden_dir, "tgcir_step.npz"))
+    tokens, pooled = m.img_embed(images, return_pool_and_normalized=True)
+    assert rel(tokens, torch.from_numpy(z["img_tokens"])) < 1e-2
+    cos = torch.nn.functional.cosine_similarity(pooled.cpu().double(), torch.from_numpy(z["img_pooled"]).double(), dim=-1)
+    assert (1 - cos).max() < 1e-3                                       # north_star gate on the embeddings
+    assert torch.equal(m.img_embed(images), tokens)
+
+    class DS:
+        image_id = 5
+        trip = [(0, 1), (2, 3), (0, 4), (4, 1)]
+
+        def __len__(self):
+            return len(self.trip)
+
+        def __getitem__(self, i):
+            r, t = self.trip[i]
+            return images[r], "cap", images[t], i, t, r, t
+
+    ds, path = DS(), str(tmp_path / "bank.pt")
+    m.extract_bank_features(ds, torch.device("cuda"), path)
+    assert m.refer_bank.shape == (4, 12, 512) and m.target_bank.shape == (5, 512)
+    for i, (r, t) in enumerate(ds.trip):
+        assert rel(m.refer_bank[i], tokens[r]) < 1e-5
+    assert rel(m.target_bank, pooled) < 1e-5
+    saved = torch.load(path)
+    assert torch.equal(saved[0], m.refer_bank) and torch.equal(saved[1], m.target_bank)
+    p2 = str(tmp_path / "refer.pt")
+    m.extract_refer_bank_features(ds, torch.device("cuda"), p2)
+    assert m.refer_bank.shape == (5, 12, 512) and rel(m.refer_bank, tokens) < 1e-5
+    m.load_refer_bank(p2)
+    # the banks drive the step: per-triplet rows of the token bank
+    m.extract_bank_features(ds, torch.device("cuda"), path)
+    ids = __import__("cases").tgcir_inputs()[0][:4]
+    m.plus = False
+    out = m.forward(ids, torch.arange(4), torch.tensor([1, 3, 4, 1]), None)
+    out["bank_loss"].backward()
+    assert torch.isfinite(out["bank_loss"])
