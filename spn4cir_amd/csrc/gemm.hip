@@ -339,7 +339,11 @@ size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2) {
 int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
             float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st) {
     // small outputs (e.g. 768x768) give the 256x256 tiling too few workgroups: v1 (128x128) is faster there
-    if (!gemm_use_v1() && (size_t)N1 * N2 >= (size_t)768 * 2304)
+    static const size_t tn2_min = [] {
+        const char* e = getenv("SPN_TN2_MIN");           // experiment knob: smallest N1*N2 routed to the 256x256 kernel
+        return e ? (size_t)atoll(e) : (size_t)768 * 2304;
+    }();
+    if (!gemm_use_v1() && (size_t)N1 * N2 >= tn2_min)
         return gemm_tn2(A, B, Kr, N1, N2, lda, ldb, C, ldc, alpha, accumulate, colsum_out, ws, ws_bytes, st);
     if (Kr <= 0 || N1 <= 0 || N2 <= 0) return SPN_ERR_ARG;
     if (N1 % 8 || N2 % 8 || lda % 8 || ldb % 8 || ldc % 4) return SPN_ERR_SHAPE;
