@@ -135,7 +135,8 @@ int spn_bank_grad_q_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const
  * targets_total count TARGETS.  The reference loops over the batch in Python with one [M,32] matmul per sample;
  * here the bank streams through LDS once per pass, the max is taken per 32-row tile and the gradient goes to the
  * arg-max row (first index on ties, as torch.max).  Same statistics / finalize contract as above; workspace from
- * spn_bank_workspace_bytes(B, n_targets * 32, D). */
+ * spn_bank_workspace_bytes(B, n_targets * 32, D).  One call addresses its bank shard with 32-bit offsets:
+ * n_targets * 32 * D * 2 bytes < 4 GiB (262 143 targets at D = 256); larger banks are split into shards (t_begin). */
 int spn_bank_stats_fwd_tokmax(const void* q_bf16, int ldq, const void* bank_bf16, const int64_t* labels, int B,
                               int n_targets, int D, int t_begin, float inv_tau, float* stats, void* ws, size_t ws_bytes,
                               void* stream);

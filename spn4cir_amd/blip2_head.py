@@ -24,6 +24,17 @@ def prepare_token_bank(target_feats):
     return out
 
 
+_MAX_SHARD_BYTES = (1 << 32) - 1
+
+
+def _shards(bank, fn):
+    """One kernel call addresses < 4 GiB of bank (32-bit buffer offsets): larger banks go through in target shards,
+    exactly as ranks would hold them (statistics merged by bank_loss_finalize, dq partials summed)."""
+    M, _, Dp = bank.shape
+    per = max(1, _MAX_SHARD_BYTES // (32 * Dp * 2) - 1)
+    return [fn(bank[t0:t0 + per], t0) for t0 in range(0, M, per)]
+
+
 class _TokMaxLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fusion_feats, temp, bank, labels):
@@ -33,8 +44,8 @@ class _TokMaxLoss(torch.autograd.Function):
         # the reference feeds already-normalised features; only the bf16 cast + padding happen here
         qb = torch.zeros(B, Dp, dtype=torch.bfloat16, device=fusion_feats.device)
         qb[:, :D] = fusion_feats.detach()
-        stats = ops.bank_stats_fwd_tokmax(qb, bank, labels, 1.0 / tau)
-        lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
+        stats = _shards(bank, lambda sh, t0: ops.bank_stats_fwd_tokmax(qb, sh, labels, 1.0 / tau, t_begin=t0))
+        lse, row, mean = ops.bank_loss_finalize(torch.stack(stats), bank.shape[0])
         ctx.st = dict(qb=qb, bank=bank, labels=labels, lse=lse, tau=tau, B=B, D=D, q=fusion_feats.detach(),
                       temp_is_tensor=torch.is_tensor(temp))
         return mean.reshape(()).clone()
@@ -42,8 +53,11 @@ class _TokMaxLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         st = ctx.st
-        dq = ops.bank_grad_q_tokmax(st["qb"], st["bank"], st["labels"], 1.0 / st["tau"], st["lse"],
-                                    float(grad_out) / st["B"], targets_total=st["bank"].shape[0])[:, :st["D"]].contiguous()
+        M = st["bank"].shape[0]
+        parts = _shards(st["bank"], lambda sh, t0: ops.bank_grad_q_tokmax(st["qb"], sh, st["labels"], 1.0 / st["tau"], st["lse"],
+                                                                           float(grad_out) / st["B"], targets_total=M, t_begin=t0))
+        dq = parts[0] if len(parts) == 1 else torch.stack(parts).sum(0)
+        dq = dq[:, :st["D"]].contiguous()
         # logits = s / temp  =>  dL/dtemp = -(1/temp) * sum_b <q_b, dL/dq_b>   (the max picks rows, it has no scale)
         dtemp = (-(st["q"] * dq).sum() / st["tau"]).reshape(()) if st["temp_is_tensor"] else None
         return dq, dtemp, None, None

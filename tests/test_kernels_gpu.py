@@ -358,6 +358,17 @@ def test_bank_tokmax_ties_and_head(ops):
     assert abs(out["loss_qtc"].item() - ref.item()) < 2e-4
     assert rel_err(qg.grad, qd.grad) < 1.5e-2
     assert abs(tg.grad.item() - td.grad.item()) < 2e-2 * abs(td.grad.item()) + 1e-4
+    # banks beyond one call's 4 GiB window go through in target shards: force 3 shards and expect the same numbers
+    old = blip2_head._MAX_SHARD_BYTES
+    try:
+        blip2_head._MAX_SHARD_BYTES = 15 * 32 * 256 * 2
+        q2 = q.cuda().requires_grad_(True)
+        out2 = blip2_head.loss_qtc(q2, blip2_head.prepare_token_bank(bank), labels, temp)
+        out2["loss_qtc"].backward()
+    finally:
+        blip2_head._MAX_SHARD_BYTES = old
+    assert abs(out2["loss_qtc"].item() - out["loss_qtc"].item()) < 1e-5
+    assert rel_err(q2.grad, qg.grad) < 1e-5
 
 
 @pytest.mark.parametrize("B,M,D,tau", [(32, 4099, 512, 0.02), (16, 100000, 768, 0.02), (256, 40000, 768, 0.02),
