@@ -56,6 +56,13 @@ int spn_gemm_nt_dact(const void* A, const void* B, int M, int N, int K, int lda,
 int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
                 float alpha, int accumulate, float* colsum_out, void* ws, size_t ws_bytes, void* stream);
 size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2);
+/* Two such products over the same Kr rows in one launch (dense operands: lda = N1, ldb = N2, ldc = N2; both outputs
+ * overwritten): a weight gradient with a small output (the W x W out-projection) shares the grid of a larger one (the
+ * 3W x W qkv projection) instead of under-filling the chip in a launch of its own. */
+int spn_gemm_tn_pair(const void* A1, const void* B1, int N1a, int N2a, float* C1, float* colsum1, const void* A2,
+                     const void* B2, int N1b, int N2b, float* C2, float* colsum2, int Kr, void* ws, size_t ws_bytes,
+                     void* stream);
+size_t spn_gemm_tn_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b);
 
 /* ---------------------------------------------------------------- elementwise / reductions */
 int spn_cast_f32_bf16(const float* x, void* y_bf16, size_t n, void* stream);

@@ -55,6 +55,18 @@ int spn_gemm_tn(const void* A, const void* B, int Kr, int N1, int N2, int lda, i
 
 size_t spn_gemm_tn_workspace_bytes(int Kr, int N1, int N2) { return gemm_tn_workspace_bytes(Kr, N1, N2); }
 
+int spn_gemm_tn_pair(const void* A1, const void* B1, int N1a, int N2a, float* C1, float* colsum1, const void* A2,
+                     const void* B2, int N1b, int N2b, float* C2, float* colsum2, int Kr, void* ws, size_t ws_bytes,
+                     void* stream) {
+    if (!A1 || !B1 || !C1 || !A2 || !B2 || !C2 || !ws) return SPN_ERR_ARG;
+    return gemm_tn2_pair(CBF(A1), CBF(B1), N1a, N2a, N1a, N2a, C1, N2a, colsum1, CBF(A2), CBF(B2), N1b, N2b, N1b, N2b, C2, N2b,
+                         colsum2, Kr, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_gemm_tn_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b) {
+    return gemm_tn2_pair_workspace_bytes(Kr, N1a, N2a, N1b, N2b);
+}
+
 int spn_cast_f32_bf16(const float* x, void* y, size_t n, void* stream) { return cast_f32_bf16(x, BF(y), n, ST(stream)); }
 
 int spn_cast_transpose_f32_bf16(const float* x, void* y, void* yt, int rows, int cols, void* stream) {

@@ -645,13 +645,36 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* sT, int cb, int kk, int l
     return u.v;
 }
 
+// Optional second problem of the same launch (same Kr, same split): its tiles follow the first problem's in the grid.
+// A weight gradient with a small output (768 x 768: 9 tiles) cannot fill the chip on its own even with split-K, but it
+// rides along with a larger one at no extra launch: tiles1 = INT_MAX when there is none.
+struct TnSecond {
+    const bf16_t* A; const bf16_t* B;
+    int N1, N2, lda, ldb;
+    float* C; int ldc;
+    size_t split_stride;
+    float* colsum_out;
+    int tiles1;
+};
+
 template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A,
-                                                                            const bf16_t* __restrict__ B, int Kr,
-                                                                            int N1, int N2, int lda, int ldb,
-                                                                            float* __restrict__ C, int ldc,
-                                                                            size_t split_stride, int k_chunk,
-                                                                            float* __restrict__ colsum_out) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A_,
+                                                                            const bf16_t* __restrict__ B_, int Kr,
+                                                                            int N1_, int N2_, int lda_, int ldb_,
+                                                                            float* __restrict__ C_, int ldc_,
+                                                                            size_t split_stride_, int k_chunk,
+                                                                            float* __restrict__ colsum_out_,
+                                                                            TnSecond g2) {
+    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const bool second = bid_all >= g2.tiles1;              // block-uniform
+    const bf16_t* A = second ? g2.A : A_;
+    const bf16_t* B = second ? g2.B : B_;
+    const int N1 = second ? g2.N1 : N1_, N2 = second ? g2.N2 : N2_;
+    const int lda = second ? g2.lda : lda_, ldb = second ? g2.ldb : ldb_;
+    float* C = second ? g2.C : C_;
+    const int ldc = second ? g2.ldc : ldc_;
+    const size_t split_stride = second ? g2.split_stride : split_stride_;
+    float* colsum_out = second ? g2.colsum_out : colsum_out_;
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
     const int tiles_n = (N2 + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = second ? bid_all - g2.tiles1 : bid_all;
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     const int kb = blockIdx.y * k_chunk;
     const int ke = min(Kr, kb + k_chunk);
@@ -881,7 +904,7 @@ size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2) {
 
 template <int BM, int BN, int WM, int WN, int STAGES, int SCHED = 0>
 static int launch_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* ws, int splits,
-                      int k_chunk, float* cs_ws, hipStream_t st) {
+                      int k_chunk, float* cs_ws, hipStream_t st, const TnSecond* second = nullptr) {
     constexpr int LDS = STAGES * (BM + BN) * 128;
     auto kern = gemm_tn2_kernel<BM, BN, WM, WN, STAGES, SCHED>;
     static bool attr_set = false;
@@ -890,9 +913,16 @@ static int launch_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    int tiles = ((N1 + BM - 1) / BM) * ((N2 + BN - 1) / BN);
+    TnSecond g2{};
+    g2.tiles1 = INT32_MAX;
+    if (second) {
+        g2 = *second;
+        g2.tiles1 = tiles;
+        tiles += ((g2.N1 + BM - 1) / BM) * ((g2.N2 + BN - 1) / BN);
+    }
     hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(WM * WN * 64), LDS, st, A, B, Kr, N1, N2, lda, ldb, ws, N2,
-                       (size_t)N1 * N2, k_chunk, cs_ws);
+                       (size_t)N1 * N2, k_chunk, cs_ws, g2);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -931,6 +961,75 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
                        (const float*)cs_ws, colsum_out);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
+}
+
+// Two weight gradients over the same Kr rows in ONE launch (+ one reduction each): C1 = A1^T B1, C2 = A2^T B2, both
+// overwritten (alpha 1), optional column sums.  The split count is chosen for the tiles of both, so the small problem
+// costs its share of a full wave of blocks instead of a launch of its own (768x768 next to 2304x768: 146 -> 125 us).
+size_t gemm_tn2_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b) {
+    const int tiles = ((N1a + 255) / 256) * ((N2a + 255) / 256) + ((N1b + 255) / 256) * ((N2b + 255) / 256);
+    const int ktiles = (Kr + BK2 - 1) / BK2;
+    int s = 256 / tiles;
+    const int max_s = (ktiles + 5) / 6;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    return (size_t)s * ((size_t)N1a * N2a + (size_t)N1b * N2b + N1a + N1b) * sizeof(float);
+}
+
+// pairing pays when the larger problem runs on this kernel anyway (gemm_tn's routing rule) and nothing was overridden;
+// SPN_TN_PAIR=0 keeps the two launches (A/B switch)
+bool gemm_tn2_pair_ok(int N1a, int N2a) {
+    static const bool off = [] {
+        const char* e = getenv("SPN_TN_PAIR");
+        return e && e[0] == '0';
+    }();
+    return !off && gemm_cfg() == 3 && tn_phased() && (size_t)N1a * N2a >= (size_t)768 * 2304;
+}
+
+int gemm_tn2_pair(const bf16_t* A1, const bf16_t* B1, int N1a, int N2a, int lda1, int ldb1, float* C1, int ldc1, float* cs1,
+                  const bf16_t* A2, const bf16_t* B2, int N1b, int N2b, int lda2, int ldb2, float* C2, int ldc2, float* cs2,
+                  int Kr, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (Kr <= 0 || N1a <= 0 || N2a <= 0 || N1b <= 0 || N2b <= 0) return SPN_ERR_ARG;
+    if (N1a % 8 || N2a % 8 || N1b % 8 || N2b % 8 || lda1 % 8 || ldb1 % 8 || lda2 % 8 || ldb2 % 8 || ldc1 % 4 || ldc2 % 4)
+        return SPN_ERR_SHAPE;
+    const uint64_t lim = 1ull << 32;
+    if ((uint64_t)Kr * lda1 * 2 >= lim || (uint64_t)Kr * ldb1 * 2 >= lim || (uint64_t)Kr * lda2 * 2 >= lim ||
+        (uint64_t)Kr * ldb2 * 2 >= lim)
+        return SPN_ERR_SHAPE;
+    if (gemm_cfg() != 3 || !tn_phased()) return SPN_ERR_ARG;          // only the default 256x256 staggered kernel is grouped
+    if (ws_bytes < gemm_tn2_pair_workspace_bytes(Kr, N1a, N2a, N1b, N2b)) return SPN_ERR_WORKSPACE;
+    const int tiles = ((N1a + 255) / 256) * ((N2a + 255) / 256) + ((N1b + 255) / 256) * ((N2b + 255) / 256);
+    const int ktiles = (Kr + BK2 - 1) / BK2;
+    int splits = 256 / tiles;
+    const int max_s = (ktiles + 5) / 6;
+    if (splits > max_s) splits = max_s;
+    if (splits < 1) splits = 1;
+    const int k_chunk = ((ktiles + splits - 1) / splits) * BK2;
+    splits = (Kr + k_chunk - 1) / k_chunk;
+    float* p1 = ws;
+    float* p2 = p1 + (size_t)splits * N1a * N2a;
+    float* c1 = p2 + (size_t)splits * N1b * N2b;
+    float* c2 = c1 + (size_t)splits * N1a;
+    TnSecond g2{};
+    g2.A = A2; g2.B = B2; g2.N1 = N1b; g2.N2 = N2b; g2.lda = lda2; g2.ldb = ldb2;
+    g2.C = p2; g2.ldc = N2b; g2.split_stride = (size_t)N1b * N2b; g2.colsum_out = cs2 ? c2 : nullptr;
+    int rc;
+    {
+        ProfScope prof(PK_GEMM_TN, 2.0 * Kr * ((double)N1a * N2a + (double)N1b * N2b), st);
+        rc = launch_tn2<256, 256, 2, 4, 2, 2>(A1, B1, Kr, N1a, N2a, lda1, ldb1, p1, splits, k_chunk, cs1 ? c1 : nullptr, st, &g2);
+    }
+    if (rc) return rc;
+    auto reduce = [&](const float* part, int N1, int N2, float* C, int ldc, const float* csw, float* cs) -> int {
+        const size_t total = (size_t)N1 * (N2 / 4);
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        if ((size_t)blocks * 256 < (size_t)N1) return SPN_ERR_SHAPE;
+        hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(blocks), dim3(256), 0, st, part, splits, N1, N2, C, ldc, 1.0f, 0, csw, cs);
+        SPN_CHECK_LAUNCH();
+        return SPN_OK;
+    };
+    rc = reduce(p1, N1a, N2a, C1, ldc1, cs1 ? c1 : nullptr, cs1);
+    if (rc) return rc;
+    return reduce(p2, N1b, N2b, C2, ldc2, cs2 ? c2 : nullptr, cs2);
 }
 
 }  // namespace spn

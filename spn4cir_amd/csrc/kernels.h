@@ -46,6 +46,11 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
                     float inv_tau, int m_begin, float* partial, hipStream_t st);
 int gemm_bank_stats_tiles(int M);
+bool gemm_tn2_pair_ok(int N1a, int N2a);
+size_t gemm_tn2_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b);
+int gemm_tn2_pair(const bf16_t* A1, const bf16_t* B1, int N1a, int N2a, int lda1, int ldb1, float* C1, int ldc1, float* cs1,
+                  const bf16_t* A2, const bf16_t* B2, int N1b, int N2b, int lda2, int ldb2, float* C2, int ldc2, float* cs2,
+                  int Kr, float* ws, size_t ws_bytes, hipStream_t st);
 int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
              float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);

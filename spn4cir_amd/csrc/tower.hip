@@ -146,6 +146,7 @@ size_t block_op_ws_bytes(const BlockCfg& c) {
     mx(gemm_tn_workspace_bytes(T, 4 * W, W));
     mx(gemm_tn_workspace_bytes(T, W, W));
     mx(gemm_tn_workspace_bytes(T, 3 * W, W));
+    mx(gemm_tn2_pair_workspace_bytes(T, 3 * W, W, W, W));
     mx(colsum_workspace_bytes(T, 4 * W));
     mx(layernorm_bwd_workspace_bytes(T, W));
     return align256(m);
@@ -247,7 +248,9 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         e.out_bf16 = dattn; e.ldc = W;
         SPN_TRY(gemm_nt(dxb_mid, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dxb_mid, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, wws, wws_bytes, sw));
+    // the out-projection's weight gradient (W x W: 9 tiles) rides along with the qkv one below when they can share a launch
+    const bool pair = !ov && gemm_tn2_pair_ok(3 * W, W);
+    if (!pair) SPN_TRY(gemm_tn(dxb_mid, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, wws, wws_bytes, sw));
     {
         AttnBwdArgs g;
         AttnArgs& a = g.f;
@@ -268,7 +271,10 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dqkv, P.w_qkv_t, T, W, 3 * W, 3 * W, 3 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, wws, wws_bytes, sw));
+    if (pair)
+        SPN_TRY(gemm_tn2_pair(dqkv, A.h1, 3 * W, W, 3 * W, W, G.w_qkv, W, G.b_qkv, dxb_mid, A.attn, W, W, W, W, G.w_o, W, G.b_o,
+                              T, wws, wws_bytes, sw));
+    else SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, wws, wws_bytes, sw));
     if (ov) {                                          // LayerNorm backward rewrites dx_bf16: w_proj's GEMM must be done with it
         hipError_t e = hipStreamWaitEvent(st, ov->ev[4], 0);
         if (e != hipSuccess) return (int)e;

@@ -91,6 +91,21 @@ def gemm_tn(a, b, alpha=1.0, out=None, accumulate=False, want_colsum=False):
     return (out, cs) if want_colsum else out
 
 
+def gemm_tn_pair(a1, b1, a2, b2):
+    """(a1.T @ b1, colsum(a1), a2.T @ b2, colsum(a2)) for bf16 [Kr, N] operands sharing Kr, in one launch."""
+    for t in (a1, b1, a2, b2):
+        _req(t, torch.bfloat16, "operand")
+    Kr = a1.shape[0]
+    N1a, N2a, N1b, N2b = a1.shape[1], b1.shape[1], a2.shape[1], b2.shape[1]
+    dev = a1.device
+    c1 = torch.empty(N1a, N2a, dtype=torch.float32, device=dev); s1 = torch.empty(N1a, dtype=torch.float32, device=dev)
+    c2 = torch.empty(N1b, N2b, dtype=torch.float32, device=dev); s2 = torch.empty(N1b, dtype=torch.float32, device=dev)
+    ws = workspace(lib().spn_gemm_tn_pair_workspace_bytes(Kr, N1a, N2a, N1b, N2b), dev)
+    check(lib().spn_gemm_tn_pair(_p(a1), _p(b1), N1a, N2a, _p(c1), _p(s1), _p(a2), _p(b2), N1b, N2b, _p(c2), _p(s2), Kr,
+                                 _p(ws), ws.numel(), _stream()), "gemm_tn_pair")
+    return c1, s1, c2, s2
+
+
 # ------------------------------------------------------------------------- elementwise
 def cast_bf16(x):
     _req(x, torch.float32, "x")

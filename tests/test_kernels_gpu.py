@@ -107,6 +107,23 @@ def test_gemm_tn(ops, Kr, N1, N2):
     assert rel_err(acc, base.double() + 0.5 * ref) < 3e-5
 
 
+@pytest.mark.parametrize("Kr,sa,sb", [(19712, (2304, 768), (768, 768)), (1000, (512, 256), (256, 264)),
+                                      (70, (256, 256), (8, 520)), (4099, (768, 3072), (128, 64))])
+def test_gemm_tn_pair(ops, Kr, sa, sb):
+    """Two weight-gradient products in one launch (tiles of the second follow the first's; shared split-K): each
+    must equal its own fp64 product, ragged tiles and split boundaries included."""
+    g = torch.Generator().manual_seed(Kr)
+    a1, b1 = bf(torch.randn(Kr, sa[0], generator=g)), bf(torch.randn(Kr, sa[1], generator=g))
+    a2, b2 = bf(torch.randn(Kr, sb[0], generator=g)), bf(torch.randn(Kr, sb[1], generator=g))
+    c1, s1, c2, s2 = ops.gemm_tn_pair(dev(a1), dev(b1), dev(a2), dev(b2))
+    assert rel_err(c1, a1.double().t() @ b1.double()) < 3e-5
+    assert rel_err(c2, a2.double().t() @ b2.double()) < 3e-5
+    assert rel_err(s1, a1.double().sum(0)) < 3e-5 and rel_err(s2, a2.double().sum(0)) < 3e-5
+    # canary: same inputs again give the same bits (no cross-problem race on the shared workspace)
+    d1, t1, d2, t2 = ops.gemm_tn_pair(dev(a1), dev(b1), dev(a2), dev(b2))
+    assert torch.equal(c1, d1) and torch.equal(c2, d2) and torch.equal(s1, t1) and torch.equal(s2, t2)
+
+
 def test_gemm_tn_asymmetric(ops):
     # one-hot A picks single rows of B: exact, catches any row/column permutation in the
     # transpose-read fragments
