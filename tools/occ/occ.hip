@@ -1,0 +1,18 @@
+// Resident blocks per CU as a function of dynamic LDS bytes (320-thread blocks): finds the LDS allocation granule.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+extern "C" __global__ __launch_bounds__(320) void k(float* p) {
+    extern __shared__ float s[];
+    s[threadIdx.x] = p[threadIdx.x];
+    __syncthreads();
+    p[threadIdx.x] = s[(threadIdx.x + 1) % 320];
+}
+int main() {
+    for (int lds : {30464, 32768, 40960, 52224, 53248, 53760, 54096, 54272, 54432, 54613, 54784, 65536, 77760, 81920}) {
+        int n = 0;
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 320, lds);
+        printf("lds %6d -> %d blocks/CU (%s)\n", lds, n, hipGetErrorString(e));
+    }
+    return 0;
+}
