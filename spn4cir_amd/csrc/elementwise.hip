@@ -302,19 +302,28 @@ int embed_bwd_all(const int32_t* ids, const float* dx, float* dtok, float* dpos,
 }
 
 // eot[b] = argmax_l ids[b,l] (first maximum), clip/model.py:356
-__global__ void eot_argmax_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ eot, int B, int L) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per caption: lanes take positions lane, lane+64, ...; (value, position) pairs are merged with the FIRST
+// maximum winning (a serial loop per thread chained L dependent loads: 24 us at L = 77)
+__global__ __launch_bounds__(256) void eot_argmax_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ eot, int B,
+                                                        int L) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    int best = ids[(size_t)b * L], bi = 0;
-    for (int l = 1; l < L; ++l) {
+    int best = INT32_MIN, bi = INT32_MAX;
+    for (int l = lane; l < L; l += 64) {
         const int v = ids[(size_t)b * L + l];
-        if (v > best) { best = v; bi = l; }
+        if (v > best) { best = v; bi = l; }              // ascending l within a lane: strict > keeps the first
     }
-    eot[b] = bi;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int v2 = __shfl_xor(best, off, 64), i2 = __shfl_xor(bi, off, 64);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if (lane == 0) eot[b] = bi;
 }
 
 int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st) {
-    hipLaunchKernelGGL(eot_argmax_kernel, dim3((B + 63) / 64), dim3(64), 0, st, ids, eot, B, L);
+    hipLaunchKernelGGL(eot_argmax_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ids, eot, B, L);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -160,3 +160,27 @@ def test_packed_rows_ragged_cases(B, L, lens):
     # and against the CPU oracle's features (bf16 GEMM operands vs fp32: north_star's 1e-3 cosine)
     ref = clip_text.encode_text(sd, ids_host.long())
     assert (1 - cosine(f_pack.cpu(), ref)).max() < 1e-3
+
+
+def test_eot_is_first_maximum_and_long_rows():
+    """clip/model.py:356 pools x[arange, ids.argmax(-1)]: the FIRST maximum on ties; positions beyond one wave's 64
+    lanes included (the argmax kernel merges (value, position) pairs across lanes)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import clip_text
+    from spn4cir_amd.text_tower import TextTower
+    W, H, layers, D, vocab, L = 128, 2, 1, 64, 600, 77
+    sd = clip_text.synthetic_text_state_dict(width=W, layers=layers, embed_dim=D, vocab=vocab, ctx=L, seed=8)
+    t = TextTower(W, layers, H, D, vocab, L, "cuda")
+    t.load_clip_state_dict(sd)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(1, vocab - 2, (6, L), generator=g, dtype=torch.int32)
+    ids[0, 5] = ids[0, 9] = vocab - 1            # tie: position 5 wins
+    ids[1, 70] = ids[1, 3] = vocab - 1           # tie across the lane / lane+64 split: position 3 wins
+    ids[2, 76] = vocab - 1                       # last position (lane 12 of the second pass)
+    ids[3, 64] = ids[3, 65] = vocab - 1          # tie inside the second pass
+    ids[4, 0] = vocab - 1                        # first position
+    ids[5, 63] = ids[5, 64] = vocab - 1          # tie across the pass boundary: 63 wins
+    feats = t.forward(ids.cuda())
+    ref = clip_text.encode_text(sd, ids.long())
+    assert (1 - cosine(feats.cpu(), ref)).max() < 1e-3
