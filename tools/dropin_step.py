@@ -1,0 +1,37 @@
+"""The reference's own loop body (train_negplus.py:107-123) on the drop-in CIRPlus: captions as strings (host BPE every
+step), autograd backward, torch.optim.AdamW on the exposed parameters, GradScaler as in the reference - vs the fused
+Stage2Trainer path that bench.py times.  Config 2 shape."""
+import random, sys, time, torch
+sys.path.insert(0, ".")
+from spn4cir_amd import synthetic
+from spn4cir_amd.models import CIRPlus
+
+def main():
+    B, M = 256, 40000
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    model = CIRPlus(sd, tau=0.02, device=torch.device("cuda"), plus=True)
+    target, refer = synthetic.banks(M, D, seed=2)
+    model.refer_bank, model.target_bank = refer, target
+    random.seed(0)
+    words = ("is red and has long sleeves with a floral pattern shorter more colorful dress shirt top blue striped darker "
+             "lighter green collar buttons casual formal the same but different style material lace silk cotton").split()
+    caps = [" ".join(random.choice(words) for _ in range(random.randint(5, 30))) for _ in range(B)]
+    ridx, labels = synthetic.triplet_indices(B, M, seed=4)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, betas=(0.9, 0.999), eps=1e-7)
+    scaler = torch.cuda.amp.GradScaler()
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.forward(caps, None, labels, ridx)["bank_loss"]
+        scaler.scale(loss).backward()
+        scaler.step(opt); scaler.update()
+        model.parameters_changed()
+        return loss
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    n = 10
+    for _ in range(n): loss = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+    print(f"drop-in loop: {dt*1e3:.2f} ms/step  {B/dt:.0f} triplets/s  loss {loss.item():.4f}")
+
+main()
