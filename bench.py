@@ -99,7 +99,16 @@ def cpu_baseline(args, sd, target, refer):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n if n else warm      # a pathological host: report the warm-up step
-    return {"value": round(B / dt, 3), "unit": "triplets/sec", "cores": threads, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(B / dt, 3), "unit": "triplets/sec", "cores": threads, "kind": "port", "cpu_model": cpu_model,
             "sample": f"{max(n, 1)} steps of B={B} at the config-2 shape (ViT-L/14 text tower, M={target.shape[0]}, "
                       f"D={target.shape[1]}, fp32, torch CPU kernels, {threads} threads of {avail} available cores), "
                       f"after 1 warm-up step",
