@@ -64,3 +64,40 @@ def tgcir_grad_check(z, name, g, tol):
     floor = gn * (got.numel() / max(1, g.numel())) ** 0.5          # expected norm of the sample
     err = (got - ref).norm().item()
     assert err <= tol * max(ref.norm().item(), floor) + 1e-12, (name, err, ref.norm().item())
+
+
+# ----------------------------------------------------------------------- fusion-style validation (valfusion.npz)
+def valfusion_inputs():
+    """Synthetic token gallery [NG, 12, 512] (the reference hard-codes the 512-wide feature), its pooled + normalised
+    form, stub query features and the FashionIQ / CIRR rows; regenerated from seeds on both sides, only the metrics are
+    stored."""
+    g = torch.Generator().manual_seed(23)
+    D, NG, NQ, T = 512, 260, 90, 12
+    tokens = torch.randn(NG, T, D, generator=g)
+    pooled = torch.nn.functional.normalize(tokens.mean(dim=1), dim=-1)
+    names = [f"img{i:04d}" for i in range(NG)]
+    ref_i = torch.randint(0, NG, (NQ,), generator=g)
+    tgt_i = (ref_i + 1 + torch.randint(0, NG - 1, (NQ,), generator=g)) % NG
+    q = 0.045 * torch.randn(NQ, D, generator=g) + pooled[tgt_i] * torch.rand(NQ, 1, generator=g) * 0.6
+    fiq_rows = [(names[int(r)], names[int(t)], [f"cap a {i}.", f"cap b {i}?"]) for i, (r, t) in enumerate(zip(ref_i, tgt_i))]
+    members = []
+    for r, t in zip(ref_i, tgt_i):
+        pool = [int(x) for x in torch.randperm(NG, generator=g)[:12] if int(x) not in (int(r), int(t))][:5]
+        members.append([names[j] for j in pool + [int(t)]])
+    cirr_rows = [(names[int(r)], names[int(t)], f"cap {i}", members[i]) for i, (r, t) in enumerate(zip(ref_i, tgt_i))]
+    return tokens, pooled, names, q, fiq_rows, cirr_rows
+
+
+class StubFusion:
+    """img_txt_fusion returns pre-made query rows in call order, nudged by the gathered reference tokens (so a wrong
+    gather shows)."""
+
+    def __init__(self, q):
+        self.q, self.pos = q, 0
+
+    def img_txt_fusion(self, ref_token, mod):
+        n = len(mod)
+        assert ref_token.shape[0] == n and ref_token.dim() == 3
+        out = self.q[self.pos:self.pos + n].to(ref_token.device) + 0.05 * ref_token.mean(dim=1)
+        self.pos += n
+        return out

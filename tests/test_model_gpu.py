@@ -389,3 +389,34 @@ def test_cirplus_with_resnet_image_tower(golden_dir):
     out = model.encode_image(torch.from_numpy(zr["image"]).cuda()).cpu()
     ref = torch.from_numpy(zr["image_feats"])
     assert (out - ref).abs().max() < 1e-4 * ref.abs().max()
+
+
+def test_fusion_validation_matches_reference(golden_dir):
+    """spn4cir_amd.validate_fusion vs tgcir/validate.py (= blip4cir/validate.py) on a synthetic token gallery: same
+    FashionIQ / CIRR metrics (reference kept in the FashionIQ ranking, dropped in CIRR; capitalised caption join)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cases import StubFusion, valfusion_inputs
+    from spn4cir_amd import validate_fusion as vf
+    z = np.load(os.path.join(golden_dir, "valfusion.npz"))
+    tokens, pooled, names, q, fiq_rows, cirr_rows = valfusion_inputs()
+    r10, r50 = vf.compute_fiq_val_metrics(fiq_rows, StubFusion(q), tokens, pooled, names)
+    assert abs(r10 - float(z["fiq"][0])) < 1e-4 and abs(r50 - float(z["fiq"][1])) < 1e-4
+    cirr = vf.compute_cirr_val_metrics(cirr_rows, StubFusion(q), tokens, pooled, names)
+    assert np.allclose(np.array(cirr), z["cirr"], atol=1e-4)
+
+    class Blip(StubFusion):                      # blip4cir's call shape: (r_image_embeds, t_image_embeds, text)
+        def img_txt_fusion(self, r, t, text, train=False):
+            assert t is None
+            return StubFusion.img_txt_fusion(self, r, text)
+    r10b, r50b = vf.compute_fiq_val_metrics(fiq_rows, Blip(q), tokens, pooled, names)
+    assert (r10b, r50b) == (r10, r50)
+    # the capitalised join reaches the model (blip4cir/validate.py:92-94)
+    seen = []
+
+    class Spy(StubFusion):
+        def img_txt_fusion(self, r, mod):
+            seen.extend(mod)
+            return StubFusion.img_txt_fusion(self, r, mod)
+    vf.generate_fiq_val_predictions(Spy(q), fiq_rows[:2], names, tokens)
+    assert seen == ["Cap a 0 and cap b 0", "Cap a 1 and cap b 1"]
