@@ -18,6 +18,23 @@ def extract_index_features(dataset, model, device=torch.device("cuda")):
     return torch.vstack(feats), names
 
 
+def extract_index_features_fusion(dataset, model, device=torch.device("cuda")):
+    """tgcir/utils.py:24-51 (= blip4cir/utils.py): -> (token features [N, T, C] on the CPU, pooled + normalised features
+    [N, C] on the device, names) from model.img_embed(images, return_pool_and_normalized=True)."""
+    toks, pooled, names = [], [], []
+    n = len(dataset)
+    for s in range(0, n, 32):
+        items = [dataset[i] for i in range(s, min(n, s + 32))]
+        items = [it for it in items if it is not None]
+        if not items:
+            continue
+        names.extend(it[0] for it in items)
+        t, p = model.img_embed(torch.stack([it[1] for it in items]), return_pool_and_normalized=True)
+        toks.append(t.cpu())
+        pooled.append(p)
+    return torch.vstack(toks), torch.vstack(pooled), names
+
+
 def save_model(name, cur_epoch, model_to_save, training_path):
     """utils.py:53-67: {'epoch', 'state_dict'} at <training_path>/<name>.pt"""
     path = Path(training_path)

@@ -142,6 +142,10 @@ def test_tgcir_image_side_and_bank_builders(golden_dir, tmp_path):
     cos = torch.nn.functional.cosine_similarity(pooled.cpu().double(), torch.from_numpy(z["img_pooled"]).double(), dim=-1)
     assert (1 - cos).max() < 1e-3                                       # north_star gate on the embeddings
     assert torch.equal(m.img_embed(images), tokens)
+    from spn4cir_amd.utils import extract_index_features_fusion
+    feats, feats_p, names = extract_index_features_fusion([(f"n{i}", images[i]) for i in range(5)], m)
+    assert names == [f"n{i}" for i in range(5)] and not feats.is_cuda and feats_p.is_cuda
+    assert torch.equal(feats, tokens.cpu()) and torch.equal(feats_p, pooled)
 
     class DS:
         image_id = 5
