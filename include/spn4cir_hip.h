@@ -130,6 +130,10 @@ size_t spn_bank_workspace_bytes(int B, int M, int D);
  * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /
  * dq contract as the bf16 entry points above. */
 int spn_bank_quantize_fp8(const float* bank_f32, int M, int D, int Dp, void* bank_fp8, float* bank_scale, void* stream);
+/* workspace for the two fp8 calls: at B >= 128 it includes room for a bf16 expansion of the shard, made once per
+ * pass (every bank tile then serves many query tiles; the per-tile dequantisation only pays at small batches).  With
+ * only spn_bank_workspace_bytes() the calls still work and dequantise per tile. */
+size_t spn_bank_workspace_bytes_fp8(int B, int M, int D);
 int spn_bank_stats_fwd_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale,
                            const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau, float* stats, void* ws,
                            size_t ws_bytes, void* stream);

@@ -174,6 +174,7 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
 }
 
 size_t spn_bank_workspace_bytes(int B, int M, int D) { return bank_workspace_bytes(B, M, D); }
+size_t spn_bank_workspace_bytes_fp8(int B, int M, int D) { return bank_workspace_bytes_fp8(B, M, D); }
 
 int spn_bank_quantize_fp8(const float* bank, int M, int D, int Dp, void* bank_fp8, float* scale, void* stream) {
     return bank_quantize_fp8(bank, M, D, Dp, (uint8_t*)bank_fp8, scale, ST(stream));

@@ -744,9 +744,62 @@ static int bank_check(const BankArgs& a) {
     return SPN_OK;
 }
 
+// e4m3 bytes [M, D] x per-row scale -> bf16 [M, D]: at large batches (every bank tile is used by many query tiles) the
+// fp8 bank is expanded ONCE per pass into scratch and the bf16 kernels run on it - the in-kernel dequantisation of the
+// streaming path repeats per query tile (B = 256: 96 -> ~57 us forward, 115 -> ~88 us backward).
+__global__ void bank_dequant_fp8_kernel(const uint8_t* __restrict__ src, const float* __restrict__ scale,
+                                        bf16_t* __restrict__ dst, size_t n16, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 16;
+        const float sc = scale[e / D];
+        const u32x4 v = *(const u32x4*)(src + e);
+        bf16x8 o[2];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[d], false);
+            const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[d], true);
+            o[d >> 1][(d & 1) * 4 + 0] = f2bf(lo[0] * sc);
+            o[d >> 1][(d & 1) * 4 + 1] = f2bf(lo[1] * sc);
+            o[d >> 1][(d & 1) * 4 + 2] = f2bf(hi[0] * sc);
+            o[d >> 1][(d & 1) * 4 + 3] = f2bf(hi[1] * sc);
+        }
+        *(bf16x8*)(dst + e) = o[0];
+        *(bf16x8*)(dst + e + 8) = o[1];
+    }
+}
+
+static constexpr int FP8_EXPAND_MIN_B = 128;
+
+size_t bank_workspace_bytes_fp8(int B, int M, int D) {
+    size_t b = (bank_workspace_bytes(B, M, D) + 255) & ~(size_t)255;
+    if (B >= FP8_EXPAND_MIN_B) b += (size_t)M * D * 2;
+    return b;
+}
+
+// -> true (and *out filled) when the call should run on an expanded bf16 copy placed behind the regular workspace
+static bool bank_expand_fp8(const BankArgs& a, float* ws, size_t ws_bytes, BankArgs* out, size_t* base, hipStream_t st) {
+    if (!a.bank_scale || a.group || a.B < FP8_EXPAND_MIN_B || a.D % 16) return false;
+    *base = (bank_workspace_bytes(a.B, a.M, a.D) + 255) & ~(size_t)255;
+    if (ws_bytes < *base + (size_t)a.M * a.D * 2) return false;
+    bf16_t* deq = (bf16_t*)((char*)ws + *base);
+    const size_t n16 = (size_t)a.M * a.D / 16;
+    const int blocks = (int)((n16 + 255) / 256 > 4096 ? 4096 : (n16 + 255) / 256);
+    hipLaunchKernelGGL(bank_dequant_fp8_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t*)a.bank, a.bank_scale, deq, n16,
+                       a.D);
+    *out = a;
+    out->bank = deq;
+    out->bank_scale = nullptr;
+    return true;
+}
+
 int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st) {
     int rc = bank_check(a);
     if (rc) return rc;
+    {
+        BankArgs b;
+        size_t base;
+        if (bank_expand_fp8(a, ws, ws_bytes, &b, &base, st)) return bank_stats_fwd(b, stats, ws, base, st);
+    }
     // Large batches: the logits pass as a 256x256-tile GEMM with a statistics epilogue (the bank is read once, the
     // queries come from L2); the streaming kernel below re-reads every bank tile once per 32 queries, which is the
     // right trade only while B is small (8-way data parallel: 32 per GPU).  SPN_BANK_GEMM=0 forces streaming.
@@ -795,6 +848,12 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     int rc = bank_check(a);
     if (rc) return rc;
     if (!row_lse || !dq || M_total <= 0) return SPN_ERR_ARG;
+    {
+        BankArgs b;
+        size_t base;
+        if (bank_expand_fp8(a, ws, ws_bytes, &b, &base, st))
+            return bank_grad_q(b, row_lse, label_smoothing, M_total, grad_scale, dq, ws, base, st);
+    }
     const BankChunking c = bank_chunking(a.B, a.M);
     if (ws_bytes < (size_t)c.nchunks * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
     if (tokmax_wave_path(a)) {

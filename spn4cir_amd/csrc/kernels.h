@@ -161,6 +161,7 @@ int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, 
 int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
                 float* dq /*[B,D] fp32*/, float* ws, size_t ws_bytes, hipStream_t st);
 size_t bank_workspace_bytes(int B, int M, int D);
+size_t bank_workspace_bytes_fp8(int B, int M, int D);   // + room for the expanded bf16 copy at large batches
 // in-batch negatives (clip4cir/models.py:160-167): dt[j] = grad_scale * inv_tau * sum_i (softmax_i[j] - [i == j]) q[i]
 int inbatch_grad_t(const bf16_t* q, const bf16_t* t, int ldq, const float* row_lse, int B, int D, float inv_tau,
                    float grad_scale, float* dt, hipStream_t st);

@@ -252,8 +252,10 @@ def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0):
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
     stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
-    ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
-    if isinstance(bank_bf16, Fp8Bank):
+    fp8 = isinstance(bank_bf16, Fp8Bank)
+    ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
+                   "bank")
+    if fp8:
         check(lib().spn_bank_stats_fwd_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
                                            m_begin, inv_tau, _p(stats), _p(ws), ws.numel(), _stream()), "bank_stats_fwd_fp8")
         return stats
@@ -280,8 +282,10 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
     dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
-    ws = workspace(lib().spn_bank_workspace_bytes(B, M, Dp), q_bf16.device, "bank")
-    if isinstance(bank_bf16, Fp8Bank):
+    fp8 = isinstance(bank_bf16, Fp8Bank)
+    ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
+                   "bank")
+    if fp8:
         check(lib().spn_bank_grad_q_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
                                         m_begin, inv_tau, _p(row_lse), label_smoothing, M_total or M, grad_scale, _p(dq),
                                         _p(ws), ws.numel(), _stream()), "bank_grad_q_fp8")
