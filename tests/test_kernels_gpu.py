@@ -588,3 +588,41 @@ def test_output_canaries(ops):
         assert (buf[:pad] == SENT).all() and (buf[pad + N1 * N2:] == SENT).all(), ("tn", Kr, N1, N2)
         ref = x.double().t() @ y.double()
         assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 2e-3
+
+
+def test_c_abi_error_codes(ops):
+    """Boundary contract (include/spn4cir_hip.h): bad arguments come back as negative SPN_ERR_* codes - nothing throws
+    inside the library, nothing is launched - and the Python side turns them into RuntimeError with the library's text."""
+    from spn4cir_amd._lib import lib
+    L = lib()
+    a = torch.zeros(128, 96, dtype=torch.bfloat16, device="cuda")       # K = 96 is not a multiple of the 64-deep k step
+    b = torch.zeros(128, 96, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        ops.gemm_nt(a, b)
+    out = torch.zeros(128, 128, dtype=torch.float32, device="cuda")
+    p = lambda t: t.data_ptr()
+    # gemm_tn: workspace too small -> SPN_ERR_WORKSPACE (-3); null output -> an error code, not a crash
+    a2 = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda")
+    rc = L.spn_gemm_tn(p(a2), p(a2), 256, 128, 128, 128, 128, p(out), 128, 1.0, 0, None, p(out), 16, None)
+    assert rc == -3
+    # bank: D outside the supported widths -> SPN_ERR_SHAPE; B = 0 -> SPN_ERR_ARG
+    q = torch.zeros(4, 96, dtype=torch.bfloat16, device="cuda")
+    bank = torch.zeros(8, 96, dtype=torch.bfloat16, device="cuda")
+    lab = torch.zeros(4, dtype=torch.int64, device="cuda")
+    st = torch.zeros(4, 4, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    assert L.spn_bank_stats_fwd(p(q), 96, p(bank), p(lab), 4, 8, 96, 0, 50.0, p(st), p(ws), ws.numel(), None) == -2
+    q2 = torch.zeros(4, 128, dtype=torch.bfloat16, device="cuda")
+    bank2 = torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda")
+    assert L.spn_bank_stats_fwd(p(q2), 128, p(bank2), p(lab), 0, 8, 128, 0, 50.0, p(st), p(ws), ws.numel(), None) == -1
+    assert L.spn_bank_stats_fwd(p(q2), 128, p(bank2), p(lab), 4, 8, 128, 0, 50.0, None, p(ws), ws.numel(), None) == -1
+    # token-max bank: rows must come in groups of 32 per target, widths as the plain bank
+    assert L.spn_bank_stats_fwd_tokmax(p(q2), 128, p(bank2), p(lab), 4, 0, 128, 0, 14.0, p(st), p(ws), ws.numel(), None) == -1
+    # TG-CIR head: more than 640 positions / 8 local tokens only
+    z = torch.zeros(2, 4, 64, device="cuda")
+    assert L.spn_tg_tokenlearn_fwd(p(z), p(z), p(z), p(z), p(z), 2, 700, 64, 8, 4, None) == -2
+    assert L.spn_tg_tokenlearn_fwd(p(z), p(z), p(z), p(z), p(z), 2, 4, 64, 6, 4, None) == -2
+    for code, text in ((-1, "invalid argument"), (-2, "unsupported shape"), (-3, "workspace")):
+        assert text.split()[0] in L.spn_error_string(code).decode()
+    # the library is still healthy afterwards
+    assert rel_err(ops.gemm_nt(dev(bf(torch.eye(128))), dev(bf(torch.eye(128))), out_dtype=torch.float32), torch.eye(128)) < 1e-6
