@@ -420,3 +420,47 @@ def test_fusion_validation_matches_reference(golden_dir):
             return StubFusion.img_txt_fusion(self, r, mod)
     vf.generate_fiq_val_predictions(Spy(q), fiq_rows[:2], names, tokens)
     assert seen == ["Cap a 0 and cap b 0", "Cap a 1 and cap b 1"]
+
+
+def test_full_size_step_properties():
+    """BASELINE config 2 at full size (ViT-L/14 text tower, B = 256, 77 tokens, 40 000 x 768 bank) through properties
+    that do not need a full-size CPU run: batch-permutation equivariance, gradient linearity, the loss recomputed by
+    the oracle from the GPU features, and the first captions' features against the oracle tower."""
+    _need_gpu()
+    from oracle import bank_loss, clip_text
+    from spn4cir_amd import ops, synthetic
+    from spn4cir_amd.text_tower import TextTower
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
+    B, M, tau = 256, 40000, 0.02
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    t = TextTower(W, layers, heads, D, device="cuda")
+    t.load_clip_state_dict(sd)
+    ids = synthetic.token_ids(B, seed=1)
+    target, refer = synthetic.banks(M, D, seed=2)
+    ridx, labels = synthetic.triplet_indices(B, M, seed=4)
+    feats = t.forward(ids.cuda()).clone()
+    # (1) a caption's feature does not depend on its position in the batch (every row runs the same k order)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    feats_p = t.forward(ids[perm].contiguous().cuda())
+    assert torch.equal(feats_p, feats[perm.cuda()])
+    # (2) the first captions against the oracle tower at full model size (north_star: 1 - cos <= 1e-3)
+    ref4 = clip_text.encode_text(sd, ids[:4].long())
+    cos = torch.nn.functional.cosine_similarity(feats[:4].cpu().double(), ref4.double(), dim=-1)
+    assert (1 - cos).max() < 1e-3
+    # (3) loss: kernels vs the oracle applied to the same GPU features (bf16 operand rounding only)
+    t.forward(ids.cuda())
+    q, qb, inv = ops.combine_l2norm_fwd(refer.cuda(), ridx.cuda(), feats)
+    bank_b = ops.prepare_bank(target.cuda())
+    stats = ops.bank_stats_fwd(qb, bank_b, labels.cuda(), 1.0 / tau)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    ref_loss = bank_loss.bank_large_step(refer, ridx, feats.cpu(), target, labels, tau)
+    assert abs(mean.item() - ref_loss.item()) < 1e-2 * max(1.0, abs(ref_loss.item()))
+    # (4) backward is linear in the incoming gradient: doubling d(feats) doubles every parameter gradient exactly
+    #     (powers of two survive the bf16 roundings of the intermediate gradients)
+    dq = ops.bank_grad_q(qb, bank_b, labels.cuda(), 1.0 / tau, lse, 1.0 / B)[:, :D].contiguous()
+    dfe = ops.combine_l2norm_bwd(q, inv, dq)
+    g1 = t.backward(dfe).clone()
+    t.forward(ids.cuda())
+    g2 = t.backward(2.0 * dfe)
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    assert ((g2 - 2.0 * g1).norm() / (2.0 * g1).norm()).item() < 1e-6
