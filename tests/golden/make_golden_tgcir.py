@@ -93,6 +93,9 @@ def main():
             continue
         assert p.grad is not None, n
         put("clip." + n, p.grad)
+    import json
+    out["state_dict_keys"] = json.dumps({k: list(v.shape) for k, v in model.state_dict().items()
+                                         if not k.startswith("backbone.clip.visual.") and not k.startswith("backbone.image_backbone.")})
     np.savez_compressed(os.path.join(OUT, "tgcir_step.npz"), **out)
     print("loss", float(loss), "entries", len(out), "bytes", os.path.getsize(os.path.join(OUT, "tgcir_step.npz")))
 

@@ -177,3 +177,57 @@ def test_tgcir_image_side_and_bank_builders(golden_dir, tmp_path):
     out = m.forward(ids, torch.arange(4), torch.tensor([1, 3, 4, 1]), None)
     out["bank_loss"].backward()
     assert torch.isfinite(out["bank_loss"])
+
+
+def test_tgcir_reference_checkpoint_names(golden_dir, tmp_path):
+    """load_ckpt consumes the reference's own `state_dict()` naming (key list + shapes captured from tgcir CIRPlus):
+    per-head Conv1d TokenLearner weights, `backbone.clip.*`, the fusion MLP; is_origin copies the image-side
+    TokenLearner / masks into the text side (models.py:210-213)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    from cases import TGCIR, tgcir_image_side, tgcir_inputs, tgcir_weights
+    from spn4cir_amd.tgcir_models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "tgcir_step.npz"))
+    keys = json.loads(str(z["state_dict_keys"]))
+    sd, head = tgcir_weights()
+    vsd, ihead, images = tgcir_image_side()
+    g = torch.Generator().manual_seed(1)
+    ref_sd = {}
+    for k, shape in keys.items():
+        if k.startswith("backbone.clip.") and k[len("backbone.clip."):] in sd:
+            v = sd[k[len("backbone.clip."):]]
+        elif k.startswith("backbone.tokenlearn_text.tokenizers."):
+            s = int(k.split(".")[3])
+            v = head["tokenlearn_text.weight"][s].reshape(1, -1, 1) if k.endswith("weight") else head["tokenlearn_text.bias"][s:s + 1]
+        elif k.startswith("backbone.tokenlearn.tokenizers."):
+            s = int(k.split(".")[3])
+            v = ihead["tokenlearn.weight"][s].reshape(1, -1, 1) if k.endswith("weight") else ihead["tokenlearn.bias"][s:s + 1]
+        elif k in ("backbone.text_fc.weight", "backbone.text_fc.bias", "backbone.masks_text.weight"):
+            v = head[k[len("backbone."):]]
+        elif k in ("backbone.fc.weight", "backbone.fc.bias", "backbone.masks.weight"):
+            v = ihead[k[len("backbone."):]]
+        elif k.startswith("s_remain_map."):
+            v = head[k]
+        else:
+            v = torch.randn(shape, generator=g)          # unused in the second stage (t_*_map, local_weight, logit_scale)
+        assert list(v.shape) == shape, (k, list(v.shape), shape)
+        ref_sd[k] = v.clone()
+    path = str(tmp_path / "tgcir.pt")
+    torch.save({"epoch": 3, "state_dict": ref_sd}, path)
+    ids, ref, bank, labels = tgcir_inputs()
+    blank = {k: torch.zeros_like(v) if v.dtype.is_floating_point else v for k, v in sd.items()}
+    blank["ln_final.weight"] = torch.ones_like(sd["ln_final.weight"])
+    m = CIRPlus({**blank, **vsd}, tau=TGCIR["TAU"], plus=True)
+    m.load_ckpt(path)
+    m.refer_bank, m.target_bank = ref, bank
+    loss = m.forward(ids, None, labels, torch.arange(ids.shape[0]))["bank_loss"]
+    assert abs(loss.item() - float(z["loss"])) < 2e-2 * max(1.0, abs(float(z["loss"])))
+    tokens = m.img_embed(images)
+    assert rel(tokens, torch.from_numpy(z["img_tokens"])) < 1e-2        # the image-side head came with the checkpoint
+    # is_origin: text-side TokenLearner / masks <- image-side ones
+    m.load_ckpt(path, is_origin=True)
+    hv = m.head.named_views()
+    assert torch.allclose(hv["masks_text.weight"].cpu(), ihead["masks.weight"])
+    assert torch.allclose(hv["tokenlearn_text.weight"].cpu(), ihead["tokenlearn.weight"])
+    assert torch.allclose(hv["tokenlearn_text.bias"].cpu(), ihead["tokenlearn.bias"])
