@@ -69,6 +69,12 @@ def _attach(root, dotted, param):
     node.register_parameter(parts[-1], param)
 
 
+# clip/clip.py:30-40: model name -> file name of the published archive
+_CLIP_FILES = {"RN50": "RN50.pt", "RN101": "RN101.pt", "RN50x4": "RN50x4.pt", "RN50x16": "RN50x16.pt", "RN50x64": "RN50x64.pt",
+               "ViT-B/32": "ViT-B-32.pt", "ViT-B/16": "ViT-B-16.pt", "ViT-L/14": "ViT-L-14.pt",
+               "ViT-L/14@336px": "ViT-L-14-336px.pt"}
+
+
 class CIRPlus(nn.Module):
     def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
                  device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
@@ -150,10 +156,22 @@ class CIRPlus(nn.Module):
             from . import synthetic
             w, l, h, d = synthetic.CLIP_TEXT_CONFIGS[name.split(":", 1)[1]]
             return synthetic.text_state_dict(w, l, d)
-        if isinstance(name, str) and os.path.isfile(name):
-            sd = torch.load(name, map_location="cpu")
-            return sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
-        raise RuntimeError(f"Model {name} not found (expected a state-dict path, a dict or 'synthetic:<name>')")
+        path = name
+        if isinstance(name, str) and not os.path.isfile(name) and name in _CLIP_FILES:
+            # a model NAME: the file clip.load would have downloaded to ~/.cache/clip (clip/clip.py:120-121); there is
+            # no network here, so it must already be there (or under $SPN_CLIP_CACHE)
+            root = os.environ.get("SPN_CLIP_CACHE", os.path.expanduser("~/.cache/clip"))
+            path = os.path.join(root, _CLIP_FILES[name])
+        if isinstance(path, str) and os.path.isfile(path):
+            # clip/clip.py:127-137: the published files are TorchScript archives; a saved state dict is the fallback
+            try:
+                sd = torch.jit.load(path, map_location="cpu").state_dict()
+            except RuntimeError:
+                sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd) if isinstance(sd, dict) and "state_dict" in sd else sd
+            return {k: v for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+        raise RuntimeError(f"Model {name} not found (expected a CLIP file - JIT archive or state dict -, a model name whose "
+                           f"file is in ~/.cache/clip, a dict or 'synthetic:<name>')")
 
     @staticmethod
     def _input_resolution(sd):

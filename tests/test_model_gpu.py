@@ -464,3 +464,45 @@ def test_full_size_step_properties():
     g2 = t.backward(2.0 * dfe)
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
     assert ((g2 - 2.0 * g1).norm() / (2.0 * g1).norm()).item() < 1e-6
+
+
+class _Box(torch.nn.Module):
+    """Container used to build a TorchScript archive with CLIP's parameter names (the published CLIP files are such
+    archives, clip/clip.py:127-131)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+
+def test_clip_file_formats(golden_dir, tmp_path, monkeypatch):
+    """`clip_model_name` as clip.load accepts it (clip/clip.py:120-137): a TorchScript archive, a saved state dict, or a
+    model NAME whose file sits in the cache directory - all give the same model."""
+    _need_gpu()
+    from spn4cir_amd.models import CIRPlus
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    root = _Box()
+    for k, v in sd.items():
+        node, parts = root, k.split(".")
+        for p in parts[:-1]:
+            if not hasattr(node, p):
+                node.add_module(p, _Box())
+            node = getattr(node, p)
+        node.register_parameter(parts[-1], torch.nn.Parameter(v.clone(), requires_grad=False))
+    for name, val in (("input_resolution", 32), ("context_length", 77), ("vocab_size", 512)):   # clip/model.py:434-436
+        root.register_buffer(name, torch.tensor(val))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    torch.jit.script(root).save(str(cache / "ViT-B-32.pt"))
+    torch.save(sd, str(tmp_path / "sd.pt"))
+    ids = torch.from_numpy(z["ids"])[:4]
+    dev = torch.device("cuda")
+    ref = CIRPlus(sd, device=dev).encode_text(ids)
+    for spec in (str(cache / "ViT-B-32.pt"), str(tmp_path / "sd.pt")):
+        m = CIRPlus(spec, device=dev)
+        assert torch.equal(m.encode_text(ids), ref)
+        assert "input_resolution" not in m.state_dict()
+    monkeypatch.setenv("SPN_CLIP_CACHE", str(cache))
+    assert torch.equal(CIRPlus("ViT-B/32", device=dev).encode_text(ids), ref)
+    with pytest.raises(RuntimeError, match="not found"):
+        CIRPlus("ViT-L/14", device=dev)                         # named, but its file is not in the cache
