@@ -194,11 +194,8 @@ class CIRPlus(nn.Module):
             raise RuntimeError("spn4cir_amd runs on an MI355X (device='cuda'); there is no CPU path")
         if local_token_num != S_LOCAL:
             raise ValueError("the TokenLearner kernels are built for 8 local tokens (the reference default)")
-        sd = clip_model_name
-        if isinstance(sd, str):
-            if not os.path.isfile(sd):
-                raise RuntimeError(f"CLIP state dict {sd} not found (no download path offline)")
-            sd = torch.load(sd, map_location="cpu")
+        from .models import CIRPlus as _ClipCIRPlus
+        sd = _ClipCIRPlus._resolve_state_dict(clip_model_name)     # dict, JIT archive / state-dict file, or cached model name
         c = text_cfg_from_state_dict(sd)
         if c["embed_dim"] != c["width"]:
             raise ValueError("TG-CIR feeds ln_final tokens and projected features to the same 512-d head: width == embed_dim")
