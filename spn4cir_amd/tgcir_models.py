@@ -409,3 +409,63 @@ class CIRPlus(nn.Module):
         ref = self.refer_bank[idx.to(self.refer_bank.device)].to(self.device, torch.float32)
         labels = target_indexs.to(self.device, torch.int64)
         return {"bank_loss": _TgcirStep.apply(self._anchor, self, ids, ref, labels)}
+
+
+class TgcirStage2Trainer:
+    """tgcir/train.py's second-stage loop body (:82-92 optimizer, :120-135 step) on one GPU or data-parallel over
+    RCCL: triplets sharded across ranks, text tower + head replicated, bank replicated or sharded as for the CLIP path
+    (spn4cir_amd.distributed.BankLossDP), both flat gradient buffers all-reduced, one fused AdamW launch per buffer
+    (lr, betas (0.9, 0.999), eps 1e-7, torch's default weight decay - what optim.AdamW(param_groups) configures)."""
+
+    def __init__(self, model, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None, bank_mode="sharded",
+                 label_smoothing=0.0, bucket_elems=8 << 20):
+        from . import distributed as dp
+        self.model, self.group = model, group
+        self.text, self.head = model.text, model.head
+        self.lr, self.betas, self.eps, self.wd, self.ls = lr, betas, eps, weight_decay, label_smoothing
+        self.world, self.rank = dp._world(group)
+        self.loss_dp = dp.BankLossDP(ops, group, bank_mode if (self.world > 1 or dp._FORCE) else "replicated")
+        self.red_text = dp.GradBucketReducer(self.text.grads, group, bucket_elems)
+        self.red_head = dp.GradBucketReducer(self.head.grads, group, bucket_elems)
+        self._shard_range = dp.shard_range
+        self.state = [(torch.zeros_like(self.text.params), torch.zeros_like(self.text.params)),
+                      (torch.zeros_like(self.head.params), torch.zeros_like(self.head.params))]
+        self.step_count = 0
+        self._bank, self._m_begin, self._M_total = None, 0, 0
+        self.refer_bank = None
+
+    def set_banks(self, refer_bank, target_bank):
+        """refer_bank [N, 12, C] token bank (kept on the device), target_bank fp32 [M, C] normalised rows; the sharded
+        mode keeps only this rank's target rows."""
+        dev = self.text.device
+        self.refer_bank = refer_bank.to(dev, torch.float32).contiguous()
+        self._M_total = target_bank.shape[0]
+        if self.loss_dp.mode == "sharded" and self.world > 1:
+            b, e = self._shard_range(self._M_total, self.world, self.rank)
+            self._m_begin = b
+            self._bank = ops.prepare_bank(target_bank[b:e].to(dev, torch.float32).contiguous())
+        else:
+            self._m_begin = 0
+            self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32))
+
+    def step(self, ids, refer_idx, labels):
+        """ids int32 [B_local, L], refer_idx int64 [B_local] rows of the token bank, labels int64 [B_local] global
+        target rows (all on the device).  Returns the global mean loss (1-element device tensor)."""
+        text, head = self.text, self.head
+        feats, tokens, tokens_b = text.forward_tokens(ids)
+        pooled, _ = head.forward(feats, tokens, tokens_b, self.refer_bank[refer_idx])
+        q, qb, inv = ops.combine_l2norm_fwd(None, None, pooled)
+        ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / self.model.tau, self.ls)
+        dq = self.loss_dp.backward(ctx)[:, :head.C].contiguous()
+        dfeats, dtokens = head.backward(ops.combine_l2norm_bwd(q, inv, dq))
+        self.red_head.on_span_ready(0, head.n_params)
+        text.backward_tokens(dfeats, dtokens)
+        self.red_text.on_span_ready(0, text.n_params)
+        self.red_head.finish()
+        self.red_text.finish()
+        self.step_count += 1
+        for (p, g), (m, v) in zip(((text.params, text.grads), (head.params, head.grads)), self.state):
+            ops.adamw_step(p, g, m, v, self.step_count, self.lr, self.betas, self.eps, self.wd)
+        text.mark_stale()
+        head.mark_stale()
+        return ctx["loss"]
