@@ -30,6 +30,16 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// Accumulator staging of the epilogues: row r of the fp32 [rows][BN] LDS image keeps its 16-byte unit `unit` (4 columns)
+// at slot ((unit >> 1) | (unit & 1) * BN/8) ^ (r & 15): even units in the first half of the row, odd units in the second,
+// XOR-rotated by the row.  The writers (16 lanes = 16 rows, one unit) then hit 16 different slots, and so do the readers
+// (16 lanes = one row, units 2u resp. 2u+1) - with the plain unit ^ (r & 15) layout the readers' stride-2 units collided
+// pairwise (1 024 conflict cycles per 256x256 tile in the SQ counters).
+template <int BN>
+__device__ __forceinline__ int stage_slot(int unit, int r) {
+    return ((unit >> 1) | ((unit & 1) * (BN / 8))) ^ (r & 15);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                     for (int g = 0; g < 4; ++g) {
                         const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
                         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        *(f32x4*)(sC + r * BN + ((unit ^ (r & 15)) << 2)) = v;
+                        *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
                     }
             }
             __syncthreads();
@@ -369,8 +379,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                 const int m = m0 + ch * CHUNK + rr;
                 if (rr >= CHUNK || m >= M) continue;          // wave-uniform per row pair for the shuffles below
                 if (MODE != GEMM_BANKSTATS && n >= N) continue;
-                f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
-                f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
+                f32x4 v0 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
+                f32x4 v1 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
                 if constexpr (MODE == GEMM_BANKSTATS) {
                     // this lane's 8 logits of row m -> {max, sum exp, sum, label logit}, merged over the LPR lanes
                     // that share the row (consecutive lanes: xor shuffles below LPR stay inside the row)
@@ -838,15 +848,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
                     for (int g = 0; g < 4; ++g) {
                         const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
                         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        *(f32x4*)(sC + r * BN + ((unit ^ (r & 15)) << 2)) = v;
+                        *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
                     }
             }
             __syncthreads();
             for (int rr = wid * RPI + lane / LPR; rr < CHUNK; rr += NW * RPI) {
                 const int m = m0 + ch * CHUNK + rr;
                 if (m >= N1 || n >= N2) continue;
-                const f32x4 v0 = *(const f32x4*)(sC + rr * BN + (((2 * u) ^ (rr & 15)) << 2));
-                const f32x4 v1 = *(const f32x4*)(sC + rr * BN + (((2 * u + 1) ^ (rr & 15)) << 2));
+                const f32x4 v0 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
+                const f32x4 v1 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
                 float* o = Cz + (size_t)m * ldc + n;
                 *(f32x4*)o = v0;
                 if (hi) *(f32x4*)(o + 4) = v1;
