@@ -198,7 +198,7 @@ template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArgs g) {
     const AttnArgs& a = g.f;
     constexpr int KS = (NT + 1) / 2, KP = KS * 32;
-    constexpr int PLD = KP;              // P / dS row stride: key columns 0..KP-1
+    constexpr int PLD = KP + 8;          // P / dS row stride (elements): +16 B spreads 16 rows of one column over the banks (conflict ratio 0.60 -> 0.39)
     constexpr int ZR = NT * 16;          // index of the all-zero row; tiles have ZR + 1 rows
     constexpr int TR_ = ZR + 1;
     // Q, K, V, dO tiles [TR_][SLD] + P, dS matrices [TR_][PLD] (rows = queries)
@@ -688,7 +688,7 @@ static int launch_small_fwd(const AttnArgs& a, hipStream_t st) {
 
 template <int NT>
 static int launch_small_bwd(const AttnBwdArgs& g, hipStream_t st) {
-    constexpr int KS = (NT + 1) / 2, KP = KS * 32, PLD = KP, TR_ = NT * 16 + 1;
+    constexpr int KS = (NT + 1) / 2, KP = KS * 32, PLD = KP + 8, TR_ = NT * 16 + 1;
     constexpr int LDS = (4 * TR_ * SLD + 2 * TR_ * PLD) * 2;
     auto kern = attention_small_bwd_kernel<NT>;
     static bool attr_set = false;
