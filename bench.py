@@ -22,8 +22,15 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# The HSA runtime reads these when it is initialised (the first torch.cuda call), RCCL at init_process_group: they
+# have to be in the environment before either.  dmabuf IPC is the only mode the host driver supports (without it
+# RCCL's buffer exchange fails with hipIpcGetMemHandle: invalid argument); rendezvous goes over loopback.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -133,9 +140,6 @@ def main():
     # gradient all-reduce - with a 1-rank group
     force_dp = os.environ.get("SPN_DP_FORCE_COLLECTIVES") == "1"
     if world > 1 or force_dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         dist.barrier()
         C.CDLL(None).fflush(None)          # emit RCCL's start-up banner now, not after the result line

@@ -103,9 +103,12 @@ int spn_embed_bwd(const int32_t* ids, const int32_t* eot_or_null, const float* d
 
 /* ---------------------------------------------------------------- combiner + normalise
  * q = F.normalize(refer_bank[ref_idx] + text)   (models_negplus.py:48-50,133-137).
- * refer_bank may be NULL (q = normalize(text)).  q_bf16 has leading dim ldq >= D (pad is zeroed). */
-int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
-                           void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream);
+ * refer_bank may be NULL (q = normalize(text)).  q_bf16 has leading dim ldq >= D (pad is zeroed).
+ * n_refer = rows of refer_bank: a ref_idx outside [0, n_refer) is never dereferenced (the reference raises
+ * IndexError at models_negplus.py:133; a kernel cannot) - that query row and its inv_norm come out as NaN, so the
+ * loss of the step is NaN instead of silently wrong.  n_refer <= 0 disables the check. */
+int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
+                           float* q_f32, void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream);
 int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const float* dq, float* dtext, int B, int D,
                            void* stream);
 

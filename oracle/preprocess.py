@@ -40,11 +40,16 @@ def center_crop_offsets(w, h, dim):
 
 
 def targetpad_transform_u8(img, target_ratio, dim):
-    """PIL RGB image -> uint8 [dim, dim, 3] right before ToTensor."""
+    """PIL image (any mode) -> uint8 [dim, dim, 3] right before ToTensor.  Pad, resize and crop run in the image's own
+    mode, the RGB conversion comes after them (data_utils.py:91-95)."""
     w, h = img.size
     hp, vp = targetpad_padding(w, h, target_ratio)
     if hp or vp:
-        canvas = Image.new("RGB", (w + 2 * hp, h + 2 * vp), 0)      # F.pad(image, [hp, vp, hp, vp], 0, 'constant')
+        # F.pad(image, [hp, vp, hp, vp], 0, 'constant') on a PIL image = ImageOps.expand(border, fill=0); torchvision
+        # re-attaches the palette of a 'P' image afterwards
+        canvas = Image.new(img.mode, (w + 2 * hp, h + 2 * vp), 0)
+        if img.mode == "P" and img.palette is not None:
+            canvas.putpalette(img.getpalette())
         canvas.paste(img, (hp, vp))
         img = canvas
     w, h = img.size

@@ -72,7 +72,7 @@ _SIGS = {
                                 i32, i32, i32, i32, i32, f32, vp]),
     "spn_embed_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spn_embed_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "spn_combine_l2norm_fwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "spn_combine_l2norm_fwd": (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_combine_l2norm_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
     "spn_bank_stats_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "spn_bank_loss_finalize": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),

@@ -13,7 +13,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import gradsink, ops
 from .fusion import FusionEncoder, fusion_cfg_from_state_dict
 from .vision_tower import VisionTower
 
@@ -39,10 +39,9 @@ class _FusionBankStep(torch.autograd.Function):
         dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], float(grad_out) / st["B"],
                              M_total=bank.shape[0])[:, :enc.Dp].contiguous()
         dtau = (-(st["q"] * dq).sum() / st["tau"]).reshape(())            # models.py:29: tau is an nn.Parameter
+        snap = gradsink.snapshot(m._params, enc.grads, enc.named_views)
         flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq))
-        for key, view in enc.named_views(flat).items():
-            p = m._params[key]
-            p.grad = view if p.grad is None else p.grad + view
+        gradsink.publish(m._params, flat, enc.named_views, snap)
         return torch.zeros((), device=grad_out.device), dtau, None, None, None, None, None
 
 

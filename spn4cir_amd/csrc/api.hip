@@ -135,9 +135,9 @@ int spn_embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float
     return embed_bwd(ids, eot, dx, dtok, dpos, B, L, W, vocab, ST(stream));
 }
 
-int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
-                           void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream) {
-    return combine_l2norm_fwd(refer_bank, ref_idx, text, q_f32, BF(q_bf16), inv_norm, B, D, ldq, ST(stream));
+int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
+                           float* q_f32, void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream) {
+    return combine_l2norm_fwd(refer_bank, ref_idx, n_refer, text, q_f32, BF(q_bf16), inv_norm, B, D, ldq, ST(stream));
 }
 
 int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const float* dq, float* dtext, int B, int D,

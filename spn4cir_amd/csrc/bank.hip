@@ -28,13 +28,27 @@ __device__ __forceinline__ f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) {
 
 // ------------------------------------------------------------------ combiner + normalise
 // q = normalize(refer_bank[ref_idx] + text)   (models_negplus.py:133-137; F.normalize eps 1e-12)
+// A reference row outside [0, n_refer) is not dereferenced: the whole query row (and inv_norm) becomes NaN.
 __global__ void combine_l2norm_fwd_kernel(const float* __restrict__ refer, const int64_t* __restrict__ ref_idx,
-                                          const float* __restrict__ text, float* __restrict__ qf,
+                                          int64_t n_refer, const float* __restrict__ text, float* __restrict__ qf,
                                           bf16_t* __restrict__ qb, float* __restrict__ inv_norm, int B, int D, int ldq) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float* r = refer ? refer + (size_t)ref_idx[b] * D : nullptr;
+    const int64_t ri = refer ? ref_idx[b] : 0;
+    if (refer && n_refer > 0 && (ri < 0 || ri >= n_refer)) {
+        const float nan = __builtin_nanf("");
+        if (lane == 0 && inv_norm) inv_norm[b] = nan;
+        for (int c = lane * 4; c < ldq; c += 256) {
+            if (c < D && qf) *(f32x4*)(qf + (size_t)b * D + c) = f32x4{nan, nan, nan, nan};
+            if (qb) {
+                const bf16_t v = f2bf(c < D ? nan : 0.f);
+                *(bf16x4*)(qb + (size_t)b * ldq + c) = bf16x4{v, v, v, v};
+            }
+        }
+        return;
+    }
+    const float* r = refer ? refer + (size_t)ri * D : nullptr;
     const float* t = text + (size_t)b * D;
     float ss = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
@@ -60,12 +74,12 @@ __global__ void combine_l2norm_fwd_kernel(const float* __restrict__ refer, const
     }
 }
 
-int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
-                       bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st) {
+int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
+                       float* q_f32, bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st) {
     if (B <= 0 || D <= 0) return SPN_ERR_ARG;
     if (D % 4 || ldq % 4 || ldq < D || (refer_bank && !ref_idx)) return SPN_ERR_SHAPE;
-    hipLaunchKernelGGL(combine_l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, refer_bank, ref_idx, text, q_f32,
-                       q_bf16, inv_norm, B, D, ldq);
+    hipLaunchKernelGGL(combine_l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, refer_bank, ref_idx, n_refer, text,
+                       q_f32, q_bf16, inv_norm, B, D, ldq);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -134,8 +134,8 @@ int attention_cross_bwd(const AttnBwdArgs& a, hipStream_t st);
 int attention_cross_fwd(const AttnArgs& a, hipStream_t st);
 
 // bank.hip
-int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, const float* text, float* q_f32,
-                       bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st);
+int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
+                       float* q_f32, bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st);
 int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, float* dtext, int B, int D,
                        hipStream_t st);
 struct BankArgs {

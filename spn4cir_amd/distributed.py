@@ -131,7 +131,7 @@ class GradBucketReducer:
             else:
                 merged.append([s, e])
         for s, e in merged:
-            self._works.append(dist.all_reduce(self.flat[s:e], group=self.group, async_op=True))
+            self._works.append((s, e, dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)))
         self._pending = []
 
     def on_span_ready(self, start, end):
@@ -141,19 +141,31 @@ class GradBucketReducer:
         if sum(e - s for s, e in self._pending) >= self.bucket_elems:
             self._flush()
 
-    def finish(self, keep_last=0):
-        """Make the compute stream wait for the all-reduces.  keep_last = n leaves the n most recent ones in
-        flight and returns their handles (the caller overlaps them with work that does not touch those spans,
-        e.g. AdamW over the already-reduced part of the buffer, then calls .wait() on each)."""
+    def finish(self, keep_span=None):
+        """Make the compute stream wait for the all-reduces.  keep_span = (start, end) leaves the all-reduces of
+        exactly that flat range in flight and returns their handles: the caller overlaps them with work that does
+        not touch the range (AdamW over the rest of the buffer) and then calls .wait() on each.  Handles are kept
+        only when their spans lie inside keep_span AND tile it completely - decided from the recorded spans, not
+        from issue order; otherwise everything is waited for and [] is returned."""
         if _skip(self.world):
             return []
         self._flush()
-        cut = len(self._works) - keep_last if keep_last else len(self._works)
-        for w in self._works[:cut]:
+        works, self._works = self._works, []
+        kept = []
+        if keep_span is not None:
+            lo, hi = keep_span
+            inside = sorted((s, e) for s, e, _ in works if lo <= s and e <= hi)
+            pos = lo
+            for s, e in inside:
+                if s != pos:
+                    break
+                pos = e
+            if inside and pos == hi:
+                kept = [w for s, e, w in works if lo <= s and e <= hi]
+                works = [(s, e, w) for s, e, w in works if not (lo <= s and e <= hi)]
+        for _, _, w in works:
             w.wait()            # the compute stream waits for the RCCL stream; no host sync on RCCL
-        rest = self._works[cut:]
-        self._works = []
-        return rest
+        return kept
 
     def flush(self):
         """Close the current bucket now (its all-reduce starts behind the work enqueued so far)."""

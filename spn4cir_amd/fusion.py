@@ -91,14 +91,22 @@ class FusionEncoder:
     def mark_stale(self):
         self._stale = True
 
+    def is_stale(self):
+        """True when the bf16 GEMM operands no longer match the fp32 masters: flagged explicitly (mark_stale) or the
+        flat parameter buffer was written in place through any view since the last refresh - torch bumps the shared
+        version counter for that, which is how an external `optimizer.step()` on the exposed nn.Parameters
+        (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
+        return self._stale or self.params._version != getattr(self, "_seen_version", -1)
+
     def forward(self, ids, mask, enc):
         """ids int32 [B,L], mask int32 [B,L] or None, enc fp32 [B,S,E] (device) -> text_proj output fp32 [B,Dp]."""
         B, L = ids.shape
         S = enc.shape[1]
         cfg = self._cfg(B, L, S)
-        if self._stale:
+        if self.is_stale():
             check(lib().spn_fusion_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()), "fusion_refresh")
             self._stale = False
+            self._seen_version = self.params._version
         if self._key != (B, L, S):
             self._acts = torch.empty(lib().spn_fusion_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
             self._ws = torch.empty(lib().spn_fusion_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)

@@ -16,7 +16,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import gradsink, ops
 from .text_tower import TextTower, text_cfg_from_state_dict
 from .vision_tower import VisionTower, vision_cfg_from_state_dict
 
@@ -349,10 +349,9 @@ class CIRPlus(nn.Module):
         dq = ops.bank_grad_q(st["qb"], self._target_bank_dev, st["labels"], 1.0 / self.tau, st["lse"],
                              scale / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing)
         dtext = ops.combine_l2norm_bwd(st["q"], st["inv"], dq[:, :self.output_dim].contiguous())
+        snap = gradsink.snapshot(self._params, self.tower.grads, self.tower.named_views)
         flat = self.tower.backward(dtext)
-        for key, view in self.tower.named_views(flat).items():
-            p = self._params[key]
-            p.grad = view if p.grad is None else p.grad + view
+        gradsink.publish(self._params, flat, self.tower.named_views, snap)
 
     # ---------------------------------------------------------------- in-batch step (config 1)
     def _inbatch_forward(self, ids, refer_image, target_image):
@@ -379,14 +378,12 @@ class CIRPlus(nn.Module):
         dt = ops.inbatch_grad_t(st["qb"], st["tb"], st["lse"], 1.0 / self.tau, gs, D)
         dsum = ops.combine_l2norm_bwd(st["q"], st["inv_q"], dq[:, :D].contiguous())      # = d ref_feats = d text_feats
         dtgt = ops.combine_l2norm_bwd(st["t"], st["inv_t"], dt)
+        snap_t = gradsink.snapshot(self._params, self.tower.grads, self.tower.named_views)
+        snap_v = gradsink.snapshot(self._params, self.vision.grads, self.vision.named_views, "visual.")
         flat_t = self.tower.backward(dsum)
         flat_v = self.vision.backward(torch.cat([dsum, dtgt]))
-        for key, view in self.tower.named_views(flat_t).items():
-            p = self._params[key]
-            p.grad = view if p.grad is None else p.grad + view
-        for key, view in self.vision.named_views(flat_v).items():
-            p = self._params["visual." + key]
-            p.grad = view if p.grad is None else p.grad + view
+        gradsink.publish(self._params, flat_t, self.tower.named_views, snap_t)
+        gradsink.publish(self._params, flat_v, self.vision.named_views, snap_v, "visual.")
 
     def forward(self, text, indexs, target_indexs, refer_indexs, refer_image=None, target_image=None):
         """models_negplus.py:144-148 -> {'bank_loss': 0-dim tensor with grad}; with wo_bank
@@ -395,6 +392,8 @@ class CIRPlus(nn.Module):
         if self.wo_bank:
             loss = _InBatchStep.apply(self._anchor, self, ids, refer_image, target_image)
             return {"bbc_loss": loss}
+        ops.check_index_range(refer_indexs if self.plus else indexs, self.refer_bank.shape[0], "refer_bank")
+        ops.check_index_range(target_indexs, self.target_bank.shape[0], "target_bank labels")   # CrossEntropyLoss: class < M
         bank, ridx = self._refer_rows(indexs, refer_indexs)
         self._refer_f32 = bank if bank.dtype == torch.float32 else bank.float()
         labels = target_indexs.to(self.device, torch.int64)

@@ -5,6 +5,7 @@ passes raw device pointers plus torch's current stream to libspn4cir_hip.so and 
 tensors.  There is no CPU fallback: CPU tensors are rejected.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -42,6 +43,20 @@ def workspace(nbytes, device, slot="default"):
 def _req(t, dtype, name):
     if t.dtype != dtype or not t.is_contiguous():
         raise ValueError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def check_index_range(idx, n, name):
+    """IndexError for a row index outside [0, n), as `refer_bank[refer_indexs]` raises in the reference
+    (models_negplus.py:133).  Free for host tensors - the DataLoader hands the reference's loop CPU LongTensors
+    (train_negplus.py:107-111); a device tensor is only inspected (one sync) under SPN_CHECK_INDICES=1, otherwise the
+    kernels' own guards apply (NaN query row / infinite loss, never an out-of-bounds read)."""
+    if idx is None or idx.numel() == 0:
+        return
+    if idx.is_cuda and os.environ.get("SPN_CHECK_INDICES") != "1":
+        return
+    lo, hi = int(idx.min()), int(idx.max())
+    if lo < 0 or hi >= n:
+        raise IndexError(f"{name}: index {lo if lo < 0 else hi} is out of bounds for a bank with {n} rows")
 
 
 # ------------------------------------------------------------------------------- GEMMs
@@ -229,14 +244,22 @@ def prepare_bank(bank_f32, dtype="bf16"):
 
 
 def combine_l2norm_fwd(refer_bank, ref_idx, text, ldq=None):
-    """-> (q fp32 [B,D], q bf16 [B,ldq], inv_norm [B])"""
+    """-> (q fp32 [B,D], q bf16 [B,ldq], inv_norm [B]).  A ref_idx outside the bank gives a NaN row (the kernel never
+    dereferences it); callers that still hold the indices on the host raise IndexError first (check_index_range)."""
     _req(text, torch.float32, "text")
     B, D = text.shape
+    n_refer = 0
+    if refer_bank is not None:
+        _req(refer_bank, torch.float32, "refer_bank")
+        _req(ref_idx, torch.int64, "ref_idx")
+        if refer_bank.dim() != 2 or refer_bank.shape[1] != D or ref_idx.numel() != B:
+            raise ValueError(f"refer_bank {tuple(refer_bank.shape)} / ref_idx {tuple(ref_idx.shape)} do not match text {tuple(text.shape)}")
+        n_refer = refer_bank.shape[0]
     ldq = ldq or bank_dim(D)
     q = torch.empty(B, D, dtype=torch.float32, device=text.device)
     qb = torch.empty(B, ldq, dtype=torch.bfloat16, device=text.device)
     inv = torch.empty(B, dtype=torch.float32, device=text.device)
-    check(lib().spn_combine_l2norm_fwd(_p(refer_bank), _p(ref_idx), _p(text), _p(q), _p(qb), _p(inv), B, D, ldq,
+    check(lib().spn_combine_l2norm_fwd(_p(refer_bank), _p(ref_idx), n_refer, _p(text), _p(q), _p(qb), _p(inv), B, D, ldq,
                                        _stream()), "combine_l2norm_fwd")
     return q, qb, inv
 

@@ -69,7 +69,8 @@ def targetpad_geometry(w, h, target_ratio, dim):
 
 class TargetPadTransform:
     """GPU `targetpad_transform(target_ratio, dim)`: uint8 RGB [H, W, 3] (numpy / CPU or device tensor, or a PIL
-    image) -> fp32 [3, dim, dim] on the device, bit-identical to the reference's CPU pipeline."""
+    image) -> fp32 [3, dim, dim] on the device, bit-identical to the reference's CPU pipeline.  PIL images in modes
+    other than RGB / L are padded / resized / cropped by Pillow in their own mode first (`_native_mode_u8`)."""
 
     def __init__(self, target_ratio=1.25, dim=224, device="cuda", mean=CLIP_MEAN, std=CLIP_STD):
         self.target_ratio, self.dim, self.device = float(target_ratio), int(dim), torch.device(device)
@@ -84,9 +85,36 @@ class TargetPadTransform:
             self._tables[key] = (torch.from_numpy(kk).to(self.device), torch.from_numpy(bounds).to(self.device), kk.shape[1])
         return self._tables[key]
 
+    def _native_mode_u8(self, image):
+        """PIL image in a mode other than RGB / L -> uint8 RGB [dim, dim, 3] right before ToTensor.
+
+        The reference's Compose pads, resizes and crops in the image's OWN mode and converts to RGB afterwards
+        (data_utils.py:91-95).  For RGB that order is immaterial and for L the three channels stay equal, but Pillow
+        resamples palettised ('P') and bilevel ('1') images with NEAREST whatever filter is asked for, resizes
+        RGBA / LA with premultiplied alpha, and 'I' / 'F' / CMYK have their own arithmetic - convert-first gives
+        different pixels there.  Such files are rare (a few PNGs), so they take Pillow's own path on the host and only
+        ToTensor + Normalize run on the device (the kernel with identical input and output size is the identity)."""
+        from PIL import Image
+        w, h = image.size
+        hp, vp, ow, oh, left, top = targetpad_geometry(w, h, self.target_ratio, self.dim)
+        if hp or vp:                               # torchvision F.pad(img, [hp, vp, hp, vp], 0, 'constant') = ImageOps.expand
+            canvas = Image.new(image.mode, (w + 2 * hp, h + 2 * vp), 0)
+            if image.mode == "P" and image.palette is not None:
+                canvas.putpalette(image.getpalette())
+            canvas.paste(image, (hp, vp))
+            image = canvas
+        if image.size != (ow, oh):
+            image = image.resize((ow, oh), Image.BICUBIC)
+        image = image.crop((left, top, left + self.dim, top + self.dim))
+        return np.array(image.convert("RGB"), dtype=np.uint8)
+
     def __call__(self, image, return_uint8=False):
         if not torch.is_tensor(image):
-            image = torch.from_numpy(np.array(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8))
+            if hasattr(image, "convert"):
+                if image.mode not in ("RGB", "L"):
+                    return self(self._native_mode_u8(image), return_uint8)
+                image = image.convert("RGB")
+            image = torch.from_numpy(np.array(image, dtype=np.uint8))
         if image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3:
             raise ValueError("expected a uint8 RGB image [H, W, 3]")
         src = image.to(self.device).contiguous()

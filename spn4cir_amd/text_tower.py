@@ -95,9 +95,17 @@ class TextTower:
         check(lib().spn_text_refresh_bf16(C.byref(self._cfg(1, self.ctx)), _p(self.params), _p(self.wbf16), _stream()),
               "text_refresh_bf16")
         self._stale = False
+        self._seen_version = self.params._version
 
     def mark_stale(self):
         self._stale = True
+
+    def is_stale(self):
+        """True when the bf16 GEMM operands no longer match the fp32 masters: flagged explicitly (mark_stale) or the
+        flat parameter buffer was written in place through any view since the last refresh - torch bumps the shared
+        version counter for that, which is how an external `optimizer.step()` on the exposed nn.Parameters
+        (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
+        return self._stale or self.params._version != getattr(self, "_seen_version", -1)
 
     # ------------------------------------------------------------------ compute
     def _buffers(self, B, L, need_ws, T=0):
@@ -129,7 +137,7 @@ class TextTower:
         if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
             raise ValueError("ids must be a contiguous int32 device tensor")
         B, L = ids.shape
-        if self._stale:
+        if self.is_stale():
             self.refresh()
         T = int(total_rows) if cu_seqlens is not None else 0
         cfg = self._buffers(B, L, False, T)
@@ -178,7 +186,7 @@ class TextTower:
         if ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
             raise ValueError("ids must be a contiguous int32 device tensor")
         B, L = ids.shape
-        if self._stale:
+        if self.is_stale():
             self.refresh()
         cfg = self._buffers(B, L, False, 0)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)

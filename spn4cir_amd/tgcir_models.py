@@ -19,7 +19,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import gradsink, ops
 from ._lib import check, lib
 from .ops import _p, _stream
 from .text_tower import TextTower, text_cfg_from_state_dict
@@ -77,10 +77,18 @@ class TgcirHead:
     def mark_stale(self):
         self._stale = True
 
+    def is_stale(self):
+        """True when the bf16 GEMM operands no longer match the fp32 masters: flagged explicitly (mark_stale) or the
+        flat parameter buffer was written in place through any view since the last refresh - torch bumps the shared
+        version counter for that, which is how an external `optimizer.step()` on the exposed nn.Parameters
+        (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
+        return self._stale or self.params._version != getattr(self, "_seen_version", -1)
+
     def _refresh(self):
         v = self.named_views()
         self.wfc_b, self.wfc_t = ops.cast_transpose_bf16(v["text_fc.weight"])            # [C, C] and its transpose
         self._stale = False
+        self._seen_version = self.params._version
 
     def _ws(self, B):
         return ops.workspace(lib().spn_tg_ws_bytes(B, self.C), self.device, "tgcir")
@@ -88,7 +96,7 @@ class TgcirHead:
     def forward(self, feats, tokens, tokens_b, ref_tokens):
         """feats [B, C], tokens [B, L, C] (+ bf16 copy) from TextTower.forward_tokens, ref_tokens [B, NT, C] fp32
         -> pooled fused feature [B, C] (un-normalised); state kept for backward()."""
-        if self._stale:
+        if self.is_stale():
             self._refresh()
         B, L, C = tokens.shape
         S, G, NT = self.S, self.G, self.NT
@@ -171,14 +179,12 @@ class _TgcirStep(torch.autograd.Function):
         dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / m.tau, st["lse"], float(grad_out) / st["B"],
                              M_total=bank.shape[0])[:, :m.head.C].contiguous()
         dpooled = ops.combine_l2norm_bwd(st["q"], st["inv"], dq)
+        snap_h = gradsink.snapshot(m._params, m.head.grads, m.head.named_views)
+        snap_t = gradsink.snapshot(m._params, m.text.grads, m.text.named_views, "clip.")
         dfeats, dtokens = m.head.backward(dpooled)
         flat = m.text.backward_tokens(dfeats, dtokens)
-        for key, view in m.text.named_views(flat).items():
-            p = m._params["clip." + key]
-            p.grad = view if p.grad is None else p.grad + view
-        for key, view in m.head.named_views(m.head.grads).items():
-            p = m._params[key]
-            p.grad = view if p.grad is None else p.grad + view
+        gradsink.publish(m._params, flat, m.text.named_views, snap_t, "clip.")
+        gradsink.publish(m._params, m.head.grads, m.head.named_views, snap_h)
         return torch.zeros((), device=grad_out.device), None, None, None, None
 
 

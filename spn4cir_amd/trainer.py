@@ -71,7 +71,7 @@ class Stage2Trainer:
 
         t.backward_phased(dtext, on_span)
         split = self.world > 1 and not self.check_finite
-        pending = self.reducer.finish(keep_last=1 if split else 0)
+        pending = self.reducer.finish(keep_span=(0, tail_end) if split else None)
         self.step_count += 1
         found = None
         if self.check_finite:

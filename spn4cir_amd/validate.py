@@ -61,8 +61,12 @@ def _name_index(index_names):
 
 
 def _predict(model, captions, ref_idx, index_features):
-    """normalize(combining_function(index_features[ref], encode_text(captions)))  (validate.py:84-95)"""
-    text = model.encode_text(captions)
+    """normalize(combining_function(index_features[ref], encode_text(captions)))  (validate.py:84-95)
+
+    Under torch.no_grad() as in the reference (validate.py:83): that is what selects CIRPlus(exact_eval=True)'s fp32
+    tower, and a bf16 training forward here would overwrite the activations of a pending backward."""
+    with torch.no_grad():
+        text = model.encode_text(captions)
     q, _, _ = ops.combine_l2norm_fwd(index_features, ref_idx, text.float().contiguous())
     return q
 

@@ -101,11 +101,19 @@ class VisionTower:
     def mark_stale(self):
         self._stale = True
 
+    def is_stale(self):
+        """True when the bf16 GEMM operands no longer match the fp32 masters: flagged explicitly (mark_stale) or the
+        flat parameter buffer was written in place through any view since the last refresh - torch bumps the shared
+        version counter for that, which is how an external `optimizer.step()` on the exposed nn.Parameters
+        (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
+        return self._stale or self.params._version != getattr(self, "_seen_version", -1)
+
     def _refresh(self, cfg):
-        if self._stale:
+        if self.is_stale():
             check(lib().spn_vision_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()),
                   "vision_refresh_bf16")
             self._stale = False
+            self._seen_version = self.params._version
 
     def forward_exact(self, image):
         """fp32-exact image features of the CLIP tower (see TextTower.forward_exact)."""

@@ -91,6 +91,25 @@ def _worker(rank, world, port, mode, out):
             red.on_span_ready(s, e)
         red.finish()
         ok_red = torch.equal(flat, torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1)))
+        # finish(keep_span): the kept handles are chosen by their recorded spans - here the head span [0, 250) is
+        # issued FIRST, so "the last work" would be the wrong one - and only when they tile the span exactly
+        want = torch.arange(1000, dtype=torch.float32) * sum(range(1, world + 1))
+        flat2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        red2 = GradBucketReducer(flat2, None, bucket_elems=300)
+        red2.on_span_ready(0, 250)
+        red2.flush()
+        for s, e in [(900, 1000), (600, 900), (250, 600)]:
+            red2.on_span_ready(s, e)
+        kept = red2.finish(keep_span=(0, 250))
+        ok_red = ok_red and len(kept) == 1 and torch.equal(flat2[250:], want[250:])
+        for w in kept:
+            w.wait()
+        ok_red = ok_red and torch.equal(flat2, want)
+        flat3 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        red3 = GradBucketReducer(flat3, None, bucket_elems=10 ** 9)       # one bucket [0, 1000): nothing tiles [0, 250)
+        for s, e in [(250, 1000), (0, 250)]:
+            red3.on_span_ready(s, e)
+        ok_red = ok_red and red3.finish(keep_span=(0, 250)) == [] and torch.equal(flat3, want)
         out.put((rank, ok_loss, ok_grad, ok_red, ctx["loss"].item(), ref.item()))
     finally:
         dist.destroy_process_group()

@@ -506,3 +506,114 @@ def test_clip_file_formats(golden_dir, tmp_path, monkeypatch):
     assert torch.equal(CIRPlus("ViT-B/32", device=dev).encode_text(ids), ref)
     with pytest.raises(RuntimeError, match="not found"):
         CIRPlus("ViT-L/14", device=dev)                         # named, but its file is not in the cache
+
+
+def _loop_model(golden_dir):
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    s = np.load(os.path.join(golden_dir, "cirplus_step.npz"))
+    model = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=True)
+    model.refer_bank = torch.from_numpy(s["refer_bank"])
+    model.target_bank = torch.from_numpy(s["target_bank"])
+    ids = torch.from_numpy(z["ids"])
+    args = (ids, torch.arange(ids.shape[0]), torch.from_numpy(s["tgt_img_ids"]), torch.from_numpy(s["ref_img_ids"]))
+    return model, args, s
+
+
+def test_grad_accumulates_like_autograd(golden_dir):
+    """p.grad is a slice of the tower's overwrite-on-backward flat buffer, yet `.backward()` must ADD to an existing
+    .grad as autograd does: two backward passes without zero_grad (gradient accumulation) give g1 + g2, and
+    `zero_grad(set_to_none=False)` - the default of the reference's torch 1.13 - followed by a backward gives g."""
+    _need_gpu()
+    model, args, s = _loop_model(golden_dir)
+    ref = torch.from_numpy(s["grad_plus::text_projection"])
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0)
+    model.forward(*args)["bank_loss"].backward()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert ((g1["clip.text_projection"].cpu() - ref).norm() / ref.norm()).item() < 5e-2
+    (2.0 * model.forward(*args)["bank_loss"]).backward()               # accumulate: g + 2 g
+    for n, p in model.named_parameters():
+        if n in g1:
+            assert torch.allclose(p.grad, 3.0 * g1[n], rtol=1e-4, atol=1e-6 * g1[n].abs().max().item()), n
+    opt.zero_grad(set_to_none=False)                                   # keeps the (aliasing) tensors, zero-filled
+    assert all(p.grad is not None and not p.grad.any() for p in params if p.grad is not None)
+    model.forward(*args)["bank_loss"].backward()
+    for n, p in model.named_parameters():
+        if n in g1:
+            assert torch.allclose(p.grad, g1[n], rtol=1e-4, atol=1e-6 * g1[n].abs().max().item()), n
+    # a caller-owned .grad (not a slice of the flat buffer) accumulates too, and a mixed state is handled per tensor
+    tp = model.clip.text_projection
+    tp.grad = torch.ones_like(tp)
+    model.clip.ln_final.weight.grad = None
+    model.forward(*args)["bank_loss"].backward()
+    assert torch.allclose(tp.grad, 1.0 + g1["clip.text_projection"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(model.clip.ln_final.weight.grad, g1["clip.ln_final.weight"], rtol=1e-4, atol=1e-6)
+    k = "clip.transformer.resblocks.0.attn.in_proj_weight"
+    assert torch.allclose(dict(model.named_parameters())[k].grad, 2.0 * g1[k], rtol=1e-4, atol=1e-6 * g1[k].abs().max().item())
+
+
+def test_external_optimizer_step_is_noticed_without_parameters_changed(golden_dir):
+    """The reference loop (train_negplus.py:121-123) knows nothing about parameters_changed(): an in-place optimizer
+    update of the exposed nn.Parameters must reach the bf16 GEMM operands of the next forward by itself."""
+    _need_gpu()
+    model, args, s = _loop_model(golden_dir)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, eps=1e-7)
+    l0 = model.forward(*args)["bank_loss"]
+    l0.backward()
+    opt.step()                                                          # no model.parameters_changed()
+    opt.zero_grad()
+    l1 = model.forward(*args)["bank_loss"]
+    assert l1.item() < l0.item() - 1e-4, (l0.item(), l1.item())
+    f1 = model.encode_text(args[0]).clone()
+    with torch.no_grad():
+        model.clip.text_projection.mul_(0.5)                            # any in-place write through a view
+    assert torch.allclose(model.encode_text(args[0]), 0.5 * f1, atol=2e-2 * f1.abs().max().item())
+    assert not model.tower.is_stale()                                   # and an unchanged model is not refreshed again
+
+
+def test_validation_uses_exact_tower_and_keeps_pending_backward(golden_dir):
+    """validate.compute_*_val_metrics as the reference's loop calls them (no torch.no_grad() around the call,
+    train_negplus.py:128): CIRPlus(exact_eval=True) must take its fp32 tower there, and the training activations of
+    a forward whose backward is still pending must survive the validation pass."""
+    _need_gpu()
+    from spn4cir_amd import validate
+    from spn4cir_amd.models import CIRPlus
+    z, sd = _tiny_sd(golden_dir)
+    model = CIRPlus(sd, device=torch.device("cuda"), exact_eval=True)
+    ids = torch.from_numpy(z["ids"])
+    D = model.output_dim
+    g = torch.Generator().manual_seed(5)
+    gallery = torch.randn(40, D, generator=g).cuda()
+    ridx = torch.arange(ids.shape[0]).cuda()
+    exact = model.tower.forward_exact(ids.cuda().to(torch.int32).contiguous())
+    pred = validate._predict(model, ids, ridx, gallery)                 # grad mode is ON here
+    want = torch.nn.functional.normalize(gallery[ridx] + exact)
+    assert (pred - want).abs().max() < 1e-6
+    bf = torch.nn.functional.normalize(gallery[ridx] + model.tower.forward(ids.cuda().to(torch.int32).contiguous()))
+    assert (bf - want).abs().max() > 1e-6                               # the bf16 tower is measurably different
+
+
+def test_out_of_range_indices_are_loud(golden_dir):
+    """refer_bank[refer_indexs] raises IndexError in the reference (models_negplus.py:133).  Host index tensors raise
+    the same here; device tensors are never dereferenced out of range - the affected rows (and the loss) turn NaN."""
+    _need_gpu()
+    from spn4cir_amd import ops
+    model, args, s = _loop_model(golden_dir)
+    ids, idx, tgt, ref = args
+    bad = ref.clone()
+    bad[1] = model.refer_bank.shape[0]
+    with pytest.raises(IndexError):
+        model.forward(ids, idx, tgt, bad)
+    badt = tgt.clone()
+    badt[0] = -1
+    with pytest.raises(IndexError):
+        model.forward(ids, idx, badt, ref)
+    text = torch.randn(4, 64, device="cuda")
+    bank = torch.randn(10, 64, device="cuda")
+    ridx = torch.tensor([0, 10, 9, -1], device="cuda")
+    q, qb, inv = ops.combine_l2norm_fwd(bank, ridx, text)
+    assert torch.isnan(q[1]).all() and torch.isnan(q[3]).all() and torch.isnan(inv[[1, 3]]).all()
+    assert torch.isnan(qb[1, :64].float()).all() and not qb[1, 64:].float().any()
+    want = torch.nn.functional.normalize(bank[[0, 9]] + text[[0, 2]])
+    assert torch.allclose(q[[0, 2]], want, atol=1e-6)

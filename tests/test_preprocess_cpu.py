@@ -49,3 +49,21 @@ def test_host_tables_reproduce_pillow(w, h):
     src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     ref = op.targetpad_transform_u8(Image.fromarray(src), 1.25, 224)
     assert np.array_equal(_replay(src, 1.25, 224), ref)
+
+
+def test_native_mode_order_matters_and_host_fallback_matches_oracle():
+    """Why TargetPadTransform keeps Pillow's own path for non-RGB modes: for a palettised image, convert-then-resize
+    (bicubic on RGB) differs from the reference's resize-then-convert (NEAREST on indices).  The host half of the
+    fallback (`_native_mode_u8`) is checked against the oracle here; the device half in test_preprocess_gpu.py."""
+    import numpy as np
+    from PIL import Image
+    from oracle import preprocess as op
+    from spn4cir_amd.preprocess import TargetPadTransform
+    rng = np.random.default_rng(3)
+    rgb = Image.fromarray(rng.integers(0, 256, (150, 310, 3), dtype=np.uint8))
+    tf = TargetPadTransform(1.25, 224, device="cpu")
+    for img in (rgb.quantize(colors=32), rgb.convert("RGBA"), rgb.convert("1")):
+        ref = op.targetpad_transform_u8(img, 1.25, 224)
+        assert np.array_equal(tf._native_mode_u8(img), ref)
+    pal = rgb.quantize(colors=32)
+    assert not np.array_equal(op.targetpad_transform_u8(pal, 1.25, 224), op.targetpad_transform_u8(pal.convert("RGB"), 1.25, 224))

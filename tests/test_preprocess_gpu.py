@@ -28,3 +28,31 @@ def test_targetpad_transform_bit_exact(w, h, ratio, dim):
     assert np.array_equal(u8.cpu().numpy(), op.targetpad_transform_u8(img, ratio, dim))
     assert torch.equal(out.cpu(), op.targetpad_transform(img, ratio, dim))
     assert torch.equal(tf(img).cpu(), out.cpu())          # PIL input path
+
+
+@pytest.mark.parametrize("mode", ["P", "RGBA", "LA", "1", "L"])
+def test_targetpad_transform_non_rgb_modes(mode):
+    """Palettised / alpha / bilevel PNG-style inputs: the reference pads, resizes and crops in the image's own mode and
+    converts to RGB afterwards (data_utils.py:91-95) - Pillow resamples 'P' and '1' with NEAREST and premultiplies alpha."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import preprocess as op
+    from spn4cir_amd.preprocess import TargetPadTransform
+    rng = np.random.default_rng(7)
+    w, h = 410, 260                                       # ratio 1.58 >= 1.25: padded
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (127 + 120 * np.sin(xx / 9.0)[..., None] * np.cos(yy / 13.0)[..., None] * np.array([1, -1, 0.5])).clip(0, 255)
+    rgb = Image.fromarray((base + rng.integers(-30, 31, (h, w, 3))).clip(0, 255).astype(np.uint8))
+    if mode == "P":
+        img = rgb.quantize(colors=64)
+    elif mode in ("RGBA", "LA"):
+        alpha = Image.fromarray((255 * (xx + yy) / (w + h)).astype(np.uint8))
+        img = rgb.convert(mode[:-1])
+        img.putalpha(alpha)
+    else:
+        img = rgb.convert(mode)
+    assert img.mode == mode
+    tf = TargetPadTransform(1.25, 224)
+    out, u8 = tf(img, return_uint8=True)
+    assert np.array_equal(u8.cpu().numpy(), op.targetpad_transform_u8(img, 1.25, 224))
+    assert torch.equal(out.cpu(), op.targetpad_transform(img, 1.25, 224))
