@@ -14,6 +14,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#include "gemm3_nt_clobbers.inc"
 
 namespace spn {
 
@@ -81,6 +82,221 @@ __device__ __forceinline__ void nt2_stage_one(__amdgpu_buffer_rsrc_t rs, char* s
 template <int BKT>
 __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * (BKT * 2) + (nt2_swz<BKT>(r, c) << 4));
+}
+
+// Epilogue shared by the NT kernels.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3,
+// the 4 consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
+// Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
+// first staged through LDS (fp32, 16-B units XOR-swizzled by row) and the epilogue math + all
+// global traffic run row-major: one wave instruction = one or two whole rows, fully coalesced.
+template <int BM, int BN, int WM, int WN, int LDS_BYTES, int MODE, int ACT>
+__device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem, int M, int N, int m0,
+                                            int n0, int wr, int wc, int wid, int lane, const GemmEpilogue& ep) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
+    if (!ep.direct_store) {
+        constexpr int CR0 = LDS_BYTES / (BN * 4);
+        constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;     // rows per staging pass
+        constexpr int NCH = (BM + CHUNK - 1) / CHUNK;
+        // a lane owns 8 consecutive columns of a row: bf16 traffic moves 16 B per lane (the store path is
+        // issue-bound, so half as many, twice as wide instructions), fp32 traffic as two 16-B accesses
+        constexpr int LPR = BN / 8, RPI = 64 / LPR;                 // lanes per row, rows per wave instruction
+        static_assert(LPR <= 64 && 64 % LPR == 0, "row mapping");
+        float* sC = (float*)smem;
+        const int u = lane % LPR, n = n0 + u * 8;
+        const bool hi = n + 4 < N;                                  // N % 4 == 0: each half is all in or all out
+        const bool wide = hi && (ep.ldc % 8 == 0);
+        f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
+        if (ep.bias && n < N) bias_lo = *(const f32x4*)(ep.bias + n);
+        if (ep.bias && hi) bias_hi = *(const f32x4*)(ep.bias + n + 4);
+        constexpr int ITERS = (CHUNK + NW * RPI - 1) / (NW * RPI);   // rows of a chunk handled by one lane
+        for (int ch = 0; ch < NCH; ++ch) {
+            // the epilogue's global READS of this chunk (pre-activation / residual) are issued first, so that their
+            // latency hides behind the LDS staging of the accumulators instead of stalling every row
+            [[maybe_unused]] bf16x8 pf_aux[ITERS];
+            [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
+            if constexpr (MODE == GEMM_DACT || MODE == GEMM_RESID) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int rr = wid * RPI + lane / LPR + it * NW * RPI;
+                    const int m = m0 + ch * CHUNK + rr;
+                    const bool ok = rr < CHUNK && m < M && n < N;
+                    if constexpr (MODE == GEMM_DACT) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf_aux[it][e] = (bf16_t)0.f;
+                        if (ok) {
+                            const size_t o = (size_t)m * ep.ldc + n;
+                            if (wide) {
+                                pf_aux[it] = *(const bf16x8*)(ep.aux_in + o);
+                            } else {
+                                const bf16x4 p0 = *(const bf16x4*)(ep.aux_in + o);
+                                bf16x4 p1 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                                if (hi) p1 = *(const bf16x4*)(ep.aux_in + o + 4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { pf_aux[it][e] = p0[e]; pf_aux[it][4 + e] = p1[e]; }
+                            }
+                        }
+                    } else {
+                        pf_r0[it] = f32x4{0, 0, 0, 0};
+                        pf_r1[it] = f32x4{0, 0, 0, 0};
+                        if (ok) {
+                            const float* rp = ep.resid + (size_t)m * ep.ldr + n;
+                            pf_r0[it] = *(const f32x4*)rp;
+                            if (hi) pf_r1[it] = *(const f32x4*)(rp + 4);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // operand tiles (or the previous chunk) are no longer read
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int rl = wr * TM + i * 32 + (lane & 31);
+                if (rl / CHUNK != ch) continue;
+                const int r = rl - ch * CHUNK;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int rr = wid * RPI + lane / LPR + it * NW * RPI;
+                const int m = m0 + ch * CHUNK + rr;
+                if (rr >= CHUNK || m >= M) continue;          // wave-uniform per row pair for the shuffles below
+                if (MODE != GEMM_BANKSTATS && n >= N) continue;
+                f32x4 v0 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
+                f32x4 v1 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
+                if constexpr (MODE == GEMM_BANKSTATS) {
+                    // this lane's 8 logits of row m -> {max, sum exp, sum, label logit}, merged over the LPR lanes
+                    // that share the row (consecutive lanes: xor shuffles below LPR stay inside the row)
+                    const int64_t lab = ep.bs_labels[m] - (int64_t)ep.bs_m_begin;
+                    float mx = -INFINITY, sl = 0.f, lv = -INFINITY, l = 0.f;
+                    float z[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (e < 4 ? v0[e] : v1[e - 4]) * ep.bs_inv_tau;
+                        const bool ok = n + e < N;
+                        z[e] = ok ? x : -INFINITY;
+                        if (ok) {
+                            mx = fmaxf(mx, x);
+                            sl += x;
+                            if ((int64_t)(n + e) == lab) lv = x;
+                        }
+                    }
+                    if (mx > -INFINITY) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) l += __expf(z[e] - mx);
+                    }
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) {
+                        const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
+                        const float mn = fmaxf(mx, m2);
+                        if (mn > -INFINITY) l = l * __expf(mx - mn) + l2 * __expf(m2 - mn);
+                        mx = mn;
+                        sl += __shfl_xor(sl, off, 64);
+                        lv = fmaxf(lv, __shfl_xor(lv, off, 64));
+                    }
+                    if (u == 0) {
+                        const int tile_n = n0 / BN;
+                        *(f32x4*)(ep.bs_out + ((size_t)tile_n * M + m) * 4) = f32x4{mx, l, sl, lv};
+                    }
+                    continue;
+                }
+                v0 = v0 * ep.alpha + bias_lo;
+                v1 = v1 * ep.alpha + bias_hi;
+                const size_t o = (size_t)m * ep.ldc + n;
+                auto pack8 = [](f32x4 x, f32x4 y) {
+                    bf16x8 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+                    return p;
+                };
+                auto store_bf16 = [&](bf16_t* dst, f32x4 x, f32x4 y) {
+                    if (wide) {
+                        *(bf16x8*)(dst + o) = pack8(x, y);
+                    } else {
+                        bf16x4 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+                        *(bf16x4*)(dst + o) = p;
+                        if (hi) {
+                            bf16x4 q = {f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+                            *(bf16x4*)(dst + o + 4) = q;
+                        }
+                    }
+                };
+                if constexpr (MODE == GEMM_STORE) {
+                    if constexpr (ACT != ACT_NONE) {
+                        if (ep.aux_out) store_bf16(ep.aux_out, v0, v1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                        }
+                    }
+                } else if constexpr (MODE == GEMM_RESID) {
+                    v0 += pf_r0[it];
+                    v1 += pf_r1[it];
+                } else if constexpr (MODE == GEMM_DACT) {
+                    const bf16x8 p = pf_aux[it];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
+                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
+                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
+                    }
+                }
+                if (ep.out_f32) {
+                    *(f32x4*)(ep.out_f32 + o) = v0;
+                    if (hi) *(f32x4*)(ep.out_f32 + o + 4) = v1;
+                }
+                if (ep.out_bf16) store_bf16(ep.out_bf16, v0, v1);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wr * TM + i * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= N) continue;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                v *= ep.alpha;
+                if (ep.bias) v += *(const f32x4*)(ep.bias + n);
+                const size_t o = (size_t)m * ep.ldc + n;
+                if constexpr (MODE == GEMM_STORE) {
+                    if constexpr (ACT != ACT_NONE) {
+                        if (ep.aux_out) {
+                            bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                            *(bf16x4*)(ep.aux_out + o) = p;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                    }
+                } else if constexpr (MODE == GEMM_RESID) {
+                    v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
+                } else if constexpr (MODE == GEMM_DACT) {
+                    const bf16x4 p = *(const bf16x4*)(ep.aux_in + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = bf2f(p[e]);
+                        v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                    }
+                }
+                if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
+                if (ep.out_bf16) {
+                    bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *(bf16x4*)(ep.out_bf16 + o) = p;
+                }
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
@@ -303,210 +519,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         if (t == 12345.678f && ep.out_f32) ep.out_f32[0] = t;
         return;
     }
-    if (!ep.direct_store) {
-        constexpr int LDS_BYTES = STAGES * STAGE;
-        constexpr int CR0 = LDS_BYTES / (BN * 4);
-        constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;     // rows per staging pass
-        constexpr int NCH = (BM + CHUNK - 1) / CHUNK;
-        // a lane owns 8 consecutive columns of a row: bf16 traffic moves 16 B per lane (the store path is
-        // issue-bound, so half as many, twice as wide instructions), fp32 traffic as two 16-B accesses
-        constexpr int LPR = BN / 8, RPI = 64 / LPR;                 // lanes per row, rows per wave instruction
-        static_assert(LPR <= 64 && 64 % LPR == 0, "row mapping");
-        float* sC = (float*)smem;
-        const int u = lane % LPR, n = n0 + u * 8;
-        const bool hi = n + 4 < N;                                  // N % 4 == 0: each half is all in or all out
-        const bool wide = hi && (ep.ldc % 8 == 0);
-        f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
-        if (ep.bias && n < N) bias_lo = *(const f32x4*)(ep.bias + n);
-        if (ep.bias && hi) bias_hi = *(const f32x4*)(ep.bias + n + 4);
-        constexpr int ITERS = (CHUNK + NW * RPI - 1) / (NW * RPI);   // rows of a chunk handled by one lane
-        for (int ch = 0; ch < NCH; ++ch) {
-            // the epilogue's global READS of this chunk (pre-activation / residual) are issued first, so that their
-            // latency hides behind the LDS staging of the accumulators instead of stalling every row
-            [[maybe_unused]] bf16x8 pf_aux[ITERS];
-            [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
-            if constexpr (MODE == GEMM_DACT || MODE == GEMM_RESID) {
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int rr = wid * RPI + lane / LPR + it * NW * RPI;
-                    const int m = m0 + ch * CHUNK + rr;
-                    const bool ok = rr < CHUNK && m < M && n < N;
-                    if constexpr (MODE == GEMM_DACT) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf_aux[it][e] = (bf16_t)0.f;
-                        if (ok) {
-                            const size_t o = (size_t)m * ep.ldc + n;
-                            if (wide) {
-                                pf_aux[it] = *(const bf16x8*)(ep.aux_in + o);
-                            } else {
-                                const bf16x4 p0 = *(const bf16x4*)(ep.aux_in + o);
-                                bf16x4 p1 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                                if (hi) p1 = *(const bf16x4*)(ep.aux_in + o + 4);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { pf_aux[it][e] = p0[e]; pf_aux[it][4 + e] = p1[e]; }
-                            }
-                        }
-                    } else {
-                        pf_r0[it] = f32x4{0, 0, 0, 0};
-                        pf_r1[it] = f32x4{0, 0, 0, 0};
-                        if (ok) {
-                            const float* rp = ep.resid + (size_t)m * ep.ldr + n;
-                            pf_r0[it] = *(const f32x4*)rp;
-                            if (hi) pf_r1[it] = *(const f32x4*)(rp + 4);
-                        }
-                    }
-                }
-            }
-            __syncthreads();   // operand tiles (or the previous chunk) are no longer read
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int rl = wr * TM + i * 32 + (lane & 31);
-                if (rl / CHUNK != ch) continue;
-                const int r = rl - ch * CHUNK;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
-                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
-                    }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int rr = wid * RPI + lane / LPR + it * NW * RPI;
-                const int m = m0 + ch * CHUNK + rr;
-                if (rr >= CHUNK || m >= M) continue;          // wave-uniform per row pair for the shuffles below
-                if (MODE != GEMM_BANKSTATS && n >= N) continue;
-                f32x4 v0 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
-                f32x4 v1 = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
-                if constexpr (MODE == GEMM_BANKSTATS) {
-                    // this lane's 8 logits of row m -> {max, sum exp, sum, label logit}, merged over the LPR lanes
-                    // that share the row (consecutive lanes: xor shuffles below LPR stay inside the row)
-                    const int64_t lab = ep.bs_labels[m] - (int64_t)ep.bs_m_begin;
-                    float mx = -INFINITY, sl = 0.f, lv = -INFINITY, l = 0.f;
-                    float z[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (e < 4 ? v0[e] : v1[e - 4]) * ep.bs_inv_tau;
-                        const bool ok = n + e < N;
-                        z[e] = ok ? x : -INFINITY;
-                        if (ok) {
-                            mx = fmaxf(mx, x);
-                            sl += x;
-                            if ((int64_t)(n + e) == lab) lv = x;
-                        }
-                    }
-                    if (mx > -INFINITY) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) l += __expf(z[e] - mx);
-                    }
-#pragma unroll
-                    for (int off = LPR / 2; off > 0; off >>= 1) {
-                        const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
-                        const float mn = fmaxf(mx, m2);
-                        if (mn > -INFINITY) l = l * __expf(mx - mn) + l2 * __expf(m2 - mn);
-                        mx = mn;
-                        sl += __shfl_xor(sl, off, 64);
-                        lv = fmaxf(lv, __shfl_xor(lv, off, 64));
-                    }
-                    if (u == 0) {
-                        const int tile_n = n0 / BN;
-                        *(f32x4*)(ep.bs_out + ((size_t)tile_n * M + m) * 4) = f32x4{mx, l, sl, lv};
-                    }
-                    continue;
-                }
-                v0 = v0 * ep.alpha + bias_lo;
-                v1 = v1 * ep.alpha + bias_hi;
-                const size_t o = (size_t)m * ep.ldc + n;
-                auto pack8 = [](f32x4 x, f32x4 y) {
-                    bf16x8 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
-                    return p;
-                };
-                auto store_bf16 = [&](bf16_t* dst, f32x4 x, f32x4 y) {
-                    if (wide) {
-                        *(bf16x8*)(dst + o) = pack8(x, y);
-                    } else {
-                        bf16x4 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
-                        *(bf16x4*)(dst + o) = p;
-                        if (hi) {
-                            bf16x4 q = {f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
-                            *(bf16x4*)(dst + o + 4) = q;
-                        }
-                    }
-                };
-                if constexpr (MODE == GEMM_STORE) {
-                    if constexpr (ACT != ACT_NONE) {
-                        if (ep.aux_out) store_bf16(ep.aux_out, v0, v1);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
-                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
-                        }
-                    }
-                } else if constexpr (MODE == GEMM_RESID) {
-                    v0 += pf_r0[it];
-                    v1 += pf_r1[it];
-                } else if constexpr (MODE == GEMM_DACT) {
-                    const bf16x8 p = pf_aux[it];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
-                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
-                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
-                    }
-                }
-                if (ep.out_f32) {
-                    *(f32x4*)(ep.out_f32 + o) = v0;
-                    if (hi) *(f32x4*)(ep.out_f32 + o + 4) = v1;
-                }
-                if (ep.out_bf16) store_bf16(ep.out_bf16, v0, v1);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wr * TM + i * 32 + (lane & 31);
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
-                if (n >= N) continue;
-                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                v *= ep.alpha;
-                if (ep.bias) v += *(const f32x4*)(ep.bias + n);
-                const size_t o = (size_t)m * ep.ldc + n;
-                if constexpr (MODE == GEMM_STORE) {
-                    if constexpr (ACT != ACT_NONE) {
-                        if (ep.aux_out) {
-                            bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                            *(bf16x4*)(ep.aux_out + o) = p;
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
-                    }
-                } else if constexpr (MODE == GEMM_RESID) {
-                    v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
-                } else if constexpr (MODE == GEMM_DACT) {
-                    const bf16x4 p = *(const bf16x4*)(ep.aux_in + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = bf2f(p[e]);
-                        v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
-                    }
-                }
-                if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
-                if (ep.out_bf16) {
-                    bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *(bf16x4*)(ep.out_bf16 + o) = p;
-                }
-            }
-        }
-    }
+    nt_epilogue<BM, BN, WM, WN, STAGES * STAGE, MODE, ACT>(acc, smem, M, N, m0, n0, wr, wc, wid, lane, ep);
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
@@ -524,6 +537,271 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, st, A, B, M, N, K, lda, ldb, ep);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
+}
+
+// Epilogue of gemm_nt3: FULL 256x256 tiles only (the launcher routes anything else to gemm_nt2), straight-line code, and
+// wave-private: wave (wr, wc) owns the 128x128 sub-tile rows wr*128.., columns wc*128.. and turns it row-major through
+// its OWN 32 KB of LDS, so after the one barrier that ends the k loop no wave waits for another - with one wave per SIMD
+// every exposed latency is idle time (the shared, branchy epilogue of gemm_nt2 took 15 k cycles per tile here, as long
+// as the k loop of a K = 768 product; 30 k with the activation copy).
+//   bf16 results (GEMM_STORE): bias / activation in the MFMA layout, packed to bf16, ONE pass over 128 rows x 256 B:
+//     8-byte ds_write of a lane's 4 columns, 16-byte ds_read + 16-byte global store of whole 256-B row segments.
+//   fp32 staging (GEMM_RESID, GEMM_DACT: the row-major operand - residual stream / pre-activation - is loaded coalesced
+//     and applied after the transposition): two passes of 64 rows x 512 B.
+// 16-byte units are XOR-swizzled by the row, conflict-free for the column-wise writes and the row-wise reads.
+template <int MODE, int ACT>
+__device__ __forceinline__ void nt3_epilogue(f32x16 (&acc)[4][4], char* smem, int m0, int n0, int wr, int wc, int wid,
+                                             int lane, const GemmEpilogue& ep) {
+    char* sW = smem + wid * 32768;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int mw = m0 + wr * 128, nw = n0 + wc * 128;          // first row / column of this wave's sub-tile
+    __syncthreads();                                           // every wave is done with the operand tiles
+    if constexpr (MODE == GEMM_STORE) {
+        // bias of this lane's columns nw + j*32 + 8g + 4*half + 0..3
+        f32x4 bias[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bias[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ep.bias) bias[j][g] = *(const f32x4*)(ep.bias + nw + j * 32 + 8 * g + 4 * half);
+            }
+        constexpr int PASSES = ACT != ACT_NONE ? 2 : 1;        // pass 0 of an activation GEMM: the pre-activation copy
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            bf16_t* dst = (ACT != ACT_NONE && pass == 0) ? ep.aux_out : ep.out_bf16;
+            if (dst == nullptr) continue;                      // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        v = v * ep.alpha + bias[j][g];
+                        if (ACT != ACT_NONE && pass == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                        }
+                        const bf16x4 pk = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        *(bf16x4*)(sW + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4) + half * 8) = pk;
+                    }
+            }
+            // row-major: 16 lanes x 16 B = one 256-B row segment, 4 rows per instruction
+            const int u = lane & 15, rq = lane >> 4;
+            bf16x8 t[32];
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int r = it * 4 + rq;
+                t[it] = *(const bf16x8*)(sW + r * 256 + ((u ^ (r & 15)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const int r = it * 4 + rq;
+                *(bf16x8*)(dst + (size_t)(mw + r) * ep.ldc + nw + u * 8) = t[it];
+            }
+        }
+    } else {
+        // fp32 staging, 2 passes of 64 rows: lane l of the read-back owns columns nw + 4*(l&31) .. +3 of rows 2*it + (l>>5)
+        const int u = lane & 31, rh = lane >> 5;
+        const int n = nw + u * 4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (ep.bias) bias = *(const f32x4*)(ep.bias + n);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = c * 2 + ii;
+                const int r = ii * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *(f32x4*)(sW + r * 512 + (((j * 8 + 2 * g + half) ^ (r & 31)) << 4)) = v;
+                    }
+            }
+            // batches of 8 row pairs: the row-major operand of the next batch is in flight while this one is finished
+            constexpr int NB = 4, PER = 8;
+            [[maybe_unused]] f32x4 rs[2][PER];
+            [[maybe_unused]] bf16x4 ax[2][PER];
+            auto fetch = [&](int b, int slot) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int r = (b * PER + q) * 2 + rh;
+                    const size_t m = (size_t)(mw + c * 64 + r);
+                    if constexpr (MODE == GEMM_RESID) rs[slot][q] = *(const f32x4*)(ep.resid + m * ep.ldr + n);
+                    if constexpr (MODE == GEMM_DACT) ax[slot][q] = *(const bf16x4*)(ep.aux_in + m * ep.ldc + n);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b + 1 < NB) fetch(b + 1, (b + 1) & 1);
+                f32x4 v[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int r = (b * PER + q) * 2 + rh;
+                    v[q] = *(const f32x4*)(sW + r * 512 + ((u ^ (r & 31)) << 4));
+                }
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    const int r = (b * PER + q) * 2 + rh;
+                    const size_t m = (size_t)(mw + c * 64 + r);
+                    f32x4 x = v[q] * ep.alpha + bias;
+                    if constexpr (MODE == GEMM_RESID) x += rs[b & 1][q];
+                    if constexpr (MODE == GEMM_DACT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float p = bf2f(ax[b & 1][q][e]);
+                            x[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(p) : gelu_erf_grad_f(p);
+                        }
+                    }
+                    if (ep.out_f32) *(f32x4*)(ep.out_f32 + m * ep.ldc + n) = x;
+                    if (ep.out_bf16) {
+                        const bf16x4 pk = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+                        *(bf16x4*)(ep.out_bf16 + m * ep.ldc + n) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- NT, third generation
+// gemm_nt3: 256x256x64 tile, FOUR waves (2 x 2, one per SIMD, wave tile 128x128 = all 256 AGPRs), hand-scheduled main
+// loop (tools/gen_gemm3.py -> gemm3_nt_loop.inc, one inline-asm statement: DMA, fragment reads and MFMA interleaved by
+// hand, one barrier per k tile).  Same LDS image (nt2_swz) and the same epilogue as gemm_nt2.
+template <int MODE, int ACT, int VAR>
+__global__ __launch_bounds__(256, 1) void gemm_nt3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          int M, int N, int K, int lda, int ldb, GemmEpilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint64_t dbg_t0 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_n = (N + 255) / 256;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (bid / tiles_n) * 256, n0 = (bid % tiles_n) * 256;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero16();
+    const int nk = K / 64;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)LDS_PTR(smem);
+    uint32_t cyc, ticks;
+    const uint64_t dbg_t1 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+#define SPN_NT3_OPERANDS                                                                                              \
+        : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),       \
+          "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),       \
+          "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3]), "=s"(cyc), "=s"(ticks)                  \
+        : "v"(tid), "s"(rsA), "s"(rsB), "s"(m0), "s"(n0), "s"(lda), "s"(ldb), "s"(nk), "s"(lds_base)                  \
+        : SPN_GEMM3_CLOBBERS
+    if constexpr (VAR == 0) {
+        asm volatile(
+#include "gemm3_nt_loop.inc"
+            SPN_NT3_OPERANDS);
+    } else if constexpr (VAR == 1) {
+        asm volatile(
+#include "gemm3_nt_loop_nodma.inc"
+            SPN_NT3_OPERANDS);
+    } else if constexpr (VAR == 2) {
+        asm volatile(
+#include "gemm3_nt_loop_noread.inc"
+            SPN_NT3_OPERANDS);
+    } else if constexpr (VAR == 3) {
+        asm volatile(
+#include "gemm3_nt_loop_nobar.inc"
+            SPN_NT3_OPERANDS);
+    } else {
+        asm volatile(
+#include "gemm3_nt_loop_mfma.inc"
+            SPN_NT3_OPERANDS);
+    }
+#undef SPN_NT3_OPERANDS
+    // SPN_GEMM_DBG bit 32: clock probe of the k loop of the last tile (same convention as gemm_nt2_kernel)
+    if ((ep.dbg & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
+        uint32_t* o = (uint32_t*)ep.out_bf16;
+        o[0] = cyc;
+        o[1] = ticks;
+        return;
+    }
+    const uint64_t dbg_t2 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    nt3_epilogue<MODE, ACT>(acc, smem, m0, n0, wr, wc, wid, lane, ep);
+    // SPN_GEMM_DBG bit 64: phase times of the first block (shader cycles): setup, asm statement (prologue DMA + k loop),
+    // epilogue, and the k loop alone - written over the first 16 bytes of the fp32 / bf16 output
+    if ((ep.dbg & 64) && blockIdx.x == 0 && tid == 0) {
+        const uint64_t t3 = __builtin_readcyclecounter();
+        uint32_t* o = ep.out_f32 ? (uint32_t*)ep.out_f32 : (uint32_t*)ep.out_bf16;
+        o[0] = (uint32_t)(dbg_t1 - dbg_t0);
+        o[1] = (uint32_t)(dbg_t2 - dbg_t1);
+        o[2] = (uint32_t)(t3 - dbg_t2);
+        o[3] = cyc;
+    }
+}
+
+template <int MODE, int ACT, int VAR = 0>
+static int launch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
+                      hipStream_t st) {
+    constexpr int LDS = 131072;
+    auto kern = gemm_nt3_kernel<MODE, ACT, VAR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS, st, A, B, M, N, K, lda, ldb, ep);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// gemm_nt3 handles full 256x256 tiles with 16-byte aligned rows; everything else stays on gemm_nt2
+static bool nt3_ok(int M, int N, int mode, const GemmEpilogue& ep) {
+    if (M % 256 || N % 256 || ep.ldc % 8 || (ep.resid && ep.ldr % 4)) return false;
+    if (mode == GEMM_STORE) return ep.out_f32 == nullptr && ep.out_bf16 != nullptr;      // bf16 staging
+    return mode == GEMM_RESID || mode == GEMM_DACT;
+}
+
+static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
+                        const GemmEpilogue& ep, hipStream_t st) {
+#define SPN_NT3(MODE_, ACT_) launch_nt3<MODE_, ACT_>(A, B, M, N, K, lda, ldb, ep, st)
+    // SPN_NT3_VAR (plain-store kernel only): ablation variants of the main loop, results are wrong by design -
+    // 1 no DMA, 2 no fragment reads, 3 no barrier, 4 MFMA only
+    static const int var = [] {
+        const char* e = getenv("SPN_NT3_VAR");
+        return e ? atoi(e) : 0;
+    }();
+    if (mode == GEMM_STORE && ep.act == ACT_NONE && var) {
+        switch (var) {
+            case 1: return launch_nt3<GEMM_STORE, ACT_NONE, 1>(A, B, M, N, K, lda, ldb, ep, st);
+            case 2: return launch_nt3<GEMM_STORE, ACT_NONE, 2>(A, B, M, N, K, lda, ldb, ep, st);
+            case 3: return launch_nt3<GEMM_STORE, ACT_NONE, 3>(A, B, M, N, K, lda, ldb, ep, st);
+            default: return launch_nt3<GEMM_STORE, ACT_NONE, 4>(A, B, M, N, K, lda, ldb, ep, st);
+        }
+    }
+    if (mode == GEMM_STORE) {
+        if (ep.act == ACT_NONE) return SPN_NT3(GEMM_STORE, ACT_NONE);
+        if (ep.act == ACT_QUICKGELU) return SPN_NT3(GEMM_STORE, ACT_QUICKGELU);
+        if (ep.act == ACT_GELU_ERF) return SPN_NT3(GEMM_STORE, ACT_GELU_ERF);
+        return SPN_ERR_ARG;
+    }
+    if (mode == GEMM_RESID) {
+        if (!ep.resid || !ep.out_f32) return SPN_ERR_ARG;
+        return SPN_NT3(GEMM_RESID, ACT_NONE);
+    }
+    if (mode == GEMM_DACT) {
+        if (!ep.aux_in) return SPN_ERR_ARG;
+        if (ep.act == ACT_QUICKGELU) return SPN_NT3(GEMM_DACT, ACT_QUICKGELU);
+        if (ep.act == ACT_GELU_ERF) return SPN_NT3(GEMM_DACT, ACT_GELU_ERF);
+    }
+#undef SPN_NT3
+    return SPN_ERR_ARG;
 }
 
 static bool nt_phased() {
@@ -608,6 +886,9 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     e2.dbg = dbg;
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
     switch (gemm_cfg()) {
+        case 7:                                                                   // 4 waves, hand-scheduled loop
+            if (nt3_ok(M, N, mode, e2)) return dispatch_nt3(A, B, M, N, K, lda, ldb, mode, e2, st);
+            return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
             if (nt_phased()) return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);

@@ -626,3 +626,21 @@ def test_c_abi_error_codes(ops):
         assert text.split()[0] in L.spn_error_string(code).decode()
     # the library is still healthy afterwards
     assert rel_err(ops.gemm_nt(dev(bf(torch.eye(128))), dev(bf(torch.eye(128))), out_dtype=torch.float32), torch.eye(128)) < 1e-6
+
+
+def test_gemm_nt3_hand_scheduled_kernel():
+    """The experimental 4-wave NT GEMM with the generated inline-asm main loop (SPN_GEMM_CFG=7, tools/gen_gemm3.py):
+    every epilogue mode against a torch fp32 product, incl. shapes that fall back to gemm_nt2 (partial tiles) and
+    odd / even k-tile counts (the peeled loop tails).  Own process: the configuration is read once per process."""
+    import os, re, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPN_GEMM_CFG="7")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm3_check.py"), "child", "check"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "check" in l]
+    assert len(lines) >= 6 * 2 * 7, out.stdout[-2000:]
+    bad = [l for l in lines if not re.search(r"bad elements 0$", l)]
+    assert not bad, "\n".join(bad[:10])
