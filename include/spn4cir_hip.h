@@ -63,6 +63,21 @@ int spn_gemm_tn_pair(const void* A1, const void* B1, int N1a, int N2a, float* C1
                      const void* B2, int N1b, int N2b, float* C2, float* colsum2, int Kr, void* ws, size_t ws_bytes,
                      void* stream);
 size_t spn_gemm_tn_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b);
+/* n (<= 48) such products over the same Kr rows in ONE launch WITHOUT split-K: every 256x256 output tile is computed by one
+ * workgroup that loops over all Kr rows and writes the final fp32 values (C_p overwritten; colsum_p = column sums of A_p
+ * or NULL); only the tiles of a last, mostly empty round of workgroups are split over the reduction (slabs in ws).  This is
+ * how a whole backward pass computes its weight gradients (spn_text_bwd_wgrad): autograd's per-layer dW = dY^T X products
+ * (train_negplus.py:121, loss.backward()) are independent of each other and of the data path, so they are deferred and
+ * batched - no partial sums through HBM, no per-problem reduction launches. */
+typedef struct {
+    const void* A;      /* bf16 [Kr, lda >= N1] */
+    const void* B;      /* bf16 [Kr, ldb >= N2] */
+    float* C;           /* fp32 [N1, ldc >= N2] */
+    float* colsum;      /* fp32 [N1] or NULL */
+    int N1, N2, lda, ldb, ldc;
+} spn_tn_problem;
+int spn_gemm_tn_grouped(const spn_tn_problem* problems, int n, int Kr, void* ws, size_t ws_bytes, void* stream);
+size_t spn_gemm_tn_grouped_workspace_bytes(int Kr);
 
 /* ---------------------------------------------------------------- elementwise / reductions */
 int spn_cast_f32_bf16(const float* x, void* y_bf16, size_t n, void* stream);

@@ -67,6 +67,19 @@ size_t spn_gemm_tn_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N
     return gemm_tn2_pair_workspace_bytes(Kr, N1a, N2a, N1b, N2b);
 }
 
+int spn_gemm_tn_grouped(const spn_tn_problem* problems, int n, int Kr, void* ws, size_t ws_bytes, void* stream) {
+    if (!problems || n <= 0 || n > TN_GROUP_MAX) return SPN_ERR_ARG;
+    TnProblem p[TN_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        p[i].A = CBF(problems[i].A); p[i].B = CBF(problems[i].B); p[i].C = problems[i].C; p[i].colsum = problems[i].colsum;
+        p[i].N1 = problems[i].N1; p[i].N2 = problems[i].N2; p[i].lda = problems[i].lda; p[i].ldb = problems[i].ldb;
+        p[i].ldc = problems[i].ldc;
+    }
+    return gemm_tn_grouped(p, n, Kr, (float*)ws, ws_bytes, ST(stream));
+}
+
+size_t spn_gemm_tn_grouped_workspace_bytes(int Kr) { return gemm_tn_grouped_workspace_bytes(Kr); }
+
 int spn_cast_f32_bf16(const float* x, void* y, size_t n, void* stream) { return cast_f32_bf16(x, BF(y), n, ST(stream)); }
 
 int spn_cast_transpose_f32_bf16(const float* x, void* y, void* yt, int rows, int cols, void* stream) {

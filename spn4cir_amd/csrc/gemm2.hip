@@ -385,9 +385,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // The MFMA builtins carry no side effects, so instruction selection is free to float them across
         // s_barrier; the empty volatile asm statements tie their operands (after the first barrier) and their
         // results (before the second) to the slot.
+// SPN_EXP_NOBAR (experiment builds, tools/build_variant.sh; results are racy): 1 = no barrier behind the MFMA section,
+// 2 = no barrier at all - prices the eight barriers per k tile
+#ifndef SPN_EXP_NOBAR
+#define SPN_EXP_NOBAR 0
+#endif
+#define SPN_SLOT_BAR(LVL) do { if (SPN_EXP_NOBAR < LVL) __builtin_amdgcn_s_barrier(); } while (0)
 #define SPN_SLOT_MFMA(I0, J, BREG)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        __builtin_amdgcn_s_barrier();                                                                   \
+        SPN_SLOT_BAR(2);                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
         asm volatile("" : "+v"(BREG[0]), "+v"(BREG[1]), "+v"(BREG[2]), "+v"(BREG[3]));                  \
         __builtin_amdgcn_s_setprio(1);                                                                  \
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                      \
         __builtin_amdgcn_s_setprio(0);                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                              \
-        __builtin_amdgcn_s_barrier();                                                                   \
+        SPN_SLOT_BAR(1);                                                                                \
         __builtin_amdgcn_sched_barrier(0);
         const bool dma = !(ep.dbg & 2);
         for (int kt = 0; kt < nk; ++kt) {
@@ -948,24 +954,12 @@ struct TnSecond {
     int tiles1;
 };
 
+// One output tile (m0, n0) of C = A^T B over the reduction rows [kb, ke): Cz / colsum_out already point at the slab this
+// workgroup owns (the final matrix, or its split-K partial).  Shared by the per-problem, paired and grouped launches.
 template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A_,
-                                                                            const bf16_t* __restrict__ B_, int Kr,
-                                                                            int N1_, int N2_, int lda_, int ldb_,
-                                                                            float* __restrict__ C_, int ldc_,
-                                                                            size_t split_stride_, int k_chunk,
-                                                                            float* __restrict__ colsum_out_,
-                                                                            TnSecond g2) {
-    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
-    const bool second = bid_all >= g2.tiles1;              // block-uniform
-    const bf16_t* A = second ? g2.A : A_;
-    const bf16_t* B = second ? g2.B : B_;
-    const int N1 = second ? g2.N1 : N1_, N2 = second ? g2.N2 : N2_;
-    const int lda = second ? g2.lda : lda_, ldb = second ? g2.ldb : ldb_;
-    float* C = second ? g2.C : C_;
-    const int ldc = second ? g2.ldc : ldc_;
-    const size_t split_stride = second ? g2.split_stride : split_stride_;
-    float* colsum_out = second ? g2.colsum_out : colsum_out_;
+__device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int Kr, int N1, int N2,
+                                         int lda, int ldb, float* __restrict__ Cz, int ldc, float* __restrict__ colsum_out,
+                                         int m0, int n0, int kb, int ke) {
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
@@ -973,11 +967,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
-    const int tiles_n = (N2 + BN - 1) / BN;
-    const int bid = second ? bid_all - g2.tiles1 : bid_all;
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-    const int kb = blockIdx.y * k_chunk;
-    const int ke = min(Kr, kb + k_chunk);
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)Kr * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)Kr * (uint32_t)ldb * 2u);
     const bool do_colsum = colsum_out != nullptr && n0 == 0 && wc == 0;
@@ -993,7 +982,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-    const int nk = (ke - kb + BK2 - 1) / BK2;
+// SPN_TN_EXP (experiment builds, tools/build_variant.sh; results are wrong): 1 = no epilogue (k loop only), 2 = no k loop
+#ifndef SPN_TN_EXP
+#define SPN_TN_EXP 0
+#endif
+    const int nk = SPN_TN_EXP == 2 ? 0 : (ke - kb + BK2 - 1) / BK2;
     auto stage = [&](int kt, int buf) {
         char* s = smem + buf * STAGE;
         tn2_stage<BM, GA>(rsA, s, kb + kt * BK2, lda, m0, wid, lane);
@@ -1095,13 +1088,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
         fill = fill == STAGES - 1 ? 0 : fill + 1;
     }
     }
-    float* Cz = C + (size_t)blockIdx.y * split_stride;
+    if (SPN_TN_EXP == 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+        if (t == 12345.678f) Cz[0] = t;
+        return;
+    }
     if (do_colsum && lane < 32) {
         // every row of the ones-product equals the column sum; lanes 0..31 hold columns m
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wr * TM + i * 32 + lane;
-            if (m < N1) colsum_out[(size_t)blockIdx.y * N1 + m] = accs[i][0];
+            if (m < N1) colsum_out[m] = accs[i][0];
         }
     }
     // split-K partials leave through LDS (same staging as gemm_nt2's epilogue): the MFMA layout would store 16 B
@@ -1142,6 +1145,125 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(co
                 *(f32x4*)o = v0;
                 if (hi) *(f32x4*)(o + 4) = v1;
             }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_kernel(const bf16_t* __restrict__ A_,
+                                                                            const bf16_t* __restrict__ B_, int Kr,
+                                                                            int N1_, int N2_, int lda_, int ldb_,
+                                                                            float* __restrict__ C_, int ldc_,
+                                                                            size_t split_stride_, int k_chunk,
+                                                                            float* __restrict__ colsum_out_,
+                                                                            TnSecond g2) {
+    // The dispatcher deals the workgroups of a 2-D grid to the XCDs by their LINEAR id (x + y * gridDim.x): the remap has to
+    // work on that id.  Logical order = split-major: the workgroups of one XCD at one time share a k range, so the A
+    // columns of an output row block and the B columns of an output column block are fetched into that XCD's L2 once.
+    const int lin_id = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int split_z = lin_id / (int)gridDim.x;
+    const int bid_all = lin_id - split_z * (int)gridDim.x;
+    const bool second = bid_all >= g2.tiles1;              // block-uniform
+    const bf16_t* A = second ? g2.A : A_;
+    const bf16_t* B = second ? g2.B : B_;
+    const int N1 = second ? g2.N1 : N1_, N2 = second ? g2.N2 : N2_;
+    const int lda = second ? g2.lda : lda_, ldb = second ? g2.ldb : ldb_;
+    float* C = second ? g2.C : C_;
+    const int ldc = second ? g2.ldc : ldc_;
+    const size_t split_stride = second ? g2.split_stride : split_stride_;
+    float* colsum_out = second ? g2.colsum_out : colsum_out_;
+    const int tiles_n = (N2 + BN - 1) / BN;
+    const int bid = second ? bid_all - g2.tiles1 : bid_all;
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int kb = split_z * k_chunk;
+    const int ke = min(Kr, kb + k_chunk);
+    tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(A, B, Kr, N1, N2, lda, ldb, C + (size_t)split_z * split_stride, ldc,
+                                            colsum_out ? colsum_out + (size_t)split_z * N1 : nullptr, m0, n0, kb, ke);
+}
+
+// ------------------------------------------------------------------------- grouped weight gradients, no split-K
+// Up to TN_GROUP_MAX problems C_p = A_p^T B_p over the SAME reduction length Kr in ONE launch.  The tiles of all
+// problems are numbered consecutively; the first `full` of them (a multiple of the CU count) are computed whole -
+// one workgroup loops over all Kr rows and writes its tile of the FINAL matrix (and the column sums of A) - and only
+// the `tail` tiles that would leave most CUs idle in a last round are split `tail_splits` ways over the reduction
+// into fp32 slabs that tn_tail_reduce_kernel folds.  Against one split-K launch per problem (36 tiles x 7 splits, 64 MB of
+// slabs written and read back per launch, 3 launches + 4 reductions per transformer layer) a whole backward pass becomes one
+// launch whose k loops are 308 k tiles long.
+struct TnGroup {
+    TnProblem p[TN_GROUP_MAX];
+    int tile_begin[TN_GROUP_MAX + 1];   // prefix sums of the 256x256 tile counts
+    int n;
+    int full, tail, tail_splits, k_chunk;   // tiles [0, full) unsplit; [full, full + tail) split over the reduction
+    float* slabs;                            // [tail_splits][tail][256*256] partial tiles, then [tail_splits][tail][256] column sums
+};
+
+__device__ __forceinline__ int tn_group_find(const TnGroup& g, int tile) {
+    int p = 0;
+    while (p + 1 < g.n && tile >= g.tile_begin[p + 1]) ++p;
+    return p;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_group_kernel(const TnGroup g, int Kr) {
+    // XCD-aware order, applied to the two ranges SEPARATELY (g.full is a multiple of the CU count, so a block's XCD is
+    // blockIdx % 8 in both): whole tiles and tail slices differ in length by the split factor, and remapping the grid as
+    // one range would hand some XCDs only slices and others a round more of whole tiles.
+    const bool whole = (int)blockIdx.x < g.full;
+    int tile, z = 0;
+    if (whole) {
+        tile = xcd_remap(blockIdx.x, g.full);
+    } else {                                                // split-major: one XCD works on one k range at a time
+        const int t = xcd_remap((int)blockIdx.x - g.full, (int)gridDim.x - g.full);
+        z = t / g.tail;
+        tile = g.full + (t - z * g.tail);
+    }
+    const int pi = tn_group_find(g, tile);
+    const TnProblem& P = g.p[pi];
+    const int tiles_n = (P.N2 + BN - 1) / BN;
+    const int bid = tile - g.tile_begin[pi];
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    if (whole) {
+        tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, P.C, P.ldc, P.colsum, m0, n0, 0, Kr);
+    } else {
+        // slab of (z, tail tile): a dense [BM][BN] tile; the pointers are biased so that the tile's own (m0, n0) indexing of
+        // a [*, BN] matrix lands in it (never dereferenced outside the slab: rows / columns beyond N1 / N2 are masked)
+        const int ti = tile - g.full;
+        float* slab = g.slabs + ((size_t)z * g.tail + ti) * (size_t)(BM * BN);
+        float* cs = P.colsum ? g.slabs + (size_t)g.tail_splits * g.tail * (size_t)(BM * BN) + ((size_t)z * g.tail + ti) * BM
+                             : nullptr;
+        const int kb = z * g.k_chunk, ke = min(Kr, kb + g.k_chunk);
+        tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, slab - ((ptrdiff_t)m0 * BN + n0), BN,
+                                                cs ? cs - m0 : nullptr, m0, n0, kb, ke);
+    }
+}
+
+// folds the split slabs of the tail tiles into the final matrices (and the column sums): one workgroup per (tile, 32 rows)
+__global__ void tn_tail_reduce_kernel(const TnGroup g) {
+    constexpr int BM = 256, BN = 256;
+    const int ti = blockIdx.x, rb = blockIdx.y;            // tail tile, 32-row block
+    const int tile = g.full + ti;
+    const int pi = tn_group_find(g, tile);
+    const TnProblem& P = g.p[pi];
+    const int tiles_n = (P.N2 + BN - 1) / BN;
+    const int bid = tile - g.tile_begin[pi];
+    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int c4 = (threadIdx.x & 63) * 4, r0 = rb * 32 + (threadIdx.x >> 6) * 8;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = r0 + rr;
+        if (m0 + r >= P.N1 || n0 + c4 >= P.N2) continue;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < g.tail_splits; ++z)
+            s += *(const f32x4*)(g.slabs + ((size_t)z * g.tail + ti) * (size_t)(BM * BN) + (size_t)r * BN + c4);
+        *(f32x4*)(P.C + (size_t)(m0 + r) * P.ldc + n0 + c4) = s;
+    }
+    if (P.colsum && n0 == 0 && rb == 0) {
+        const int m = threadIdx.x;
+        if (m < BM && m0 + m < P.N1) {
+            float s = 0.f;
+            const float* cs = g.slabs + (size_t)g.tail_splits * g.tail * (size_t)(BM * BN);
+            for (int z = 0; z < g.tail_splits; ++z) s += cs[((size_t)z * g.tail + ti) * BM + m];
+            P.colsum[m0 + m] = s;
         }
     }
 }
@@ -1251,6 +1373,77 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
     hipLaunchKernelGGL(splitk_reduce2_kernel, dim3(blocks), dim3(256), 0, st, ws, splits, N1, N2, C, ldc, alpha, accumulate,
                        (const float*)cs_ws, colsum_out);
     SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+static int device_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
+size_t gemm_tn_grouped_workspace_bytes(int Kr) {
+    (void)Kr;
+    return (size_t)device_cu_count() * (256 * 256 + 256) * sizeof(float);      // at most one slab per CU
+}
+
+int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0 || n > TN_GROUP_MAX || Kr <= 0 || !probs) return SPN_ERR_ARG;
+    TnGroup g{};
+    g.n = n;
+    int total = 0;
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const TnProblem& P = probs[i];
+        if (!P.A || !P.B || !P.C || P.N1 <= 0 || P.N2 <= 0) return SPN_ERR_ARG;
+        if (P.N1 % 8 || P.N2 % 8 || P.lda % 8 || P.ldb % 8 || P.ldc % 4) return SPN_ERR_SHAPE;
+        if ((uint64_t)Kr * P.lda * 2 >= (1ull << 32) || (uint64_t)Kr * P.ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+        g.p[i] = P;
+        g.tile_begin[i] = total;
+        total += ((P.N1 + 255) / 256) * ((P.N2 + 255) / 256);
+        flops += 2.0 * Kr * P.N1 * P.N2;
+    }
+    g.tile_begin[n] = total;
+    const int cus = device_cu_count();
+    const int ktiles = (Kr + BK2 - 1) / BK2;
+    int tail = total % cus, splits = 1;
+    if (tail > 0) {
+        splits = cus / tail;                              // fill one round with the tail's slices
+        const int max_s = (ktiles + 5) / 6;               // >= ~6 k tiles per slice
+        if (splits > max_s) splits = max_s;
+        if (splits < 1) splits = 1;
+    }
+    if (splits <= 1) tail = 0;                            // a tail of more than half a round runs unsplit
+    g.full = total - tail;
+    g.tail = tail;
+    g.k_chunk = ((ktiles + splits - 1) / splits) * BK2;
+    g.tail_splits = tail ? (Kr + g.k_chunk - 1) / g.k_chunk : 1;
+    g.slabs = ws;
+    if (tail) {
+        const size_t need = (size_t)g.tail_splits * tail * (256 * 256 + 256) * sizeof(float);
+        if (!ws || ws_bytes < need) return SPN_ERR_WORKSPACE;
+    }
+    constexpr int LDS = 2 * (256 + 256) * 128;
+    auto kern = gemm_tn2_group_kernel<256, 256, 2, 4, 2, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        ProfScope prof(PK_GEMM_TN, flops, st);
+        hipLaunchKernelGGL(kern, dim3(g.full + g.tail * g.tail_splits), dim3(512), LDS, st, g, Kr);
+        SPN_CHECK_LAUNCH();
+        if (tail) {
+            hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3(tail, 8), dim3(256), 0, st, g);
+            SPN_CHECK_LAUNCH();
+        }
+    }
     return SPN_OK;
 }
 

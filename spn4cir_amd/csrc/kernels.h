@@ -53,6 +53,17 @@ int gemm_tn2_pair(const bf16_t* A1, const bf16_t* B1, int N1a, int N2a, int lda1
                   int Kr, float* ws, size_t ws_bytes, hipStream_t st);
 int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, int ldb, float* C, int ldc,
              float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st);
+// Grouped weight gradients (gemm2.hip): C_p [N1, N2] = A_p [Kr, N1]^T B_p [Kr, N2] (overwritten, fp32), colsum_p [N1] =
+// column sums of A_p (optional), for up to TN_GROUP_MAX problems sharing Kr, in one launch without split-K
+// (only the tiles of a last, mostly empty round are split; ws holds their slabs).
+struct TnProblem {
+    const bf16_t* A; const bf16_t* B;
+    float* C; float* colsum;
+    int N1, N2, lda, ldb, ldc;
+};
+constexpr int TN_GROUP_MAX = 48;
+size_t gemm_tn_grouped_workspace_bytes(int Kr);
+int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
 bool gemm_use_v1();
 int gemm_cfg();

@@ -110,8 +110,10 @@ struct BwdOverlap {
     float* ws2;
     size_t ws2_bytes;
 };
+// dxb_group (optional, [T, W] bf16): enables the grouped weight-gradient launch at the end of the block (tower.hip)
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
-              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov = nullptr);
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov = nullptr,
+              bf16_t* dxb_group = nullptr);
 
 // training path (CLIP kind 0 only): activations kept per layer, clip4cir/models.py:156-158 (wo_bank first stage)
 size_t vision_train_act_bytes(const VisionCfg& c);

@@ -147,6 +147,7 @@ size_t block_op_ws_bytes(const BlockCfg& c) {
     mx(gemm_tn_workspace_bytes(T, W, W));
     mx(gemm_tn_workspace_bytes(T, 3 * W, W));
     mx(gemm_tn2_pair_workspace_bytes(T, 3 * W, W, W, W));
+    mx(gemm_tn_grouped_workspace_bytes(T));
     mx(colsum_workspace_bytes(T, 4 * W));
     mx(layernorm_bwd_workspace_bytes(T, W));
     return align256(m);
@@ -190,8 +191,18 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
 }
 
 // dx / dx_bf16: gradient w.r.t. the block output on entry, w.r.t. the block input on exit.
+// SPN_TN_GROUP=0 (A/B switch): the four weight gradients of a block as separate split-K launches again
+static bool tn_group_on() {
+    static const bool on = [] {
+        const char* e = getenv("SPN_TN_GROUP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
-              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov) {
+              bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov,
+              bf16_t* dxb_group) {
     const int T = c.rows(), W = c.W;
     const size_t Ts = (size_t)T;
     char* p = scratch;
@@ -206,7 +217,13 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     const hipStream_t sw = ov ? ov->side : st;
     float* wws = ov ? ov->ws2 : ws;
     const size_t wws_bytes = ov ? ov->ws2_bytes : ws_bytes;
-    bf16_t* dxb_mid = ov ? ov->dxb_alt : dx_bf16;     // the residual gradient between the two halves of the block
+    // Grouped mode (dxb_group = a second [T, W] bf16 buffer): the block's four weight gradients dW = dY^T X feed nothing
+    // downstream, so they are computed at the END of the block by ONE launch without per-problem split-K
+    // (gemm_tn_grouped): 108 tiles x 2 slices instead of 3 launches of 36 tiles x 7 slices + 4 reductions.  The
+    // gradient entering the block (dx_bf16) then has to survive until that launch, so the mid-block gradient goes to
+    // dxb_group instead of overwriting it.
+    const bool grouped = !ov && dxb_group != nullptr && tn_group_on();
+    bf16_t* dxb_mid = ov ? ov->dxb_alt : (grouped ? dxb_group : dx_bf16);     // the residual gradient between the two halves
     auto fork = [&](int i) -> int {                    // side stream may start once the main stream got here
         if (!ov) return SPN_OK;
         hipError_t e = hipEventRecord(ov->ev[i], st);
@@ -227,7 +244,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         e.aux_in = A.pre; e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
         SPN_TRY(gemm_nt(dx_bf16, P.w_proj_t, T, 4 * W, W, W, W, GEMM_DACT, e, st));
     }
-    SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, wws, wws_bytes, sw));
+    if (!grouped) SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, wws, wws_bytes, sw));
     if (ov) {                                          // ev[4]: the side stream no longer reads dx_bf16
         hipError_t e = hipEventRecord(ov->ev[4], ov->side);
         if (e != hipSuccess) return (int)e;
@@ -238,7 +255,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         e.out_bf16 = dh; e.ldc = W;
         SPN_TRY(gemm_nt(dpre, P.w_fc_t, T, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
     }
-    SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, wws, wws_bytes, sw));
+    if (!grouped) SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, wws, wws_bytes, sw));
     SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dxb_mid, G.ln2_g, G.ln2_b, 0, T, W, ws,
                           ws_bytes, st));
     // attention
@@ -249,8 +266,8 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         SPN_TRY(gemm_nt(dxb_mid, P.w_o_t, T, W, W, W, W, GEMM_STORE, e, st));
     }
     // the out-projection's weight gradient (W x W: 9 tiles) rides along with the qkv one below when they can share a launch
-    const bool pair = !ov && gemm_tn2_pair_ok(3 * W, W);
-    if (!pair) SPN_TRY(gemm_tn(dxb_mid, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, wws, wws_bytes, sw));
+    const bool pair = !ov && !grouped && gemm_tn2_pair_ok(3 * W, W);
+    if (!pair && !grouped) SPN_TRY(gemm_tn(dxb_mid, A.attn, T, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, wws, wws_bytes, sw));
     {
         AttnBwdArgs g;
         AttnArgs& a = g.f;
@@ -274,7 +291,15 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     if (pair)
         SPN_TRY(gemm_tn2_pair(dqkv, A.h1, 3 * W, W, 3 * W, W, G.w_qkv, W, G.b_qkv, dxb_mid, A.attn, W, W, W, W, G.w_o, W, G.b_o,
                               T, wws, wws_bytes, sw));
-    else SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, wws, wws_bytes, sw));
+    else if (!grouped) SPN_TRY(gemm_tn(dqkv, A.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, wws, wws_bytes, sw));
+    if (grouped) {
+        TnProblem q[4];
+        q[0] = TnProblem{dx_bf16, A.u, G.w_proj, G.b_proj, W, 4 * W, W, 4 * W, 4 * W};
+        q[1] = TnProblem{dpre, A.h2, G.w_fc, G.b_fc, 4 * W, W, 4 * W, W, W};
+        q[2] = TnProblem{dqkv, A.h1, G.w_qkv, G.b_qkv, 3 * W, W, 3 * W, W, W};
+        q[3] = TnProblem{dxb_mid, A.attn, G.w_o, G.b_o, W, W, W, W, W};
+        SPN_TRY(gemm_tn_grouped(q, 4, T, ws, ws_bytes, st));
+    }
     if (ov) {                                          // LayerNorm backward rewrites dx_bf16: w_proj's GEMM must be done with it
         hipError_t e = hipStreamWaitEvent(st, ov->ev[4], 0);
         if (e != hipSuccess) return (int)e;
@@ -558,7 +583,7 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
     BwdOverlap ovs;
     const BwdOverlap* ov = bwd_overlap(w.dxb2, w.ws2, w.ws2_bytes, &ovs);
-    return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st, ov);
+    return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st, ov, w.dxb2);
 }
 
 // phase 3: token / positional embedding gradients

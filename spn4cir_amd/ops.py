@@ -121,6 +121,32 @@ def gemm_tn_pair(a1, b1, a2, b2):
     return c1, s1, c2, s2
 
 
+class _TnProblem(C.Structure):     # == spn_tn_problem
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("colsum", C.c_void_p),
+                ("N1", C.c_int), ("N2", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int)]
+
+
+def gemm_tn_grouped(pairs, want_colsum=True):
+    """[(a [Kr,N1] bf16, b [Kr,N2] bf16), ...] sharing Kr -> [(a.T @ b fp32 [N1,N2], colsum(a) [N1] or None), ...]
+    in ONE launch without split-K (spn_gemm_tn_grouped)."""
+    Kr = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    arr = (_TnProblem * len(pairs))()
+    outs = []
+    for i, (a, b) in enumerate(pairs):
+        _req(a, torch.bfloat16, "a"); _req(b, torch.bfloat16, "b")
+        if a.shape[0] != Kr or b.shape[0] != Kr:
+            raise ValueError("grouped TN problems must share the reduction length")
+        N1, N2 = a.shape[1], b.shape[1]
+        c = torch.empty(N1, N2, dtype=torch.float32, device=dev)
+        cs = torch.empty(N1, dtype=torch.float32, device=dev) if want_colsum else None
+        arr[i] = _TnProblem(a.data_ptr(), b.data_ptr(), c.data_ptr(), cs.data_ptr() if want_colsum else None, N1, N2, N1, N2, N2)
+        outs.append((c, cs))
+    ws = workspace(lib().spn_gemm_tn_grouped_workspace_bytes(Kr), dev)
+    check(lib().spn_gemm_tn_grouped(C.byref(arr), len(pairs), Kr, _p(ws), ws.numel(), _stream()), "gemm_tn_grouped")
+    return outs
+
+
 # ------------------------------------------------------------------------- elementwise
 def cast_bf16(x):
     _req(x, torch.float32, "x")

@@ -644,3 +644,27 @@ def test_gemm_nt3_hand_scheduled_kernel():
     assert len(lines) >= 6 * 2 * 7, out.stdout[-2000:]
     bad = [l for l in lines if not re.search(r"bad elements 0$", l)]
     assert not bad, "\n".join(bad[:10])
+
+
+@pytest.mark.parametrize("Kr,shapes", [
+    (640, [(256, 512), (520, 264)]),                                   # fewer tiles than CUs: everything is "tail", split
+    (448, [(768, 3072), (3072, 768), (2304, 768), (768, 768)] * 3),    # 324 tiles: a full round + a split tail of 68
+    (384, [(2048, 2048)] * 4 + [(256, 256)] * 5),                      # 261 tiles: tail of 5 tiles, split 6 ways
+    (200, [(264, 72), (8, 520)]),                                      # ragged tiles, Kr not a multiple of 64
+])
+def test_gemm_tn_grouped(ops, Kr, shapes):
+    """Grouped weight gradients without split-K (spn_gemm_tn_grouped): every problem against a torch fp32 product,
+    incl. the column sums; full rounds are written directly, the last partial round goes through slabs."""
+    g = torch.Generator(device="cuda").manual_seed(Kr)
+    pairs = [(torch.randn(Kr, n1, device="cuda", generator=g).bfloat16(), torch.randn(Kr, n2, device="cuda", generator=g).bfloat16())
+             for n1, n2 in shapes]
+    for rep in range(2):
+        outs = ops.gemm_tn_grouped(pairs)
+        for (a, b), (c, cs) in zip(pairs, outs):
+            ref = a.float().t() @ b.float()
+            assert (c - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-3, (tuple(a.shape), tuple(b.shape))
+            rs = a.float().sum(0)
+            assert (cs - rs).abs().max() <= 2e-3 * rs.abs().max() + 1e-2
+    # transpose-detecting, asymmetric check of one problem against the per-problem kernel
+    single = ops.gemm_tn(pairs[0][0], pairs[0][1])
+    assert torch.allclose(outs[0][0], single, rtol=1e-4, atol=1e-3 * single.abs().max().item())
