@@ -235,6 +235,16 @@ int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void*
                        float* grads, int layer, void* ws, size_t ws_bytes, void* stream);
 int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
                       size_t ws_bytes, void* stream);
+/* Deferred weight gradients.  spn_text_bwd_layer_deferred = spn_text_bwd_layer without the block's four weight-gradient
+ * products dW = dY^T X (c_proj, c_fc, in_proj, out_proj: nothing downstream reads them): their dY operands stay in
+ * per-layer buffers of ws, and spn_text_bwd_wgrad computes them for the blocks [layer_begin, layer_end) (<= 12) in ONE
+ * grouped launch (spn_gemm_tn_grouped) after ALL of those blocks have gone through the deferred call.  LayerNorm
+ * gradients of a block are final after its own call, weights and biases after the wgrad call: a data-parallel host
+ * starts a span's all-reduce behind the latter.  spn_text_bwd defers every block by itself. */
+int spn_text_bwd_layer_deferred(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                                float* grads, int layer, void* ws, size_t ws_bytes, void* stream);
+int spn_text_bwd_wgrad(const spn_text_cfg* cfg, void* acts, float* grads, int layer_begin, int layer_end, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* Token output for TG-CIR (tgcir/models.py:127-151, Backbone.extract_text_fea): as spn_text_fwd, plus
  * tokens [B*L, W] fp32 (and an optional bf16 copy) = ln_final of EVERY row - TG-CIR feeds all 77 positions, padding

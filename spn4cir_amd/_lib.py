@@ -107,6 +107,8 @@ _SIGS = {
     "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
     "spn_text_bwd_tail": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),
+    "spn_text_bwd_layer_deferred": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
+    "spn_text_bwd_wgrad": (i32, [C.POINTER(TextCfg), vp, vp, i32, i32, vp, sz, vp]),
     "spn_vision_layout": (i32, [C.POINTER(VisionCfg), C.POINTER(VisionLayout)]),
     "spn_vision_ws_bytes": (sz, [C.POINTER(VisionCfg)]),
     "spn_vision_refresh_bf16": (i32, [C.POINTER(VisionCfg), vp, vp, vp]),

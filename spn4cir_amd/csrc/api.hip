@@ -448,6 +448,19 @@ int spn_text_bwd_layer(const spn_text_cfg* cfg, const float* params, const void*
     return text_bwd_layer(tc(cfg), params, CBF(weights_bf16), (char*)acts, grads, layer, (char*)ws, ws_bytes, ST(stream));
 }
 
+int spn_text_bwd_layer_deferred(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                                float* grads, int layer, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_layer_deferred(tc(cfg), params, CBF(weights_bf16), (char*)acts, grads, layer, (char*)ws, ws_bytes,
+                                   ST(stream));
+}
+
+int spn_text_bwd_wgrad(const spn_text_cfg* cfg, void* acts, float* grads, int layer_begin, int layer_end, void* ws,
+                       size_t ws_bytes, void* stream) {
+    if (!cfg || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_wgrad(tc(cfg), (char*)acts, grads, layer_begin, layer_end, (char*)ws, ws_bytes, ST(stream));
+}
+
 int spn_text_bwd_tail(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws,
                       size_t ws_bytes, void* stream) {
     if (!cfg || !ids || !acts || !grads || !ws) return SPN_ERR_ARG;

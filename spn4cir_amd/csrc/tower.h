@@ -110,10 +110,20 @@ struct BwdOverlap {
     float* ws2;
     size_t ws2_bytes;
 };
+// Cross-block deferral of the weight gradients: the block keeps the four dY operands in buffers of its own (instead of
+// the shared scratch / the in-place bf16 residual gradient), writes the four products it owes into `problems` and
+// launches nothing; the caller batches the problems of several blocks into one gemm_tn_grouped launch.
+struct BwdDefer {
+    bf16_t* dpre;        // [T, 4W]
+    bf16_t* dqkv;        // [T, 3W]
+    bf16_t* dx_mid;      // [T, W]  residual gradient between the two halves of the block
+    bf16_t* dx_out;      // [T, W]  bf16 gradient leaving the block (dx_bf16, the one entering it, stays intact)
+    TnProblem* problems; // [4]
+};
 // dxb_group (optional, [T, W] bf16): enables the grouped weight-gradient launch at the end of the block (tower.hip)
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
               bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov = nullptr,
-              bf16_t* dxb_group = nullptr);
+              bf16_t* dxb_group = nullptr, const BwdDefer* defer = nullptr);
 
 // training path (CLIP kind 0 only): activations kept per layer, clip4cir/models.py:156-158 (wo_bank first stage)
 size_t vision_train_act_bytes(const VisionCfg& c);
@@ -155,6 +165,13 @@ int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char*
                   float* grads, char* ws, size_t ws_bytes, hipStream_t st);
 int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l, char* ws,
                    size_t ws_bytes, hipStream_t st);
+// Deferred variant: everything of block l except its four weight-gradient GEMMs (their operands stay in per-layer
+// buffers of the workspace); text_bwd_wgrad computes them for the blocks [l_begin, l_end) in one grouped launch - call
+// it after the deferred backward of all of them (at most TN_GROUP_MAX / 4 blocks per call).
+int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l,
+                            char* ws, size_t ws_bytes, hipStream_t st);
+int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int l_end, char* ws, size_t ws_bytes,
+                   hipStream_t st);
 int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
                   hipStream_t st);
 

@@ -202,9 +202,10 @@ static bool tn_group_on() {
 
 int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const BlockGrads& G, float* dx,
               bf16_t* dx_bf16, char* scratch, float* ws, size_t ws_bytes, hipStream_t st, const BwdOverlap* ov,
-              bf16_t* dxb_group) {
+              bf16_t* dxb_group, const BwdDefer* defer) {
     const int T = c.rows(), W = c.W;
     const size_t Ts = (size_t)T;
+    if (defer && ov) return SPN_ERR_ARG;
     char* p = scratch;
     auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
     bf16_t* dpre = (bf16_t*)take(Ts * 4 * W * 2);
@@ -212,6 +213,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     bf16_t* dattn = (bf16_t*)take(Ts * W * 2);
     bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
     float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
+    if (defer) { dpre = defer->dpre; dqkv = defer->dqkv; }
 
     // weight-gradient GEMMs: side stream + own workspace when overlapping, otherwise in line
     const hipStream_t sw = ov ? ov->side : st;
@@ -222,8 +224,8 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     // (gemm_tn_grouped): 108 tiles x 2 slices instead of 3 launches of 36 tiles x 7 slices + 4 reductions.  The
     // gradient entering the block (dx_bf16) then has to survive until that launch, so the mid-block gradient goes to
     // dxb_group instead of overwriting it.
-    const bool grouped = !ov && dxb_group != nullptr && tn_group_on();
-    bf16_t* dxb_mid = ov ? ov->dxb_alt : (grouped ? dxb_group : dx_bf16);     // the residual gradient between the two halves
+    const bool grouped = defer != nullptr || (!ov && dxb_group != nullptr && tn_group_on());
+    bf16_t* dxb_mid = ov ? ov->dxb_alt : (defer ? defer->dx_mid : (grouped ? dxb_group : dx_bf16));   // between the two halves
     auto fork = [&](int i) -> int {                    // side stream may start once the main stream got here
         if (!ov) return SPN_OK;
         hipError_t e = hipEventRecord(ov->ev[i], st);
@@ -298,14 +300,18 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         q[1] = TnProblem{dpre, A.h2, G.w_fc, G.b_fc, 4 * W, W, 4 * W, W, W};
         q[2] = TnProblem{dqkv, A.h1, G.w_qkv, G.b_qkv, 3 * W, W, 3 * W, W, W};
         q[3] = TnProblem{dxb_mid, A.attn, G.w_o, G.b_o, W, W, W, W, W};
-        SPN_TRY(gemm_tn_grouped(q, 4, T, ws, ws_bytes, st));
+        if (defer) {
+            for (int i = 0; i < 4; ++i) defer->problems[i] = q[i];
+        } else {
+            SPN_TRY(gemm_tn_grouped(q, 4, T, ws, ws_bytes, st));
+        }
     }
     if (ov) {                                          // LayerNorm backward rewrites dx_bf16: w_proj's GEMM must be done with it
         hipError_t e = hipStreamWaitEvent(st, ov->ev[4], 0);
         if (e != hipSuccess) return (int)e;
     }
-    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, dx_bf16, G.ln1_g, G.ln1_b, 0, T, W, ws,
-                          ws_bytes, st));
+    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, defer ? defer->dx_out : dx_bf16, G.ln1_g,
+                          G.ln1_b, 0, T, W, ws, ws_bytes, st));
     // every parameter gradient of the block is final in `st` order on return (DDP bucket hooks rely on it), and
     // the scratch / dxb_alt buffers are free for the next block
     SPN_TRY(join(5));
@@ -420,6 +426,13 @@ static const BwdOverlap* bwd_overlap(bf16_t* dxb_alt, float* ws2, size_t ws2_byt
     return out;
 }
 
+// per-layer buffers of the deferred backward: dpre [T,4W] | dqkv [T,3W] | dx_mid [T,W] | dx_in [T,W] (the gradient
+// entering the block; the top block reads the head's buffer instead)
+static size_t text_defer_layer_bytes(const BlockCfg& bc) {
+    const size_t T = (size_t)bc.rows(), W = bc.W;
+    return align256(T * 4 * W * 2) + align256(T * 3 * W * 2) + 2 * align256(T * W * 2);
+}
+
 size_t text_ws_bytes(const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
     const size_t T = (size_t)bc.rows();
@@ -430,6 +443,7 @@ size_t text_ws_bytes(const TextCfg& c) {
     b += align256((size_t)c.B * c.D * 2);    // dfeats bf16
     b += align256((size_t)c.B * c.W * 4);    // dln_e
     b += align256((size_t)c.B * c.W * 4);    // de
+    b += text_defer_layer_bytes(bc) * c.layers;   // per-layer dY operands of the deferred weight gradients
     size_t op = block_op_ws_bytes(bc);
     const size_t tp = align256(gemm_tn_workspace_bytes(c.B, c.W, c.D));
     if (tp > op) op = tp;
@@ -519,9 +533,23 @@ struct TextBwdWs {
     size_t ws2_bytes;
     bf16_t* dfb;
     float *dln, *de;
+    char* defer;               // layers x text_defer_layer_bytes
+    size_t defer_stride;
     float* opws;
     size_t opws_bytes;
 };
+
+struct TextDeferBufs { bf16_t *dpre, *dqkv, *dx_mid, *dx_in; };
+static TextDeferBufs text_defer_at(const TextBwdWs& w, const BlockCfg& bc, int l) {
+    const size_t T = (size_t)bc.rows(), W = bc.W;
+    char* p = w.defer + w.defer_stride * l;
+    TextDeferBufs d;
+    d.dpre = (bf16_t*)p; p += align256(T * 4 * W * 2);
+    d.dqkv = (bf16_t*)p; p += align256(T * 3 * W * 2);
+    d.dx_mid = (bf16_t*)p; p += align256(T * W * 2);
+    d.dx_in = (bf16_t*)p;
+    return d;
+}
 
 static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w) {
     if (ws_bytes < text_ws_bytes(c)) return SPN_ERR_WORKSPACE;
@@ -538,6 +566,8 @@ static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w
     w->dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
     w->dln = (float*)take((size_t)c.B * c.W * 4);
     w->de = (float*)take((size_t)c.B * c.W * 4);
+    w->defer_stride = text_defer_layer_bytes(bc);
+    w->defer = p; p += w->defer_stride * c.layers;
     w->opws = (float*)p;
     w->opws_bytes = ws_bytes - (size_t)(p - ws);
     return SPN_OK;
@@ -584,6 +614,61 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
     BwdOverlap ovs;
     const BwdOverlap* ov = bwd_overlap(w.dxb2, w.ws2, w.ws2_bytes, &ovs);
     return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st, ov, w.dxb2);
+}
+
+// phase 2, deferred: the block's data path only; its four weight-gradient products are left to text_bwd_wgrad
+static int text_defer_problems(const TextCfg& c, const TextBwdWs& w, const BlockCfg& bc, const TextActs& A, float* grads,
+                               const TextLayout& t, int l, TnProblem* q) {
+    const int W = c.W;
+    const TextDeferBufs d = text_defer_at(w, bc, l);
+    const BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
+    const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+    const bf16_t* dx_in = (l == c.layers - 1) ? w.dxb : d.dx_in;
+    q[0] = TnProblem{dx_in, a.u, G.w_proj, G.b_proj, W, 4 * W, W, 4 * W, 4 * W};
+    q[1] = TnProblem{d.dpre, a.h2, G.w_fc, G.b_fc, 4 * W, W, 4 * W, W, W};
+    q[2] = TnProblem{d.dqkv, a.h1, G.w_qkv, G.b_qkv, 3 * W, W, 3 * W, W, W};
+    q[3] = TnProblem{d.dx_mid, a.attn, G.w_o, G.b_o, W, W, W, W, W};
+    return SPN_OK;
+}
+
+int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l,
+                            char* ws, size_t ws_bytes, hipStream_t st) {
+    SPN_TRY(text_check(c));
+    if (l < 0 || l >= c.layers) return SPN_ERR_ARG;
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    TextLayout t;
+    text_layout(c, &t);
+    BlockCfg bc = text_block_cfg(c);
+    TextActs A = text_acts_at(acts, c);
+    if (c.T > 0) bc.cu = A.cu;
+    BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
+    const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
+    const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+    const TextDeferBufs d = text_defer_at(w, bc, l);
+    TnProblem unused[4];
+    BwdDefer df;
+    df.dpre = d.dpre; df.dqkv = d.dqkv; df.dx_mid = d.dx_mid;
+    df.dx_out = l > 0 ? text_defer_at(w, bc, l - 1).dx_in : w.dxb2;      // the gradient entering block l-1
+    df.problems = unused;                                               // rebuilt by text_bwd_wgrad from the layout
+    bf16_t* dx_in = (l == c.layers - 1) ? w.dxb : d.dx_in;
+    return block_bwd(bc, P, a, G, w.dx, dx_in, w.scratch, w.opws, w.opws_bytes, st, nullptr, nullptr, &df);
+}
+
+int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int l_end, char* ws, size_t ws_bytes,
+                   hipStream_t st) {
+    SPN_TRY(text_check(c));
+    if (l_begin < 0 || l_end > c.layers || l_begin >= l_end || (l_end - l_begin) * 4 > TN_GROUP_MAX) return SPN_ERR_ARG;
+    TextBwdWs w;
+    SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    TextLayout t;
+    text_layout(c, &t);
+    BlockCfg bc = text_block_cfg(c);
+    TextActs A = text_acts_at(acts, c);
+    TnProblem q[TN_GROUP_MAX];
+    int n = 0;
+    for (int l = l_end - 1; l >= l_begin; --l, n += 4) SPN_TRY(text_defer_problems(c, w, bc, A, grads, t, l, q + n));
+    return gemm_tn_grouped(q, n, bc.rows(), w.opws, w.opws_bytes, st);
 }
 
 // phase 3: token / positional embedding gradients
@@ -636,7 +721,16 @@ int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, con
 int text_bwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
              const float* dfeats, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
     SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));
-    for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    if (!tn_group_on()) {
+        for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+        return text_bwd_tail(c, ids, acts, grads, ws, ws_bytes, st);
+    }
+    // data path of every block first, then the weight gradients of up to 12 blocks per grouped launch
+    for (int l = c.layers - 1; l >= 0; --l)
+        SPN_TRY(text_bwd_layer_deferred(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    constexpr int PER = TN_GROUP_MAX / 4;
+    for (int e = c.layers; e > 0; e -= PER)
+        SPN_TRY(text_bwd_wgrad(c, acts, grads, e > PER ? e - PER : 0, e, ws, ws_bytes, st));
     return text_bwd_tail(c, ids, acts, grads, ws, ws_bytes, st);
 }
 

@@ -215,10 +215,14 @@ class TextTower:
                                         _p(self._ws), self._ws.numel(), _stream()), "text_bwd_tokens")
         return self.grads
 
-    def backward_phased(self, dfeats, on_span_ready):
+    def backward_phased(self, dfeats, on_span_ready, wgrad_groups=None):
         """Same as backward(), but calls on_span_ready(start, end) right after the launches that
         finish the flat-gradient range [start, end) have been enqueued (tail+head params first, then
-        each block from the last to the first, then the embeddings): the DDP bucket hook."""
+        each block from the last to the first, then the embeddings): the DDP bucket hook.
+
+        wgrad_groups (list of block counts, last block first, summing to `layers`, each <= 12): the weight gradients of
+        a group's blocks are deferred to ONE grouped launch behind the group's data path (spn_text_bwd_wgrad); the
+        group's spans are reported after it.  None: every block computes its own (one grouped launch per block)."""
         ids = self._last
         if ids is None:
             raise RuntimeError("backward_phased() without a preceding forward()")
@@ -230,10 +234,25 @@ class TextTower:
         check(lib().spn_text_bwd_head(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats),
                                       _p(self.grads), ws, n, _stream()), "text_bwd_head")
         on_span_ready(*spans[0])
-        for i, l in enumerate(reversed(range(self.layers))):
-            check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),
-                                           _p(self.grads), l, ws, n, _stream()), "text_bwd_layer")
-            on_span_ready(*spans[1 + i])
+        if wgrad_groups is None:
+            for i, l in enumerate(reversed(range(self.layers))):
+                check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),
+                                               _p(self.grads), l, ws, n, _stream()), "text_bwd_layer")
+                on_span_ready(*spans[1 + i])
+        else:
+            if sum(wgrad_groups) != self.layers or any(g <= 0 or g > 12 for g in wgrad_groups):
+                raise ValueError(f"wgrad_groups {wgrad_groups} must split {self.layers} layers into groups of 1..12")
+            hi = self.layers
+            for g in wgrad_groups:
+                lo = hi - g
+                for l in reversed(range(lo, hi)):
+                    check(lib().spn_text_bwd_layer_deferred(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),
+                                                            _p(self.grads), l, ws, n, _stream()), "text_bwd_layer_deferred")
+                check(lib().spn_text_bwd_wgrad(C.byref(cfg), _p(self._acts), _p(self.grads), lo, hi, ws, n, _stream()),
+                      "text_bwd_wgrad")
+                for l in reversed(range(lo, hi)):
+                    on_span_ready(*spans[1 + (self.layers - 1 - l)])
+                hi = lo
         check(lib().spn_text_bwd_tail(C.byref(cfg), _p(ids), _p(self._acts), _p(self.grads), ws, n, _stream()),
               "text_bwd_tail")
         on_span_ready(*spans[-1])

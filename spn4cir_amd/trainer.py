@@ -14,6 +14,27 @@ from . import distributed as _dp
 from .distributed import BankLossDP, GradBucketReducer, _world, shard_range
 
 
+def wgrad_groups(layers, world):
+    """How the backward pass batches the weight gradients of its blocks (TextTower.backward_phased): one process takes
+    all of them in one grouped launch (<= 12 blocks per launch); data-parallel ranks use two groups, so that the first
+    group's gradient all-reduce still runs under the second group's backward (7 + 5 of 12 blocks: 756 and 540 tiles of
+    256x256, i.e. 2.95 and 2.11 rounds of 256 CUs - the remainders are split over the reduction by the kernel).
+    SPN_WGRAD_GROUPS="a,b,.." overrides; "0" = no deferral (one grouped launch per block)."""
+    import os
+    env = os.environ.get("SPN_WGRAD_GROUPS")
+    if env is not None:
+        return None if env.strip() in ("", "0") else [int(x) for x in env.split(",")]
+    if world > 1 and 4 <= layers <= 24:
+        first = min(12, (7 * layers + 11) // 12)
+        rest = layers - first
+        return [first] + ([rest] if rest <= 12 else [12, rest - 12])
+    groups, left = [], layers
+    while left > 0:
+        groups.append(min(12, left))
+        left -= groups[-1]
+    return groups
+
+
 class Stage2Trainer:
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
                  bank_mode="replicated", check_finite=False):
@@ -69,7 +90,7 @@ class Stage2Trainer:
                 self.reducer.flush()                      # everything before the tail goes out as its own bucket(s)
             self.reducer.on_span_ready(start, end)
 
-        t.backward_phased(dtext, on_span)
+        t.backward_phased(dtext, on_span, wgrad_groups(t.layers, self.world))
         split = self.world > 1 and not self.check_finite
         pending = self.reducer.finish(keep_span=(0, tail_end) if split else None)
         self.step_count += 1

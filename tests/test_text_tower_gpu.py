@@ -184,3 +184,35 @@ def test_eot_is_first_maximum_and_long_rows():
     feats = t.forward(ids.cuda())
     ref = clip_text.encode_text(sd, ids.long())
     assert (1 - cosine(feats.cpu(), ref)).max() < 1e-3
+
+
+@pytest.mark.parametrize("layers,groups", [(2, [2]), (5, [3, 2]), (5, [1, 1, 1, 1, 1]), (13, [12, 1])])
+def test_deferred_weight_gradients_equal_immediate(layers, groups):
+    """backward_phased(wgrad_groups=...): the blocks' weight gradients deferred to grouped launches (spn_text_bwd_wgrad)
+    against one grouped launch per block and against spn_text_bwd (which defers everything itself): same gradients up
+    to the summation order of the split tail tiles; spans are reported once each, a group's spans after its launch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import synthetic
+    from spn4cir_amd.text_tower import TextTower
+    W, D, vocab, B = 128, 64, 300, 6
+    sd = synthetic.text_state_dict(W, layers, D, vocab=vocab, seed=3)
+    t = TextTower(W, layers, W // 64, D, vocab, 77, "cuda")
+    t.load_clip_state_dict(sd)
+    ids = synthetic.token_ids(B, vocab=vocab, seed=4).cuda()
+    dfeats = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).cuda()
+    t.forward(ids)
+    g_mono = t.backward(dfeats).clone()
+    got = {}
+    for name, gr in (("per_block", None), ("deferred", groups)):
+        t.forward(ids)
+        spans = []
+        t.grads.fill_(float("nan"))
+        t.backward_phased(dfeats, lambda s, e: spans.append((s, e)), wgrad_groups=gr)
+        got[name] = (t.grads.clone(), spans)
+    assert got["per_block"][1] == got["deferred"][1] == t.layer_spans()
+    for name in got:
+        g = got[name][0]
+        assert torch.isfinite(g).all(), name
+        assert ((g - g_mono).norm() / g_mono.norm()).item() < 1e-5, name
+        assert (g - g_mono).abs().max() <= 1e-4 * g_mono.abs().max(), name
