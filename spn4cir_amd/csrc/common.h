@@ -90,6 +90,20 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
     const float s = fast_sigmoid(1.702f * x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// activation and its derivative from ONE sigmoid / erf evaluation (ACT: 1 = QuickGELU, 2 = exact GELU, kernels.h)
+template <int ACT>
+__device__ __forceinline__ f32x2 act_and_grad_pair(float x) {
+    if constexpr (ACT == 1) {
+        const float s = fast_sigmoid(1.702f * x);
+        return f32x2{x * s, s * (1.0f + 1.702f * x * (1.0f - s))};
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        return f32x2{x * cdf, cdf + x * pdf};
+    }
+}
+// y = act(x), g = act'(x); a macro because vector elements cannot bind to references
+#define act_and_grad_into(ACT_, X, Y, G) do { const f32x2 ag__ = act_and_grad_pair<ACT_>(X); (Y) = ag__[0]; (G) = ag__[1]; } while (0)
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));

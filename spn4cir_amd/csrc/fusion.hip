@@ -182,7 +182,7 @@ __global__ void fusion_mask_kernel(const int32_t* __restrict__ mask, float* __re
 static int nt(const bf16_t* A, const bf16_t* Bw, int M, int N, int K, const float* bias, bf16_t* out_b, float* out_f,
               hipStream_t st, int act = ACT_NONE, bf16_t* pre = nullptr) {
     GemmEpilogue e;
-    e.bias = bias; e.out_bf16 = out_b; e.out_f32 = out_f; e.ldc = N; e.act = act; e.aux_out = pre;
+    e.bias = bias; e.out_bf16 = out_b; e.out_f32 = out_f; e.ldc = N; e.act = act; e.aux_out = pre; e.aux_grad = 1;
     return gemm_nt(A, Bw, M, N, K, K, K, GEMM_STORE, e, st);
 }
 
@@ -328,7 +328,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
                                opws, opws_bytes, st));
         {
             GemmEpilogue e;
-            e.aux_in = a.pre; e.act = ACT_GELU_ERF; e.out_bf16 = dpre; e.ldc = I;
+            e.aux_in = a.pre; e.aux_grad = 1; e.act = ACT_GELU_ERF; e.out_bf16 = dpre; e.ldc = I;
             SPN_TRYF(gemm_nt(dyb, Bw(BO_FF_W2_T), T, I, W, W, W, GEMM_DACT, e, st));
         }
         SPN_TRYF(gemm_tn(dyb, a.u, T, W, I, W, I, G(LO_FF_W2), I, 1.0f, 0, G(LO_FF_B2), opws, opws_bytes, st));

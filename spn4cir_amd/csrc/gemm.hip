@@ -111,12 +111,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
             const size_t o = (size_t)m * ep.ldc + n;
             if constexpr (MODE == GEMM_STORE) {
                 if constexpr (ACT != ACT_NONE) {
+                    f32x4 a = v;
+                    if (ep.aux_out && ep.aux_grad) {           // wave-uniform: keep act'(pre) instead of pre
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) act_and_grad_into(ACT, v[e], v[e], a[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                    }
                     if (ep.aux_out) {
-                        bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                        bf16x4 p = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
                         *(bf16x4*)(ep.aux_out + o) = p;
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
                 }
             } else if constexpr (MODE == GEMM_RESID) {
                 v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = bf2f(p[e]);
-                    v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                    v[e] *= ep.aux_grad ? x : (ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x));
                 }
             }
             if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;

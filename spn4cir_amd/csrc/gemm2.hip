@@ -228,11 +228,21 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 };
                 if constexpr (MODE == GEMM_STORE) {
                     if constexpr (ACT != ACT_NONE) {
-                        if (ep.aux_out) store_bf16(ep.aux_out, v0, v1);
+                        if (ep.aux_out && ep.aux_grad) {       // wave-uniform: keep act'(pre) instead of pre
+                            f32x4 g0, g1;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
-                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                            for (int e = 0; e < 4; ++e) {
+                                act_and_grad_into(ACT, v0[e], v0[e], g0[e]);
+                                act_and_grad_into(ACT, v1[e], v1[e], g1[e]);
+                            }
+                            store_bf16(ep.aux_out, g0, g1);
+                        } else {
+                            if (ep.aux_out) store_bf16(ep.aux_out, v0, v1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                                v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                            }
                         }
                     }
                 } else if constexpr (MODE == GEMM_RESID) {
@@ -240,11 +250,16 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                     v1 += pf_r1[it];
                 } else if constexpr (MODE == GEMM_DACT) {
                     const bf16x8 p = pf_aux[it];
+                    if (ep.aux_grad) {                         // wave-uniform: aux_in already holds act'(pre)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
-                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
-                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
+                        for (int e = 0; e < 4; ++e) { v0[e] *= bf2f(p[e]); v1[e] *= bf2f(p[4 + e]); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
+                            v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
+                            v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
+                        }
                     }
                 }
                 if (ep.out_f32) {
@@ -272,12 +287,18 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 const size_t o = (size_t)m * ep.ldc + n;
                 if constexpr (MODE == GEMM_STORE) {
                     if constexpr (ACT != ACT_NONE) {
+                        f32x4 a = v;
+                        if (ep.aux_out && ep.aux_grad) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) act_and_grad_into(ACT, v[e], v[e], a[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                        }
                         if (ep.aux_out) {
-                            bf16x4 p = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                            bf16x4 p = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
                             *(bf16x4*)(ep.aux_out + o) = p;
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
                     }
                 } else if constexpr (MODE == GEMM_RESID) {
                     v += *(const f32x4*)(ep.resid + (size_t)m * ep.ldr + n);
@@ -286,7 +307,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = bf2f(p[e]);
-                        v[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x);
+                        v[e] *= ep.aux_grad ? x : (ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x) : gelu_erf_grad_f(x));
                     }
                 }
                 if (ep.out_f32) *(f32x4*)(ep.out_f32 + o) = v;
@@ -576,6 +597,7 @@ __device__ __forceinline__ void nt3_epilogue(f32x16 (&acc)[4][4], char* smem, in
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
             bf16_t* dst = (ACT != ACT_NONE && pass == 0) ? ep.aux_out : ep.out_bf16;
+            const bool want_grad = ACT != ACT_NONE && pass == 0 && ep.aux_grad;      // wave-uniform
             if (dst == nullptr) continue;                      // wave-uniform
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -586,9 +608,13 @@ __device__ __forceinline__ void nt3_epilogue(f32x16 (&acc)[4][4], char* smem, in
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                         v = v * ep.alpha + bias[j][g];
-                        if (ACT != ACT_NONE && pass == 1) {
+                        if (ACT != ACT_NONE && (pass == 1 || want_grad)) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v[e]) : gelu_erf_f(v[e]);
+                            for (int e = 0; e < 4; ++e) {
+                                float y, gr;
+                                act_and_grad_into(ACT, v[e], y, gr);
+                                v[e] = pass == 1 ? y : gr;
+                            }
                         }
                         const bf16x4 pk = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                         *(bf16x4*)(sW + r * 256 + (((j * 4 + g) ^ (r & 15)) << 4) + half * 8) = pk;
@@ -661,7 +687,7 @@ __device__ __forceinline__ void nt3_epilogue(f32x16 (&acc)[4][4], char* smem, in
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float p = bf2f(ax[b & 1][q][e]);
-                            x[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(p) : gelu_erf_grad_f(p);
+                            x[e] *= ep.aux_grad ? p : (ACT == ACT_QUICKGELU ? quick_gelu_grad_f(p) : gelu_erf_grad_f(p));
                         }
                     }
                     if (ep.out_f32) *(f32x4*)(ep.out_f32 + m * ep.ldc + n) = x;
@@ -1237,31 +1263,34 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_group_ker
     }
 }
 
-// folds the split slabs of the tail tiles into the final matrices (and the column sums): one workgroup per (tile, 32 rows)
+// folds the split slabs of the tail tiles into the final matrices (and the column sums): one workgroup per (tile, 8 rows) -
+// 32 x tail workgroups, each wave streams two 1-KB rows of every slab (HBM bound: 64 MB of slabs in the worst case)
 __global__ void tn_tail_reduce_kernel(const TnGroup g) {
     constexpr int BM = 256, BN = 256;
-    const int ti = blockIdx.x, rb = blockIdx.y;            // tail tile, 32-row block
+    const int ti = blockIdx.x, rb = blockIdx.y;            // tail tile, 8-row block
     const int tile = g.full + ti;
     const int pi = tn_group_find(g, tile);
     const TnProblem& P = g.p[pi];
     const int tiles_n = (P.N2 + BN - 1) / BN;
     const int bid = tile - g.tile_begin[pi];
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-    const int c4 = (threadIdx.x & 63) * 4, r0 = rb * 32 + (threadIdx.x >> 6) * 8;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int r = r0 + rr;
-        if (m0 + r >= P.N1 || n0 + c4 >= P.N2) continue;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < g.tail_splits; ++z)
-            s += *(const f32x4*)(g.slabs + ((size_t)z * g.tail + ti) * (size_t)(BM * BN) + (size_t)r * BN + c4);
-        *(f32x4*)(P.C + (size_t)(m0 + r) * P.ldc + n0 + c4) = s;
+    const int c4 = (threadIdx.x & 63) * 4, r0 = rb * 8 + (threadIdx.x >> 6) * 2;
+    const size_t slab = (size_t)(BM * BN), zs = (size_t)g.tail * slab;
+    const float* base = g.slabs + (size_t)ti * slab + (size_t)r0 * BN + c4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < g.tail_splits; ++z) {
+        s0 += *(const f32x4*)(base + (size_t)z * zs);
+        s1 += *(const f32x4*)(base + (size_t)z * zs + BN);
+    }
+    if (n0 + c4 < P.N2) {
+        if (m0 + r0 < P.N1) *(f32x4*)(P.C + (size_t)(m0 + r0) * P.ldc + n0 + c4) = s0;
+        if (m0 + r0 + 1 < P.N1) *(f32x4*)(P.C + (size_t)(m0 + r0 + 1) * P.ldc + n0 + c4) = s1;
     }
     if (P.colsum && n0 == 0 && rb == 0) {
         const int m = threadIdx.x;
         if (m < BM && m0 + m < P.N1) {
             float s = 0.f;
-            const float* cs = g.slabs + (size_t)g.tail_splits * g.tail * (size_t)(BM * BN);
+            const float* cs = g.slabs + (size_t)g.tail_splits * g.tail * slab;
             for (int z = 0; z < g.tail_splits; ++z) s += cs[((size_t)z * g.tail + ti) * BM + m];
             P.colsum[m0 + m] = s;
         }
@@ -1440,7 +1469,7 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
         hipLaunchKernelGGL(kern, dim3(g.full + g.tail * g.tail_splits), dim3(512), LDS, st, g, Kr);
         SPN_CHECK_LAUNCH();
         if (tail) {
-            hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3(tail, 8), dim3(256), 0, st, g);
+            hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3(tail, 32), dim3(256), 0, st, g);
             SPN_CHECK_LAUNCH();
         }
     }

@@ -13,6 +13,9 @@ struct GemmEpilogue {
     const float* resid = nullptr;    // GEMM_RESID: fp32 [M, ldr] added to the result
     const bf16_t* aux_in = nullptr;  // GEMM_DACT: pre-activation, result *= act'(aux_in)
     bf16_t* aux_out = nullptr;       // GEMM_STORE with act: pre-activation copy (bf16)
+    int aux_grad = 0;                // 1: aux_out receives act'(pre-activation) instead, and GEMM_DACT multiplies by
+                                     // aux_in as it is - the derivative shares the forward's sigmoid / erf, so the
+                                     // backward epilogue loses its transcendentals (the training towers use this)
     bf16_t* out_bf16 = nullptr;
     float* out_f32 = nullptr;
     int ldc = 0;                     // leading dim of out_bf16 / out_f32 / aux_in / aux_out

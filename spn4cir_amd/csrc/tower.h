@@ -34,7 +34,7 @@ struct BlockActs {
     float* x_mid;
     float *mean2, *rstd2;
     bf16_t* h2;
-    bf16_t* pre;
+    bf16_t* pre;      // act'(pre-activation) of the MLP (GemmEpilogue::aux_grad): what the backward multiplies by
     bf16_t* u;
     float* x_out;
 };

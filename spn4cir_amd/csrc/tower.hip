@@ -153,6 +153,15 @@ size_t block_op_ws_bytes(const BlockCfg& c) {
     return align256(m);
 }
 
+// SPN_AUX_GRAD=0 (A/B switch): keep the MLP's pre-activation and evaluate the activation's derivative in the backward GEMM
+static int aux_grad_on() {
+    static const int on = [] {
+        const char* e = getenv("SPN_AUX_GRAD");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on;
+}
+
 // -------------------------------------------------------------------------------- block
 int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st) {
     const int T = c.rows(), W = c.W;
@@ -179,7 +188,7 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
     SPN_TRY(layernorm_fwd(A.x_mid, P.ln2_g, P.ln2_b, A.h2, nullptr, A.mean2, A.rstd2, T, W, c.eps, st));
     {
         GemmEpilogue e;
-        e.bias = P.b_fc; e.act = c.act; e.aux_out = A.pre; e.out_bf16 = A.u; e.ldc = 4 * W;
+        e.bias = P.b_fc; e.act = c.act; e.aux_out = A.pre; e.aux_grad = aux_grad_on(); e.out_bf16 = A.u; e.ldc = 4 * W;
         SPN_TRY(gemm_nt(A.h2, P.w_fc, T, 4 * W, W, W, W, GEMM_STORE, e, st));
     }
     {
@@ -243,7 +252,7 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
     SPN_TRY(fork(0));                                  // dx_bf16 is final
     {
         GemmEpilogue e;
-        e.aux_in = A.pre; e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
+        e.aux_in = A.pre; e.aux_grad = aux_grad_on(); e.act = c.act; e.out_bf16 = dpre; e.ldc = 4 * W;
         SPN_TRY(gemm_nt(dx_bf16, P.w_proj_t, T, 4 * W, W, W, W, GEMM_DACT, e, st));
     }
     if (!grouped) SPN_TRY(gemm_tn(dx_bf16, A.u, T, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, wws, wws_bytes, sw));
