@@ -248,13 +248,15 @@ def main():
             # the events cover every prof_every-th launch: scale the sampled time to all launches for the share
             launches_total = dn * max(1, args.prof_every)
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(tpath) and args.batch_per_gpu == 256 and args.model == "ViT-L/14":
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            tpath = tfiles[-1] if tfiles else ""          # the latest round's PMC passes
+            if tpath and args.batch_per_gpu == 256 and args.model == "ViT-L/14":
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command
                 # (bench.py cannot profile itself); FETCH_SIZE already doubled per the gfx950 correction
                 with open(tpath) as f:
                     tj = json.load(f)
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tpath)
             roof = {"bound": bound, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": name, "launches": dn, "avg_us": round(dms / dn * 1e3, 1),

@@ -151,6 +151,36 @@ int fold_rows(const float* ws, size_t stride, int n, size_t C, float* out, float
     return SPN_OK;
 }
 
+// The same for up to FOLD_BATCH_MAX (ws, out) pairs of one shape in ONE launch (grid.y = pair): the LayerNorm parameter
+// gradients of a whole backward pass - 24 folds of 1024 x 1536 partials, each too small to fill the chip or to hide its
+// own latency - leave in one go behind the grouped weight-gradient GEMM.
+__global__ __launch_bounds__(256) void fold_rows_batched_kernel(const FoldBatch b) {
+    __shared__ f32x4 red[16][17];
+    const float* ws = b.ws[blockIdx.y];
+    float* out = b.out[blockIdx.y];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const size_t c = ((size_t)blockIdx.x * 16 + cq) * 4;
+    f32x4 s = {0, 0, 0, 0};
+    if (c < b.C) {
+#pragma unroll 4
+        for (int r = rl; r < b.n; r += 16) s += *(const f32x4*)(ws + (size_t)r * b.stride + c);
+    }
+    red[rl][cq] = s;
+    __syncthreads();
+    if (rl == 0 && c < b.C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k][cq];
+        *(f32x4*)(out + c) = s;
+    }
+}
+
+int fold_rows_batched(const FoldBatch& b, hipStream_t st) {
+    if (b.items <= 0 || b.items > FOLD_BATCH_MAX || b.C % 4 || b.stride % 4) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(fold_rows_batched_kernel, dim3((unsigned)((b.C + 63) / 64), b.items), dim3(256), 0, st, b);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 // ----------------------------------------------------------------------------- column sums
 // out[c] (+)= sum_r x[r][c]; two stages: CS_ROWS row-slabs x column groups -> ws, then fold.
 static constexpr int CS_SLABS = 64;

@@ -86,6 +86,15 @@ int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int acc
                 hipStream_t st);
 size_t colsum_workspace_bytes(int rows, int cols);
 int fold_rows(const float* ws, size_t stride, int n, size_t C, float* out, float alpha, int accumulate, hipStream_t st);
+constexpr int FOLD_BATCH_MAX = 32;
+struct FoldBatch {            // out[i][c] = sum_{r < n} ws[i][r * stride + c], c < C, for i < items
+    const float* ws[FOLD_BATCH_MAX];
+    float* out[FOLD_BATCH_MAX];
+    int items, n;
+    size_t stride, C;
+};
+int fold_rows_batched(const FoldBatch& b, hipStream_t st);
+int layernorm_bwd_partial_rows(int rows);     // rows of the [.][2W] partial matrix layernorm_bwd leaves in ws
 int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, float* x, int B, int L, int W, int vocab,
               hipStream_t st);
 int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dtok, float* dpos, int B, int L, int W,

@@ -184,6 +184,8 @@ static int lnb_blocks(int rows) {
     return b > LNB_BLOCKS ? LNB_BLOCKS : b;
 }
 
+int layernorm_bwd_partial_rows(int rows) { return lnb_blocks(rows); }
+
 size_t layernorm_bwd_workspace_bytes(int rows, int W) { return (size_t)lnb_blocks(rows) * 2 * W * sizeof(float); }
 
 int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
@@ -211,6 +213,7 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     else SPN_LN_BWD(8);
 #undef SPN_LN_BWD
     SPN_CHECK_LAUNCH();
+    if (want_param && accumulate_dparam == 2) return SPN_OK;   // the caller folds ws [blocks][2W] itself (fold_rows_batched)
     if (want_param) {
         if (dbeta == dgamma + W)   // adjacent in the flat gradient buffer: one fold over [dgamma | dbeta]
             return fold_rows(ws, (size_t)2 * W, blocks, (size_t)2 * W, dgamma, 1.0f, accumulate_dparam, st);

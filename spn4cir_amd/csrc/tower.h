@@ -118,6 +118,7 @@ struct BwdDefer {
     bf16_t* dqkv;        // [T, 3W]
     bf16_t* dx_mid;      // [T, W]  residual gradient between the two halves of the block
     bf16_t* dx_out;      // [T, W]  bf16 gradient leaving the block (dx_bf16, the one entering it, stays intact)
+    float* ln_partials;  // 2 x layernorm_bwd_workspace_bytes: [ln_2 | ln_1] row partials of dgamma / dbeta, folded by the caller
     TnProblem* problems; // [4]
 };
 // dxb_group (optional, [T, W] bf16): enables the grouped weight-gradient launch at the end of the block (tower.hip)

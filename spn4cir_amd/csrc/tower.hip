@@ -267,8 +267,11 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         SPN_TRY(gemm_nt(dpre, P.w_fc_t, T, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
     }
     if (!grouped) SPN_TRY(gemm_tn(dpre, A.h2, T, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, wws, wws_bytes, sw));
-    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dxb_mid, G.ln2_g, G.ln2_b, 0, T, W, ws,
-                          ws_bytes, st));
+    const size_t lnp = layernorm_bwd_workspace_bytes(T, W);       // deferred: partials stay in the block's own buffer
+    if (defer) SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dxb_mid, G.ln2_g, G.ln2_b, 2, T, W,
+                                     defer->ln_partials, lnp, st));
+    else SPN_TRY(layernorm_bwd(dh, nullptr, A.x_mid, P.ln2_g, A.mean2, A.rstd2, dx, 1, dxb_mid, G.ln2_g, G.ln2_b, 0, T, W, ws,
+                               ws_bytes, st));
     // attention
     SPN_TRY(fork(2));                                  // dxb_mid is final
     {
@@ -319,8 +322,10 @@ int block_bwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, const
         hipError_t e = hipStreamWaitEvent(st, ov->ev[4], 0);
         if (e != hipSuccess) return (int)e;
     }
-    SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, defer ? defer->dx_out : dx_bf16, G.ln1_g,
-                          G.ln1_b, 0, T, W, ws, ws_bytes, st));
+    if (defer) SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, defer->dx_out, G.ln1_g, G.ln1_b, 2,
+                                     T, W, (float*)((char*)defer->ln_partials + lnp), lnp, st));
+    else SPN_TRY(layernorm_bwd(dh, nullptr, A.x_in, P.ln1_g, A.mean1, A.rstd1, dx, 1, dx_bf16, G.ln1_g, G.ln1_b, 0, T, W, ws,
+                               ws_bytes, st));
     // every parameter gradient of the block is final in `st` order on return (DDP bucket hooks rely on it), and
     // the scratch / dxb_alt buffers are free for the next block
     SPN_TRY(join(5));
@@ -439,7 +444,8 @@ static const BwdOverlap* bwd_overlap(bf16_t* dxb_alt, float* ws2, size_t ws2_byt
 // entering the block; the top block reads the head's buffer instead)
 static size_t text_defer_layer_bytes(const BlockCfg& bc) {
     const size_t T = (size_t)bc.rows(), W = bc.W;
-    return align256(T * 4 * W * 2) + align256(T * 3 * W * 2) + 2 * align256(T * W * 2);
+    return align256(T * 4 * W * 2) + align256(T * 3 * W * 2) + 2 * align256(T * W * 2) +
+           align256(2 * layernorm_bwd_workspace_bytes((int)T, (int)W));
 }
 
 size_t text_ws_bytes(const TextCfg& c) {
@@ -548,7 +554,7 @@ struct TextBwdWs {
     size_t opws_bytes;
 };
 
-struct TextDeferBufs { bf16_t *dpre, *dqkv, *dx_mid, *dx_in; };
+struct TextDeferBufs { bf16_t *dpre, *dqkv, *dx_mid, *dx_in; float* ln_partials; };
 static TextDeferBufs text_defer_at(const TextBwdWs& w, const BlockCfg& bc, int l) {
     const size_t T = (size_t)bc.rows(), W = bc.W;
     char* p = w.defer + w.defer_stride * l;
@@ -556,7 +562,8 @@ static TextDeferBufs text_defer_at(const TextBwdWs& w, const BlockCfg& bc, int l
     d.dpre = (bf16_t*)p; p += align256(T * 4 * W * 2);
     d.dqkv = (bf16_t*)p; p += align256(T * 3 * W * 2);
     d.dx_mid = (bf16_t*)p; p += align256(T * W * 2);
-    d.dx_in = (bf16_t*)p;
+    d.dx_in = (bf16_t*)p; p += align256(T * W * 2);
+    d.ln_partials = (float*)p;
     return d;
 }
 
@@ -657,7 +664,7 @@ int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t*
     const TextDeferBufs d = text_defer_at(w, bc, l);
     TnProblem unused[4];
     BwdDefer df;
-    df.dpre = d.dpre; df.dqkv = d.dqkv; df.dx_mid = d.dx_mid;
+    df.dpre = d.dpre; df.dqkv = d.dqkv; df.dx_mid = d.dx_mid; df.ln_partials = d.ln_partials;
     df.dx_out = l > 0 ? text_defer_at(w, bc, l - 1).dx_in : w.dxb2;      // the gradient entering block l-1
     df.problems = unused;                                               // rebuilt by text_bwd_wgrad from the layout
     bf16_t* dx_in = (l == c.layers - 1) ? w.dxb : d.dx_in;
@@ -677,7 +684,26 @@ int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int 
     TnProblem q[TN_GROUP_MAX];
     int n = 0;
     for (int l = l_end - 1; l >= l_begin; --l, n += 4) SPN_TRY(text_defer_problems(c, w, bc, A, grads, t, l, q + n));
-    return gemm_tn_grouped(q, n, bc.rows(), w.opws, w.opws_bytes, st);
+    SPN_TRY(gemm_tn_grouped(q, n, bc.rows(), w.opws, w.opws_bytes, st));
+    // the LayerNorm parameter gradients of the same blocks: one batched fold of their row partials ([dgamma | dbeta] are
+    // adjacent in the flat gradient layout)
+    const size_t lnp = layernorm_bwd_workspace_bytes(bc.rows(), c.W);
+    FoldBatch fb{};
+    fb.n = layernorm_bwd_partial_rows(bc.rows());
+    fb.stride = (size_t)2 * c.W;
+    fb.C = (size_t)2 * c.W;
+    for (int l = l_end - 1; l >= l_begin; --l) {
+        const TextDeferBufs d = text_defer_at(w, bc, l);
+        const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+        if (G.ln2_b != G.ln2_g + c.W || G.ln1_b != G.ln1_g + c.W) return SPN_ERR_ARG;
+        fb.ws[fb.items] = d.ln_partials; fb.out[fb.items++] = G.ln2_g;
+        fb.ws[fb.items] = (const float*)((const char*)d.ln_partials + lnp); fb.out[fb.items++] = G.ln1_g;
+        if (fb.items + 2 > FOLD_BATCH_MAX || l == l_begin) {
+            SPN_TRY(fold_rows_batched(fb, st));
+            fb.items = 0;
+        }
+    }
+    return SPN_OK;
 }
 
 // phase 3: token / positional embedding gradients
