@@ -84,6 +84,133 @@ __device__ __forceinline__ bf16x8 nt2_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * (BKT * 2) + (nt2_swz<BKT>(r, c) << 4));
 }
 
+// Fast path of nt_epilogue for FULL tiles (every row / column inside the matrix, 16-byte aligned rows): the same staging,
+// but straight-line - no per-row bounds, width or output-pointer branches (the general path compiles to ~470 branches,
+// each closing the scheduling window of a wave).  OUT_F32 / OUT_BF16 / AUX_OUT are the (block-uniform) outputs in use.
+template <int BM, int BN, int WM, int WN, int LDS_BYTES, int MODE, int ACT, bool OUT_F32, bool OUT_BF16, bool AUX_OUT>
+__device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem, int m0, int n0, int wr,
+                                                 int wc, int wid, int lane, const GemmEpilogue& ep) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
+    constexpr int CR0 = LDS_BYTES / (BN * 4);
+    constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;
+    constexpr int NCH = BM / CHUNK;
+    constexpr int LPR = BN / 8, RPI = 64 / LPR;
+    constexpr int ITERS = CHUNK / (NW * RPI);
+    static_assert(BM % CHUNK == 0 && CHUNK % (NW * RPI) == 0 && CHUNK % 32 == 0, "full-tile epilogue geometry");
+    float* sC = (float*)smem;
+    const int u = lane % LPR, n = n0 + u * 8;
+    f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
+    if (ep.bias) {
+        bias_lo = *(const f32x4*)(ep.bias + n);
+        bias_hi = *(const f32x4*)(ep.bias + n + 4);
+    }
+    const float alpha = ep.alpha;
+    const int row_l = wid * RPI + lane / LPR;                     // first row of this lane inside a chunk
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const size_t obase = (size_t)(m0 + ch * CHUNK + row_l) * ep.ldc + n;
+        [[maybe_unused]] bf16x8 pf_aux[ITERS];
+        [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
+        if constexpr (MODE == GEMM_DACT) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) pf_aux[it] = *(const bf16x8*)(ep.aux_in + obase + (size_t)it * NW * RPI * ep.ldc);
+        } else if constexpr (MODE == GEMM_RESID) {
+            const float* rp = ep.resid + (size_t)(m0 + ch * CHUNK + row_l) * ep.ldr + n;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                pf_r0[it] = *(const f32x4*)(rp + (size_t)it * NW * RPI * ep.ldr);
+                pf_r1[it] = *(const f32x4*)(rp + (size_t)it * NW * RPI * ep.ldr + 4);
+            }
+        }
+        __syncthreads();   // operand tiles (or the previous chunk) are no longer read
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if ((wr * TM + i * 32) / CHUNK != ch) continue;       // wave-uniform; compile-time when TM <= CHUNK
+            const int r = wr * TM + i * 32 + (lane & 31) - ch * CHUNK;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int unit = (wc * TN + j * 32 + 8 * g) / 4 + (lane >> 5);
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
+                }
+        }
+        __syncthreads();
+        // read-back in batches of RB rows: all LDS reads of a batch in flight, then its math and stores
+        constexpr int RB = ITERS >= 4 ? 4 : ITERS;
+        static_assert(ITERS % RB == 0, "read-back batches");
+#pragma unroll
+        for (int it0 = 0; it0 < ITERS; it0 += RB) {
+        f32x4 t0[RB], t1[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int rr = row_l + (it0 + q) * NW * RPI;
+            t0[q] = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
+            t1[q] = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int it = it0 + q;
+            f32x4 v0 = t0[q] * alpha + bias_lo, v1 = t1[q] * alpha + bias_hi;
+            const size_t o = obase + (size_t)it * NW * RPI * ep.ldc;
+            auto pack8 = [](f32x4 x, f32x4 y) {
+                bf16x8 p = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+                return p;
+            };
+            if constexpr (MODE == GEMM_STORE && ACT != ACT_NONE) {
+                if constexpr (AUX_OUT) {
+                    if (ep.aux_grad) {                            // block-uniform
+                        f32x4 g0, g1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            act_and_grad_into(ACT, v0[e], v0[e], g0[e]);
+                            act_and_grad_into(ACT, v1[e], v1[e], g1[e]);
+                        }
+                        *(bf16x8*)(ep.aux_out + o) = pack8(g0, g1);
+                    } else {
+                        *(bf16x8*)(ep.aux_out + o) = pack8(v0, v1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                        v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                    }
+                }
+            } else if constexpr (MODE == GEMM_RESID) {
+                v0 += pf_r0[it];
+                v1 += pf_r1[it];
+            } else if constexpr (MODE == GEMM_DACT) {
+                const bf16x8 p = pf_aux[it];
+                if (ep.aux_grad) {                                // block-uniform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] *= bf2f(p[e]); v1[e] *= bf2f(p[4 + e]); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = bf2f(p[e]), x1 = bf2f(p[4 + e]);
+                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
+                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
+                    }
+                }
+            }
+            if constexpr (OUT_F32) {
+                *(f32x4*)(ep.out_f32 + o) = v0;
+                *(f32x4*)(ep.out_f32 + o + 4) = v1;
+            }
+            if constexpr (OUT_BF16) *(bf16x8*)(ep.out_bf16 + o) = pack8(v0, v1);
+        }
+        }
+    }
+}
+
 // Epilogue shared by the NT kernels.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3,
 // the 4 consecutive columns n = 8g + 4*(lane>>5) + 0..3 of each 32x32 tile (regs 4g..4g+3).
 // Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
@@ -94,6 +221,24 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                                             int n0, int wr, int wc, int wid, int lane, const GemmEpilogue& ep) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
+    if constexpr (MODE != GEMM_BANKSTATS && BM == 256 && BN == 256 && LDS_BYTES >= 131072) {
+        // full tile with 16-byte aligned rows and one of the usual output combinations: the straight-line path
+        const bool full = !ep.direct_store && m0 + BM <= M && n0 + BN <= N && ep.ldc % 8 == 0 &&
+                          (MODE != GEMM_RESID || ep.ldr % 4 == 0) && !(ep.dbg & 256);
+        if (full) {
+            const bool f32o = ep.out_f32 != nullptr, b16o = ep.out_bf16 != nullptr, aux = ep.aux_out != nullptr;
+#define SPN_EPI_FULL(F_, B_, A_) \
+            nt_epilogue_full<BM, BN, WM, WN, LDS_BYTES, MODE, ACT, F_, B_, A_>(acc, smem, m0, n0, wr, wc, wid, lane, ep)
+            if constexpr (MODE == GEMM_STORE && ACT != ACT_NONE) {
+                if (b16o && !f32o && aux) { SPN_EPI_FULL(false, true, true); return; }
+                if (b16o && !f32o && !aux) { SPN_EPI_FULL(false, true, false); return; }
+            } else {
+                if (b16o && !f32o) { SPN_EPI_FULL(false, true, false); return; }
+                if (f32o && !b16o) { SPN_EPI_FULL(true, false, false); return; }
+            }
+#undef SPN_EPI_FULL
+        }
+    }
     if (!ep.direct_store) {
         constexpr int CR0 = LDS_BYTES / (BN * 4);
         constexpr int CHUNK = CR0 >= BM ? BM : (CR0 / 32) * 32;     // rows per staging pass
