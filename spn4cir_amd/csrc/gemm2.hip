@@ -477,6 +477,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
     static_assert(A_BYTES % (1024 * NW) == 0 && B_BYTES % (1024 * NW) == 0 && TM % 32 == 0 && TN % 32 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // SPN_GEMM_DBG bit 64: phase times (shader cycles) of a mid-grid block - setup / prologue (first DMA + wait) /
+    // k loop / epilogue - written over the first 16 bytes of the output
+    const uint64_t ph0 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    uint64_t ph2 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
     const int tiles_n = (N + BN - 1) / BN;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 
     // SPN_GEMM_DBG bit 32: clock probe - shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) spent in
     // the main loop of the last tile, written over the first 8 bytes of the bf16 output
-    const uint64_t dbg_c0 = (ep.dbg & 32) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_c0 = (ep.dbg & (32 | 64)) ? __builtin_readcyclecounter() : 0;
     const uint64_t dbg_r0 = (ep.dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
 
     const int nk = K / BKT;
@@ -545,6 +549,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         if (nk > 1) { chunk(0, 1); chunk(1, 1); }
         wait_tile(nk > 1);
         __builtin_amdgcn_s_barrier();
+        if (ep.dbg & 64) ph2 = __builtin_readcyclecounter();
         if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger the lower half by one barrier
         bf16x8 a[2][4], b0[4], b1[4];
         const int arow = wr * TM + (lane & 31), brow = wc * TN + (lane & 31), cl = lane >> 5;
@@ -691,7 +696,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         if (t == 12345.678f && ep.out_f32) ep.out_f32[0] = t;
         return;
     }
+    const uint64_t ph3 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
     nt_epilogue<BM, BN, WM, WN, STAGES * STAGE, MODE, ACT>(acc, smem, M, N, m0, n0, wr, wc, wid, lane, ep);
+    if ((ep.dbg & 64) && blockIdx.x == gridDim.x / 2 && tid == 0) {
+        const uint64_t ph4 = __builtin_readcyclecounter();
+        uint32_t* o = ep.out_f32 ? (uint32_t*)ep.out_f32 : (uint32_t*)ep.out_bf16;
+        o[0] = (uint32_t)(dbg_c0 - ph0);
+        o[1] = (uint32_t)(ph2 - dbg_c0);
+        o[2] = (uint32_t)(ph4 - ph3);
+        o[3] = (uint32_t)(ph3 - ph2);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>

@@ -51,7 +51,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 extra = (f"  k loop of the last tile: {cyc} cycles = {cyc / (K / 64):.0f} per k tile (2048 = MFMA bound), "
                          f"{ticks * 10} ns -> {cyc / max(ticks, 1) * 100:.0f} MHz")
             if int(os.environ.get("SPN_GEMM_DBG", "0")) & 64:
-                extra = "  block 0 cycles (setup, asm, k loop, epilogue):"
+                extra = "  cycles (setup / asm or prologue / k loop / epilogue):"
                 bias = torch.randn(N, device="cuda")
                 for name, kw in (("bf16", {}), ("bf16+bias", dict(bias=bias)),
                                  ("gelu+pre", dict(bias=bias, act=ops.ACT_QUICKGELU, want_pre=True))):
@@ -66,6 +66,10 @@ else:
             print(f"== SPN_GEMM_CFG=7 SPN_NT3_VAR={var} (1 no DMA, 2 no fragment reads, 3 no barrier, 4 MFMA only)", flush=True)
             env = dict(os.environ, SPN_GEMM_CFG="7", SPN_NT3_VAR=var, SPN_GEMM_DBG="32")
             subprocess.run(["timeout", "120", sys.executable, __file__, "child", "time"], env=env)
+        sys.exit(0)
+    if sys.argv[1:2] == ["phases2"]:          # the production 8-wave kernel: setup / prologue / k loop / epilogue
+        env = dict(os.environ, SPN_GEMM_DBG="64")
+        subprocess.run(["timeout", "120", sys.executable, __file__, "child", "time"], env=env)
         sys.exit(0)
     if sys.argv[1:2] == ["phases"]:
         env = dict(os.environ, SPN_GEMM_CFG="7", SPN_GEMM_DBG="64")
