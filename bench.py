@@ -42,7 +42,7 @@ FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 
 
 # attention at L = 77, head_dim 64 has 39 flop per byte of q/k/v/o traffic (ridge: 312): it is bounded by HBM, and is
 # priced on its algorithmic bytes (fwd: read qkv, write o = 8 W B per token; bwd: read qkv, o, dO, write dqkv = 16 W B)
-KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn_kernel (+ split-K reduce)", "mfma"),
+KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn (grouped weight gradients, no split-K, + tail reduce)", "mfma"),
            2: ("attention_small_fwd_kernel", "hbm"), 3: ("attention_small_bwd_kernel", "hbm"),
            4: ("bank forward pass (GEMM path at B >= 128)", "hbm"), 5: ("bank_stream_kernel<bwd>", "hbm")}
 
