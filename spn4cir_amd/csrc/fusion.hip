@@ -261,6 +261,25 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     return SPN_OK;
 }
 
+// Deferred weight gradients (as in the text tower, tower.hip): each layer keeps the dY operands of its seven products
+// dW = dY^T X in buffers of its own - dyb after each of the three LayerNorm backward passes [T,W] x3, dpre [T,I],
+// dq of the cross-attention [T,W], dqkv of the self-attention [T,3W], dkv of the cross-attention [B*S,2W] - and the
+// products of ALL layers run behind the data path as grouped launches without split-K (gemm_tn_grouped): the six with
+// the text rows as reduction (36 problems per launch), and the cross-attention K/V projection of all layers
+// (reduction over the B*S image tokens).  SPN_TN_GROUP=0: one split-K launch per product as before.
+static size_t fusion_defer_layer_bytes(const FusionCfg& c) {
+    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    return 4 * fa(T * W * 2) + fa(T * I * 2) + fa(T * 3 * W * 2) + fa(TS * 2 * W * 2);
+}
+
+static bool fusion_tn_group_on() {
+    static const bool on = [] {
+        const char* e = getenv("SPN_TN_GROUP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 size_t fusion_ws_bytes(const FusionCfg& c) {
     const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
     size_t b = 0;
@@ -271,6 +290,7 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     b += fa(TS * 2 * W * 2);                                     // dkv2
     b += fa((size_t)c.B * c.H * c.L * 4);                        // delta
     b += fa((size_t)c.B * c.Dp * 2) + fa((size_t)c.B * W * 4);   // dproj bf16, dh0
+    b += fusion_defer_layer_bytes(c) * c.layers;                 // per-layer dY operands of the deferred weight gradients
     size_t op = 0;
     auto mx = [&](size_t v) { if (v > op) op = v; };
     mx(gemm_tn_workspace_bytes((int)T, (int)W, (int)I));
@@ -279,6 +299,7 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     mx(gemm_tn_workspace_bytes((int)T, 3 * (int)W, (int)W));
     mx(gemm_tn_workspace_bytes((int)TS, 2 * (int)W, c.E));
     mx(gemm_tn_workspace_bytes(c.B, c.Dp, (int)W));
+    mx(gemm_tn_grouped_workspace_bytes((int)TS));
     mx(layernorm_bwd_workspace_bytes((int)T, (int)W));
     return b + fa(op);
 }
@@ -305,6 +326,12 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
     bf16_t* dprojb = (bf16_t*)take((size_t)c.B * c.Dp * 2);
     float* dh0 = (float*)take((size_t)c.B * W * 4);
+    char* defer_base = p;
+    const size_t defer_stride = fusion_defer_layer_bytes(c);
+    p += defer_stride * c.layers;
+    const bool grouped = fusion_tn_group_on() && c.layers * 6 <= 2 * TN_GROUP_MAX && c.layers <= TN_GROUP_MAX;
+    TnProblem qT[2 * TN_GROUP_MAX], qS[TN_GROUP_MAX];
+    int nT = 0, nS = 0;
     float* opws = (float*)p;
     const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
 
@@ -323,51 +350,71 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         auto P = [&](int i) { return pp + t.layer_off[i]; };
         auto G = [&](int i) { return gp + t.layer_off[i]; };
         auto Bw = [&](int i) { return b + t.bf16_off[i]; };
+        // the dY operands of this layer's weight gradients: buffers of its own when they are deferred
+        bf16_t *dyb_ff = dyb, *dyb_ca = dyb, *dyb_sa = dyb, *dpre_l = dpre, *dq_ca = dqkv, *dqkv_sa = dqkv, *dkv2_l = dkv2;
+        if (grouped) {
+            char* q = defer_base + defer_stride * l;
+            auto tk = [&](size_t bytes) { char* r = q; q += fa(bytes); return (bf16_t*)r; };
+            dyb_ff = tk(Ts * W * 2); dyb_ca = tk(Ts * W * 2); dyb_sa = tk(Ts * W * 2); dq_ca = tk(Ts * W * 2);
+            dpre_l = tk(Ts * I * 2); dqkv_sa = tk(Ts * 3 * W * 2); dkv2_l = tk((size_t)TS * 2 * W * 2);
+        }
+        auto wgrad = [&](const bf16_t* Aop, const bf16_t* Bop, int Kr, int N1, int N2, float* Cw, float* cb) -> int {
+            if (!grouped) return gemm_tn(Aop, Bop, Kr, N1, N2, N1, N2, Cw, N2, 1.0f, 0, cb, opws, opws_bytes, st);
+            TnProblem pr{Aop, Bop, Cw, cb, N1, N2, N1, N2, N2};
+            if (Kr == T) qT[nT++] = pr;
+            else qS[nS++] = pr;
+            return SPN_OK;
+        };
         // ---- FFN: x3 = LN(y3), y3 = x2 + gelu(x2 W1^T + b1) W2^T + b2
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y3, P(LO_FF_LNG), a.mean3, a.rstd3, dy, 0, dyb, G(LO_FF_LNG), G(LO_FF_LNB), 0, T, W,
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y3, P(LO_FF_LNG), a.mean3, a.rstd3, dy, 0, dyb_ff, G(LO_FF_LNG), G(LO_FF_LNB), 0, T, W,
                                opws, opws_bytes, st));
         {
             GemmEpilogue e;
-            e.aux_in = a.pre; e.aux_grad = 1; e.act = ACT_GELU_ERF; e.out_bf16 = dpre; e.ldc = I;
-            SPN_TRYF(gemm_nt(dyb, Bw(BO_FF_W2_T), T, I, W, W, W, GEMM_DACT, e, st));
+            e.aux_in = a.pre; e.aux_grad = 1; e.act = ACT_GELU_ERF; e.out_bf16 = dpre_l; e.ldc = I;
+            SPN_TRYF(gemm_nt(dyb_ff, Bw(BO_FF_W2_T), T, I, W, W, W, GEMM_DACT, e, st));
         }
-        SPN_TRYF(gemm_tn(dyb, a.u, T, W, I, W, I, G(LO_FF_W2), I, 1.0f, 0, G(LO_FF_B2), opws, opws_bytes, st));
-        SPN_TRYF(gemm_tn(dpre, a.x2b, T, I, W, I, W, G(LO_FF_W1), W, 1.0f, 0, G(LO_FF_B1), opws, opws_bytes, st));
-        SPN_TRYF(nt_resid(dpre, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));          // dx = d/dx2
+        SPN_TRYF(wgrad(dyb_ff, a.u, T, W, I, G(LO_FF_W2), G(LO_FF_B2)));
+        SPN_TRYF(wgrad(dpre_l, a.x2b, T, I, W, G(LO_FF_W1), G(LO_FF_B1)));
+        SPN_TRYF(nt_resid(dpre_l, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));        // dx = d/dx2
         // ---- cross-attention: x2 = LN(y2), y2 = x1 + attn(q(x1), kv(enc)) Wo^T + bo
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y2, P(LO_CA_LNG), a.mean2, a.rstd2, dy, 0, dyb, G(LO_CA_LNG), G(LO_CA_LNB), 0, T, W,
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y2, P(LO_CA_LNG), a.mean2, a.rstd2, dy, 0, dyb_ca, G(LO_CA_LNG), G(LO_CA_LNB), 0, T, W,
                                opws, opws_bytes, st));
-        SPN_TRYF(nt(dyb, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
-        SPN_TRYF(gemm_tn(dyb, a.ctx2, T, W, W, W, W, G(LO_CA_WO), W, 1.0f, 0, G(LO_CA_BO), opws, opws_bytes, st));
+        SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(wgrad(dyb_ca, a.ctx2, T, W, W, G(LO_CA_WO), G(LO_CA_BO)));
         {
             AttnBwdArgs g;
             g.f = cross_attn_args(c, a);
             g.d_o = dctx; g.lddo = W;
-            g.dq = dqkv; g.lddq = W;
-            g.dk = dkv2; g.dv = dkv2 + W; g.lddk = g.lddv = 2 * W;
+            g.dq = dq_ca; g.lddq = W;
+            g.dk = dkv2_l; g.dv = dkv2_l + W; g.lddk = g.lddv = 2 * W;
             g.delta = delta;
             SPN_TRYF(attention_bwd(g, st));
         }
-        SPN_TRYF(gemm_tn(dkv2, A.enc_b, TS, 2 * W, E, 2 * W, E, G(LO_CA_WKV), E, 1.0f, 0, G(LO_CA_BKV), opws, opws_bytes, st));
-        SPN_TRYF(gemm_tn(dqkv, a.x1b, T, W, W, W, W, G(LO_CA_WQ), W, 1.0f, 0, G(LO_CA_BQ), opws, opws_bytes, st));
-        SPN_TRYF(nt_resid(dqkv, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));          // dx = d/dx1
+        SPN_TRYF(wgrad(dkv2_l, A.enc_b, TS, 2 * W, E, G(LO_CA_WKV), G(LO_CA_BKV)));
+        SPN_TRYF(wgrad(dq_ca, a.x1b, T, W, W, G(LO_CA_WQ), G(LO_CA_BQ)));
+        SPN_TRYF(nt_resid(dq_ca, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));         // dx = d/dx1
         // ---- self-attention: x1 = LN(y1), y1 = x_in + attn(qkv(x_in)) Wo^T + bo
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y1, P(LO_SA_LNG), a.mean1, a.rstd1, dy, 0, dyb, G(LO_SA_LNG), G(LO_SA_LNB), 0, T, W,
+        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y1, P(LO_SA_LNG), a.mean1, a.rstd1, dy, 0, dyb_sa, G(LO_SA_LNG), G(LO_SA_LNB), 0, T, W,
                                opws, opws_bytes, st));
-        SPN_TRYF(nt(dyb, Bw(BO_SA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
-        SPN_TRYF(gemm_tn(dyb, a.ctx1, T, W, W, W, W, G(LO_SA_WO), W, 1.0f, 0, G(LO_SA_BO), opws, opws_bytes, st));
+        SPN_TRYF(nt(dyb_sa, Bw(BO_SA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(wgrad(dyb_sa, a.ctx1, T, W, W, G(LO_SA_WO), G(LO_SA_BO)));
         {
             AttnBwdArgs g;
             g.f = self_attn_args(c, a, A.key_bias);
             g.d_o = dctx; g.lddo = W;
-            g.dq = dqkv; g.dk = dqkv + W; g.dv = dqkv + 2 * W;
+            g.dq = dqkv_sa; g.dk = dqkv_sa + W; g.dv = dqkv_sa + 2 * W;
             g.lddq = g.lddk = g.lddv = 3 * W;
             g.delta = delta;
             SPN_TRYF(attention_bwd(g, st));
         }
-        SPN_TRYF(gemm_tn(dqkv, a.xb_in, T, 3 * W, W, 3 * W, W, G(LO_SA_WQKV), W, 1.0f, 0, G(LO_SA_BQKV), opws, opws_bytes, st));
-        SPN_TRYF(nt_resid(dqkv, Bw(BO_SA_WQKV_T), T, W, 3 * W, nullptr, dy, dx, st));     // dx = d/dx_in
+        SPN_TRYF(wgrad(dqkv_sa, a.xb_in, T, 3 * W, W, G(LO_SA_WQKV), G(LO_SA_BQKV)));
+        SPN_TRYF(nt_resid(dqkv_sa, Bw(BO_SA_WQKV_T), T, W, 3 * W, nullptr, dy, dx, st));  // dx = d/dx_in
     }
+    // the deferred weight gradients: everything with the text rows as reduction (<= 48 problems per launch), then the
+    // cross-attention K/V projections of all layers (reduction over the image tokens)
+    for (int i = 0; i < nT; i += TN_GROUP_MAX)
+        SPN_TRYF(gemm_tn_grouped(qT + i, nT - i < TN_GROUP_MAX ? nT - i : TN_GROUP_MAX, T, opws, opws_bytes, st));
+    if (nS) SPN_TRYF(gemm_tn_grouped(qS, nS, TS, opws, opws_bytes, st));
     // embeddings: x0 = LN(word[ids] + pos)
     SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
                            grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));

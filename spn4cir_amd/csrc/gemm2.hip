@@ -577,12 +577,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         __builtin_amdgcn_sched_barrier(0);                                                              \
         SPN_SLOT_BAR(1);                                                                                \
         __builtin_amdgcn_sched_barrier(0);
-        const bool dma = !(ep.dbg & 2);
+// SPN_GEMM_LOOP_DBG=1 builds keep the bottleneck-elimination switches of the loop (SPN_GEMM_DBG bits 2 and 4: no DMA /
+// fragments read once); the shipped loop has no such branches in its slots
+#ifndef SPN_GEMM_LOOP_DBG
+#define SPN_GEMM_LOOP_DBG 0
+#endif
+        const bool dma = SPN_GEMM_LOOP_DBG ? !(ep.dbg & 2) : true;
         for (int kt = 0; kt < nk; ++kt) {
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sB = sA + A_BYTES;
             const bool n1 = kt + 1 < nk && dma, n2 = kt + 2 < nk && dma;
-            const bool rd = !(ep.dbg & 4) || kt == 0;
+            const bool rd = SPN_GEMM_LOOP_DBG ? (!(ep.dbg & 4) || kt == 0) : true;
             // slot 0
             if (rd) {
 #pragma unroll
