@@ -72,12 +72,23 @@ int fusion_refresh_bf16(const FusionCfg& c, const float* params, bf16_t* wb, hip
     const int src[BO_SIZE / 2] = {LO_SA_WQKV, LO_SA_WO, LO_CA_WQ, LO_CA_WKV, LO_CA_WO, LO_FF_W1, LO_FF_W2};
     const int rows[BO_SIZE / 2] = {3 * W, W, W, 2 * W, W, I, W};
     const int cols[BO_SIZE / 2] = {W, W, W, E, W, W, I};
-    for (int l = 0; l < c.layers; ++l) {
-        const float* p = params + t.layers + t.layer_size * l;
-        bf16_t* b = wb + t.bf16_layer_size * l;
-        for (int i = 0; i < BO_SIZE / 2; ++i)
-            SPN_TRYF(cast_transpose_f32_bf16(p + t.layer_off[src[i]], b + t.bf16_off[2 * i], b + t.bf16_off[2 * i + 1],
-                                             rows[i], cols[i], st));
+    // all layers at once, four matrices per launch (cast_transpose_multi) instead of one launch per matrix
+    for (int i0 = 0; i0 < BO_SIZE / 2; i0 += 4) {
+        CastTransposeSet d{};
+        d.tile_start[0] = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k;
+            if (i < BO_SIZE / 2) {
+                d.src[k] = t.layer_off[src[i]]; d.dst[k] = t.bf16_off[2 * i]; d.dst_t[k] = t.bf16_off[2 * i + 1];
+                d.rows[k] = rows[i]; d.cols[k] = cols[i];
+                d.tile_start[k + 1] = d.tile_start[k] + ((rows[i] + 31) / 32) * ((cols[i] + 31) / 32);
+            } else {
+                d.rows[k] = d.cols[k] = 0;
+                d.tile_start[k + 1] = d.tile_start[k];
+            }
+        }
+        d.p_stride = t.layer_size; d.wb_stride = t.bf16_layer_size;
+        SPN_TRYF(cast_transpose_multi(params + t.layers, wb, d, c.layers, st));
     }
     SPN_TRYF(cast_transpose_f32_bf16(params + t.proj_w, wb + t.bf16_proj, wb + t.bf16_proj_t, c.Dp, c.W, st));
     return SPN_OK;
@@ -269,7 +280,8 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
 // (reduction over the B*S image tokens).  SPN_TN_GROUP=0: one split-K launch per product as before.
 static size_t fusion_defer_layer_bytes(const FusionCfg& c) {
     const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
-    return 4 * fa(T * W * 2) + fa(T * I * 2) + fa(T * 3 * W * 2) + fa(TS * 2 * W * 2);
+    return 4 * fa(T * W * 2) + fa(T * I * 2) + fa(T * 3 * W * 2) + fa(TS * 2 * W * 2) +
+           3 * fa(layernorm_bwd_workspace_bytes((int)T, (int)W));     // + row partials of the three LayerNorm backward passes
 }
 
 static bool fusion_tn_group_on() {
@@ -332,6 +344,17 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     const bool grouped = fusion_tn_group_on() && c.layers * 6 <= 2 * TN_GROUP_MAX && c.layers <= TN_GROUP_MAX;
     TnProblem qT[2 * TN_GROUP_MAX], qS[TN_GROUP_MAX];
     int nT = 0, nS = 0;
+    const size_t lnp = fa(layernorm_bwd_workspace_bytes(T, W));
+    FoldBatch fb{};                                   // LayerNorm parameter gradients: folded in batches behind the loop
+    fb.n = layernorm_bwd_partial_rows(T);
+    fb.stride = (size_t)2 * W;
+    fb.C = (size_t)2 * W;
+    auto fold_flush = [&]() -> int {
+        if (!fb.items) return SPN_OK;
+        const int rc = fold_rows_batched(fb, st);
+        fb.items = 0;
+        return rc;
+    };
     float* opws = (float*)p;
     const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
 
@@ -352,12 +375,26 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         auto Bw = [&](int i) { return b + t.bf16_off[i]; };
         // the dY operands of this layer's weight gradients: buffers of its own when they are deferred
         bf16_t *dyb_ff = dyb, *dyb_ca = dyb, *dyb_sa = dyb, *dpre_l = dpre, *dq_ca = dqkv, *dqkv_sa = dqkv, *dkv2_l = dkv2;
+        float* ln_part = nullptr;
         if (grouped) {
             char* q = defer_base + defer_stride * l;
             auto tk = [&](size_t bytes) { char* r = q; q += fa(bytes); return (bf16_t*)r; };
             dyb_ff = tk(Ts * W * 2); dyb_ca = tk(Ts * W * 2); dyb_sa = tk(Ts * W * 2); dq_ca = tk(Ts * W * 2);
             dpre_l = tk(Ts * I * 2); dqkv_sa = tk(Ts * 3 * W * 2); dkv2_l = tk((size_t)TS * 2 * W * 2);
+            ln_part = (float*)q;
         }
+        // LayerNorm backward: grouped mode leaves the [dgamma | dbeta] row partials in the layer's buffer (they are
+        // adjacent in the parameter layout) and queues their fold
+        auto ln_bwd = [&](const float* xin, int lo_g, int lo_b, const float* mean, const float* rstd, bf16_t* out_b, int k) -> int {
+            if (grouped && G(lo_b) == G(lo_g) + W) {
+                float* part = (float*)((char*)ln_part + lnp * k);
+                SPN_TRYF(layernorm_bwd(nullptr, dx, xin, P(lo_g), mean, rstd, dy, 0, out_b, G(lo_g), G(lo_b), 2, T, W, part, lnp, st));
+                fb.ws[fb.items] = part; fb.out[fb.items++] = G(lo_g);
+                if (fb.items == FOLD_BATCH_MAX) SPN_TRYF(fold_flush());
+                return SPN_OK;
+            }
+            return layernorm_bwd(nullptr, dx, xin, P(lo_g), mean, rstd, dy, 0, out_b, G(lo_g), G(lo_b), 0, T, W, opws, opws_bytes, st);
+        };
         auto wgrad = [&](const bf16_t* Aop, const bf16_t* Bop, int Kr, int N1, int N2, float* Cw, float* cb) -> int {
             if (!grouped) return gemm_tn(Aop, Bop, Kr, N1, N2, N1, N2, Cw, N2, 1.0f, 0, cb, opws, opws_bytes, st);
             TnProblem pr{Aop, Bop, Cw, cb, N1, N2, N1, N2, N2};
@@ -366,8 +403,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
             return SPN_OK;
         };
         // ---- FFN: x3 = LN(y3), y3 = x2 + gelu(x2 W1^T + b1) W2^T + b2
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y3, P(LO_FF_LNG), a.mean3, a.rstd3, dy, 0, dyb_ff, G(LO_FF_LNG), G(LO_FF_LNB), 0, T, W,
-                               opws, opws_bytes, st));
+        SPN_TRYF(ln_bwd(a.y3, LO_FF_LNG, LO_FF_LNB, a.mean3, a.rstd3, dyb_ff, 0));
         {
             GemmEpilogue e;
             e.aux_in = a.pre; e.aux_grad = 1; e.act = ACT_GELU_ERF; e.out_bf16 = dpre_l; e.ldc = I;
@@ -377,8 +413,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         SPN_TRYF(wgrad(dpre_l, a.x2b, T, I, W, G(LO_FF_W1), G(LO_FF_B1)));
         SPN_TRYF(nt_resid(dpre_l, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));        // dx = d/dx2
         // ---- cross-attention: x2 = LN(y2), y2 = x1 + attn(q(x1), kv(enc)) Wo^T + bo
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y2, P(LO_CA_LNG), a.mean2, a.rstd2, dy, 0, dyb_ca, G(LO_CA_LNG), G(LO_CA_LNB), 0, T, W,
-                               opws, opws_bytes, st));
+        SPN_TRYF(ln_bwd(a.y2, LO_CA_LNG, LO_CA_LNB, a.mean2, a.rstd2, dyb_ca, 1));
         SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
         SPN_TRYF(wgrad(dyb_ca, a.ctx2, T, W, W, G(LO_CA_WO), G(LO_CA_BO)));
         {
@@ -394,8 +429,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         SPN_TRYF(wgrad(dq_ca, a.x1b, T, W, W, G(LO_CA_WQ), G(LO_CA_BQ)));
         SPN_TRYF(nt_resid(dq_ca, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));         // dx = d/dx1
         // ---- self-attention: x1 = LN(y1), y1 = x_in + attn(qkv(x_in)) Wo^T + bo
-        SPN_TRYF(layernorm_bwd(nullptr, dx, a.y1, P(LO_SA_LNG), a.mean1, a.rstd1, dy, 0, dyb_sa, G(LO_SA_LNG), G(LO_SA_LNB), 0, T, W,
-                               opws, opws_bytes, st));
+        SPN_TRYF(ln_bwd(a.y1, LO_SA_LNG, LO_SA_LNB, a.mean1, a.rstd1, dyb_sa, 2));
         SPN_TRYF(nt(dyb_sa, Bw(BO_SA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
         SPN_TRYF(wgrad(dyb_sa, a.ctx1, T, W, W, G(LO_SA_WO), G(LO_SA_BO)));
         {
@@ -415,6 +449,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     for (int i = 0; i < nT; i += TN_GROUP_MAX)
         SPN_TRYF(gemm_tn_grouped(qT + i, nT - i < TN_GROUP_MAX ? nT - i : TN_GROUP_MAX, T, opws, opws_bytes, st));
     if (nS) SPN_TRYF(gemm_tn_grouped(qS, nS, TS, opws, opws_bytes, st));
+    SPN_TRYF(fold_flush());
     // embeddings: x0 = LN(word[ids] + pos)
     SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
                            grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));
