@@ -465,6 +465,16 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     }
 }
 
+// SPN_EXP_NOBAR (experiment builds, tools/build_variant.sh; results are racy): 1 = no barrier behind the MFMA section,
+// 2 = no barrier at all - prices the eight barriers per k tile
+#ifndef SPN_EXP_NOBAR
+#define SPN_EXP_NOBAR 0
+#endif
+// SPN_EXP_XBAR=1 (experiment): every slot barrier twice - prices one barrier event of the 8-wave workgroup
+#ifndef SPN_EXP_XBAR
+#define SPN_EXP_XBAR 0
+#endif
+#define SPN_SLOT_BAR(LVL) do { if (SPN_EXP_NOBAR < LVL) { __builtin_amdgcn_s_barrier(); for (int xb__ = 0; xb__ < SPN_EXP_XBAR; ++xb__) __builtin_amdgcn_s_barrier(); } } while (0)
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M,
@@ -550,18 +560,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         wait_tile(nk > 1);
         __builtin_amdgcn_s_barrier();
         if (ep.dbg & 64) ph2 = __builtin_readcyclecounter();
-        if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger the lower half by one barrier
+        if (wr == 1) SPN_SLOT_BAR(2);                  // stagger the lower half by one barrier (event)
         bf16x8 a[2][4], b0[4], b1[4];
         const int arow = wr * TM + (lane & 31), brow = wc * TN + (lane & 31), cl = lane >> 5;
         // The MFMA builtins carry no side effects, so instruction selection is free to float them across
         // s_barrier; the empty volatile asm statements tie their operands (after the first barrier) and their
         // results (before the second) to the slot.
-// SPN_EXP_NOBAR (experiment builds, tools/build_variant.sh; results are racy): 1 = no barrier behind the MFMA section,
-// 2 = no barrier at all - prices the eight barriers per k tile
-#ifndef SPN_EXP_NOBAR
-#define SPN_EXP_NOBAR 0
-#endif
-#define SPN_SLOT_BAR(LVL) do { if (SPN_EXP_NOBAR < LVL) __builtin_amdgcn_s_barrier(); } while (0)
 #define SPN_SLOT_MFMA(I0, J, BREG)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                              \
         SPN_SLOT_BAR(2);                                                                                \
@@ -624,8 +628,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             if (kt + 1 < nk) wait_tile(n2);             // c0, c1 of k tile kt+1 for its slot 0
             SPN_SLOT_MFMA(2, 0, b0)
         }
+        if (wr == 0) SPN_SLOT_BAR(2);                  // re-align the two halves
 #undef SPN_SLOT_MFMA
-        if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two halves
     } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
