@@ -534,11 +534,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // RAW: a chunk is read one slot after the slot whose pre-barrier wait retired it (both wave halves have
         // then executed that wait before a barrier the reader has passed).
         static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && STAGES == 2 && BKT == 64, "phased schedule geometry");
-        auto chunk = [&](int c, int j) {          // stage chunk c of k tile j (wave-uniform j < nk)
+// SPN_NT_SPLIT_DMA=1 (experiment): the second DMA of a slot's chunk is issued inside the slot's MFMA section (after four
+// MFMA) instead of in its memory section - eight DMA of the four waves of a half no longer hit the address unit as one burst
+#ifndef SPN_NT_SPLIT_DMA
+#define SPN_NT_SPLIT_DMA 0
+#endif
+        auto chunk = [&](int c, int j, int t0 = 0, int t1 = 2) {   // stage chunk c of k tile j (wave-uniform j < nk)
             char* sb = smem + (j & 1) * STAGE;
             const int k0 = j * BKT;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = t0; t < t1; ++t) {
                 const int i = wid * 2 + t;        // 16 DMA instructions x 8 rows per chunk
                 int row0;
                 if (c == 0 || c == 3) row0 = (i < 8 ? 0 : 128) + (c == 3 ? 64 : 0) + (i & 7) * 8;
@@ -552,12 +557,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
             }
         };
         auto wait_tile = [&](bool full) {          // full: a whole newer k tile was issued behind the awaited chunk
+            if (full) wait_vmcnt<SPN_NT_SPLIT_DMA ? 7 : 8>();
+            else wait_vmcnt<0>();
+        };
+        auto wait_first = [&](bool full) {         // the wait in front of the loop: whole chunks were issued
             if (full) wait_vmcnt<8>();
             else wait_vmcnt<0>();
         };
         if (nk > 0) { chunk(0, 0); chunk(1, 0); chunk(2, 0); chunk(3, 0); }
         if (nk > 1) { chunk(0, 1); chunk(1, 1); }
-        wait_tile(nk > 1);
+        wait_first(nk > 1);
         __builtin_amdgcn_s_barrier();
         if (ep.dbg & 64) ph2 = __builtin_readcyclecounter();
         if (wr == 1) SPN_SLOT_BAR(2);                  // stagger the lower half by one barrier (event)
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // The MFMA builtins carry no side effects, so instruction selection is free to float them across
         // s_barrier; the empty volatile asm statements tie their operands (after the first barrier) and their
         // results (before the second) to the slot.
-#define SPN_SLOT_MFMA(I0, J, BREG)                                                                      \
+#define SPN_SLOT_MFMA(I0, J, BREG, DCOND, DC, DJ)                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                              \
         SPN_SLOT_BAR(2);                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
@@ -575,6 +584,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                              \
             acc[I0][J] = mfma32(BREG[kk], a[0][kk], acc[I0][J]);                                        \
             acc[I0 + 1][J] = mfma32(BREG[kk], a[1][kk], acc[I0 + 1][J]);                                \
+            if (SPN_NT_SPLIT_DMA && kk == 1) {                                                          \
+                asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                              \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+                if (DCOND) chunk(DC, DJ, 1, 2);                                                         \
+                __builtin_amdgcn_sched_barrier(0);                                                      \
+            }                                                                                           \
         }                                                                                               \
         asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                      \
         __builtin_amdgcn_s_setprio(0);                                                                  \
@@ -602,17 +617,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                     a[1][kk] = nt2_frag<BKT>(sA, arow + 32, kk * 2 + cl);
                 }
             }
-            if (n1) chunk(2, kt + 1);
+            if (n1) chunk(2, kt + 1, 0, SPN_NT_SPLIT_DMA ? 1 : 2);
             wait_tile(n1);                              // c2(kt) for slot 1
-            SPN_SLOT_MFMA(0, 0, b0)
+            SPN_SLOT_MFMA(0, 0, b0, n1, 2, kt + 1)
             // slot 1
             if (rd) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) b1[kk] = nt2_frag<BKT>(sB, brow + 32, kk * 2 + cl);
             }
-            if (n1) chunk(3, kt + 1);
+            if (n1) chunk(3, kt + 1, 0, SPN_NT_SPLIT_DMA ? 1 : 2);
             wait_tile(n1);                              // c3(kt) for slot 2
-            SPN_SLOT_MFMA(0, 1, b1)
+            SPN_SLOT_MFMA(0, 1, b1, n1, 3, kt + 1)
             // slot 2
             if (rd) {
 #pragma unroll
@@ -621,12 +636,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                     a[1][kk] = nt2_frag<BKT>(sA, arow + 96, kk * 2 + cl);
                 }
             }
-            if (n2) chunk(0, kt + 2);
-            SPN_SLOT_MFMA(2, 1, b1)
+            if (n2) chunk(0, kt + 2, 0, SPN_NT_SPLIT_DMA ? 1 : 2);
+            SPN_SLOT_MFMA(2, 1, b1, n2, 0, kt + 2)
             // slot 3
-            if (n2) chunk(1, kt + 2);
+            if (n2) chunk(1, kt + 2, 0, SPN_NT_SPLIT_DMA ? 1 : 2);
             if (kt + 1 < nk) wait_tile(n2);             // c0, c1 of k tile kt+1 for its slot 0
-            SPN_SLOT_MFMA(2, 0, b0)
+            SPN_SLOT_MFMA(2, 0, b0, n2, 1, kt + 2)
         }
         if (wr == 0) SPN_SLOT_BAR(2);                  // re-align the two halves
 #undef SPN_SLOT_MFMA
