@@ -73,6 +73,7 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
                        mean, rstd, rows, W, eps)
     if (W <= 256) SPN_LN_FWD(1);
     else if (W <= 512) SPN_LN_FWD(2);
+    else if (W <= 768) SPN_LN_FWD(3);
     else if (W <= 1024) SPN_LN_FWD(4);
     else SPN_LN_FWD(8);
 #undef SPN_LN_FWD
@@ -209,6 +210,8 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     } while (0)
     if (W <= 256) SPN_LN_BWD(1);
     else if (W <= 512) SPN_LN_BWD(2);
+    else if (W <= 768) SPN_LN_BWD(3);      // the text towers' width: 144 -> <= 128 registers, 4 instead of 3 waves per SIMD,
+                                           // so all 1024 workgroups are resident in ONE round
     else if (W <= 1024) SPN_LN_BWD(4);
     else SPN_LN_BWD(8);
 #undef SPN_LN_BWD
