@@ -333,19 +333,20 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                             if ((int64_t)(n + e) == lab) lv = x;
                         }
                     }
+                    // row maximum over the tile first (shuffles only), then ONE exponential per logit against it: the
+                    // pairwise online merge cost two more exponentials per lane and shuffle stage (18 instead of 8)
+#pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) {
+                        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                        sl += __shfl_xor(sl, off, 64);
+                        lv = fmaxf(lv, __shfl_xor(lv, off, 64));
+                    }
                     if (mx > -INFINITY) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) l += __expf(z[e] - mx);
                     }
 #pragma unroll
-                    for (int off = LPR / 2; off > 0; off >>= 1) {
-                        const float m2 = __shfl_xor(mx, off, 64), l2 = __shfl_xor(l, off, 64);
-                        const float mn = fmaxf(mx, m2);
-                        if (mn > -INFINITY) l = l * __expf(mx - mn) + l2 * __expf(m2 - mn);
-                        mx = mn;
-                        sl += __shfl_xor(sl, off, 64);
-                        lv = fmaxf(lv, __shfl_xor(lv, off, 64));
-                    }
+                    for (int off = LPR / 2; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
                     if (u == 0) {
                         const int tile_n = n0 / BN;
                         *(f32x4*)(ep.bs_out + ((size_t)tile_n * M + m) * 4) = f32x4{mx, l, sl, lv};
