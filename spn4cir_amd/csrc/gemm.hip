@@ -30,11 +30,12 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // logical k-chunk c (8 elements) sits at position c ^ ((r>>1)&7).
 __device__ __forceinline__ int nt_swz(int r, int c) { return c ^ ((r >> 1) & 7); }
 
+template <int ITER = 4>   // ITER x 32 rows
 __device__ __forceinline__ void nt_stage(__amdgpu_buffer_rsrc_t rs, char* sT, int row0, int ld, int k0,
                                          int wid, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int R0 = (wid * 4 + i) * 8;
+    for (int i = 0; i < ITER; ++i) {
+        const int R0 = (wid * ITER + i) * 8;
         const int r = R0 + (lane >> 3);
         const int c = nt_swz(r, lane & 7);
         const uint32_t off = ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(k0 + c * 8)) * 2u;
@@ -46,11 +47,15 @@ __device__ __forceinline__ bf16x8 nt_frag(const char* sT, int r, int c) {
     return *(const bf16x8*)(sT + r * 128 + (nt_swz(r, c) << 4));
 }
 
-template <int MODE, int ACT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A,
+// MI = 16-row MFMA tiles per wave along M: 4 -> the 128x128 tile (2 blocks per CU); 2 -> 64x128 (24 KiB per stage,
+// 3 blocks per CU) for products with fewer 128x128 tiles than CUs (the BERT-side GEMMs of the fusion encoder: 4 096 rows).
+template <int MODE, int ACT, int MI = 4>
+__global__ __launch_bounds__(NTHREADS, MI == 4 ? 2 : 3) void gemm_nt_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ B, int M, int N, int K,
                                                               int lda, int ldb, GemmEpilogue ep) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    constexpr int BM = 32 * MI;
+    constexpr int A_BYTES = BM * 64 * 2, STAGE = A_BYTES + TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = (N + BN - 1) / BN;
@@ -60,37 +65,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    nt_stage(rsA, smem, m0, lda, 0, wid, lane);
-    nt_stage(rsB, smem + TILE_BYTES, n0, ldb, 0, wid, lane);
+    nt_stage<MI>(rsA, smem, m0, lda, 0, wid, lane);
+    nt_stage<4>(rsB, smem + A_BYTES, n0, ldb, 0, wid, lane);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         wait_vm0();
         __syncthreads();   // tile kt landed for every wave; everyone finished reading buf^1
         if (kt + 1 < nk) {
-            char* nxt = smem + (buf ^ 1) * 2 * TILE_BYTES;
-            nt_stage(rsA, nxt, m0, lda, (kt + 1) * BK, wid, lane);
-            nt_stage(rsB, nxt + TILE_BYTES, n0, ldb, (kt + 1) * BK, wid, lane);
+            char* nxt = smem + (buf ^ 1) * STAGE;
+            nt_stage<MI>(rsA, nxt, m0, lda, (kt + 1) * BK, wid, lane);
+            nt_stage<4>(rsB, nxt + A_BYTES, n0, ldb, (kt + 1) * BK, wid, lane);
         }
-        const char* sA = smem + buf * 2 * TILE_BYTES;
-        const char* sB = sA + TILE_BYTES;
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[4], b[4];
+            bf16x8 a[MI], b[4];
             const int c = ks * 4 + (lane >> 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = nt_frag(sA, wr * 64 + i * 16 + (lane & 15), c);
-                b[i] = nt_frag(sB, wc * 64 + i * 16 + (lane & 15), c);
-            }
+            for (int i = 0; i < MI; ++i) a[i] = nt_frag(sA, wr * (16 * MI) + i * 16 + (lane & 15), c);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) b[i] = nt_frag(sB, wc * 64 + i * 16 + (lane & 15), c);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
         }
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
     // Epilogue.  With the (B-fragment, A-fragment) operand order each lane owns, per 16x16
     // tile, row m = lane&15 and the 4 consecutive columns n = (lane>>4)*4 .. +3.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wr * (16 * MI) + i * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -169,10 +173,18 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     if (K % BK || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // fewer 128x128 tiles than CUs: 64-row tiles, three workgroups per CU (SPN_NT_SMALL_MI=4 keeps the 128-row tile)
+    static const int small_mi = [] { const char* e = getenv("SPN_NT_SMALL_MI"); return e ? atoi(e) : 2; }();
+    const bool half = small_mi == 2 && t128 < 256;
+    const int tiles = ((M + (half ? 64 : BM) - 1) / (half ? 64 : BM)) * ((N + BN - 1) / BN);
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
-#define SPN_LAUNCH_NT(MODE_, ACT_)                                                                             \
-    hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K, lda, ldb, ep)
+#define SPN_LAUNCH_NT(MODE_, ACT_)                                                                                       \
+    do {                                                                                                                 \
+        if (half) hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_, 2>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K, \
+                                     lda, ldb, ep);                                                                      \
+        else hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_, 4>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K,      \
+                                lda, ldb, ep);                                                                           \
+    } while (0)
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) SPN_LAUNCH_NT(GEMM_STORE, ACT_NONE);
         else if (ep.act == ACT_QUICKGELU) SPN_LAUNCH_NT(GEMM_STORE, ACT_QUICKGELU);
