@@ -93,6 +93,31 @@ __device__ __forceinline__ float qg_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// Output path of the whole-head kernels.  A wave holds a [16 rows][64] tile as four MFMA accumulators (row = lane & 15,
+// columns 16 d + 4 (lane >> 4) + r): written from there a store instruction covers 64 pieces of 8 B in 16 rows.  Staged
+// through LDS rows `st` (stride `ld` elements, a region only this wave touches; 144 / 208-byte strides put the 8-byte
+// writes of 16 rows in distinct banks) and read back 16 B per lane, a store covers 8 whole 128-byte rows instead
+// (cross-attention backward 153 -> 112 us).  dst_row(i) = global address of tile row i, or nullptr to skip it.
+template <class F>
+__device__ __forceinline__ void store_rows_staged(bf16_t* st, int ld, const f32x4 (&acc)[4], float scale, int lane,
+                                                  F dst_row) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        bf16x4 ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[r] = f2bf(acc[d][r] * scale);
+        *(bf16x4*)(st + (lane & 15) * ld + d * 16 + (lane >> 4) * 4) = ob;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const bf16x8 x = *(const bf16x8*)(st + row * ld + (lane & 7) * 8);
+        bf16_t* p = dst_row(row);
+        if (p) *(bf16x8*)(p + (lane & 7) * 8) = x;
+    }
+}
+
 // NT = number of 16-row tiles (= waves); keys are padded to KP = 32*ceil(NT/2) rows of zeros
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a) {
@@ -180,16 +205,22 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
             for (int d = 0; d < 4; ++d) o[d] = mfma16s(tfrag(Vs, SLD, ks * 32, d * 16, lane, KP), pf, o[d]);
         }
     }
-    if (qrow >= L) return;
     const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-    bf16_t* orow = a.o + (row0 + qrow) * a.ldo + h * SHD;
+    if constexpr (PLD >= 72) {                               // this wave's P rows are spent and wide enough for 64 columns
+        store_rows_staged(Ps, PLD, o, inv, lane, [&](int row) -> bf16_t* {
+            return q0 + row < L ? a.o + (row0 + q0 + row) * a.ldo + h * SHD : nullptr;
+        });
+    } else if (qrow < L) {
+        bf16_t* orow = a.o + (row0 + qrow) * a.ldo + h * SHD;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        bf16x4 ob;
+        for (int d = 0; d < 4; ++d) {
+            bf16x4 ob;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[d][r] * inv);
-        *(bf16x4*)(orow + d * 16 + (lane >> 4) * 4) = ob;
+            for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[d][r] * inv);
+            *(bf16x4*)(orow + d * 16 + (lane >> 4) * 4) = ob;
+        }
     }
+    if (qrow >= L) return;
     if (a.lse && (lane >> 4) == 0)
         a.lse[((size_t)b * a.H + h) * a.Lq + qrow] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
 }
@@ -231,6 +262,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     __syncthreads();
 
     // ---------------- phase 1: this wave's 16 queries against all visible keys
+    f32x4 dq[4];                                             // stored after the barrier, through the then dead K tile
     {
         const int q0 = w * 16, qrow = q0 + (lane & 15);
         const bool row_ok = qrow < L;
@@ -298,7 +330,6 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // dQ^T[d][q] = sum_key K[key][d] dS[q][key]
-        f32x4 dq[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) dq[d] = f32x4{0, 0, 0, 0};
         const int nks = a.causal ? (w + 2) / 2 : KS;
@@ -310,22 +341,16 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
                 for (int d = 0; d < 4; ++d) dq[d] = mfma16s(tfrag(Ks, SLD, ks * 32, d * 16, lane, ZR), df, dq[d]);
             }
         }
-        if (row_ok) {
-            bf16_t* drow = g.dq + (row0 + qrow) * g.lddq + h * SHD;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                bf16x4 ob;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = f2bf(dq[d][r] * a.scale);
-                *(bf16x4*)(drow + d * 16 + (lane >> 4) * 4) = ob;
-            }
-        }
     }
     __syncthreads();
 
     // ---------------- phase 2: this wave's 16 keys against all queries that see them
     {
-        const int k0 = w * 16, key = k0 + (lane & 15);
+        const int k0 = w * 16;
+        // K and V tiles are dead now: rows [16 w, 16 w + 16) of each are this wave's staging rows (store_rows_staged)
+        store_rows_staged(Ks + k0 * SLD, SLD, dq, a.scale, lane, [&](int row) -> bf16_t* {
+            return k0 + row < L ? g.dq + (row0 + k0 + row) * g.lddq + h * SHD : nullptr;
+        });
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -346,21 +371,12 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
                 }
             }
         }
-        if (key < L) {
-            bf16_t* dkrow = g.dk + (row0 + key) * g.lddk + h * SHD;
-            bf16_t* dvrow = g.dv + (row0 + key) * g.lddv + h * SHD;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                bf16x4 ok, ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ok[r] = f2bf(dk[d][r] * a.scale);
-                    ov[r] = f2bf(dv[d][r]);
-                }
-                *(bf16x4*)(dkrow + d * 16 + (lane >> 4) * 4) = ok;
-                *(bf16x4*)(dvrow + d * 16 + (lane >> 4) * 4) = ov;
-            }
-        }
+        store_rows_staged(Ks + k0 * SLD, SLD, dk, a.scale, lane, [&](int row) -> bf16_t* {
+            return k0 + row < L ? g.dk + (row0 + k0 + row) * g.lddk + h * SHD : nullptr;
+        });
+        store_rows_staged(Vs + k0 * SLD, SLD, dv, 1.0f, lane, [&](int row) -> bf16_t* {
+            return k0 + row < L ? g.dv + (row0 + k0 + row) * g.lddv + h * SHD : nullptr;
+        });
     }
 }
 
@@ -467,16 +483,11 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
             for (int d = 0; d < 4; ++d) o[d] = mfma16s(tfrag(Vs, SLD, ks * 32, d * 16, lane, KR), pf, o[d]);
         }
     }
-    if (!row_ok) return;
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    bf16_t* orow = a.o + ((size_t)b * Lq + qrow) * a.ldo + h * SHD;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        bf16x4 ob;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[d][r] * inv);
-        *(bf16x4*)(orow + d * 16 + (lane >> 4) * 4) = ob;
-    }
+    store_rows_staged(Ps, PLD2, o, inv, lane, [&](int row) -> bf16_t* {     // this wave's P rows are spent
+        return q0 + row < Lq ? a.o + ((size_t)b * Lq + q0 + row) * a.ldo + h * SHD : nullptr;
+    });
+    if (!row_ok) return;
     if (a.lse && (lane >> 4) == 0)
         a.lse[((size_t)b * a.H + h) * Lq + qrow] = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
 }
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
         __syncthreads();                                     // every wave's P / dS rows are in LDS
         // ---- phase B: 16-key subtiles of the tile, dealt round-robin to the waves
         for (int kt = w; kt < 4; kt += NQ) {
-            const int k0 = kt * 16, key = j0 + k0 + (lane & 15);
+            const int k0 = kt * 16;
             f32x4 dk[4], dv[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -628,21 +639,13 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
                     dk[d] = mfma16s(tfrag(Qs, SLD, qs * 32, d * 16, lane, ZRQ), df, dk[d]);
                 }
             }
-            if (key < Lk) {
-                bf16_t* dkrow = g.dk + ((size_t)b * Lk + key) * g.lddk + h * SHD;
-                bf16_t* dvrow = g.dv + ((size_t)b * Lk + key) * g.lddv + h * SHD;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    bf16x4 ok, ov;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ok[r] = f2bf(dk[d][r] * a.scale);
-                        ov[r] = f2bf(dv[d][r]);
-                    }
-                    *(bf16x4*)(dkrow + d * 16 + (lane >> 4) * 4) = ok;
-                    *(bf16x4*)(dvrow + d * 16 + (lane >> 4) * 4) = ov;
-                }
-            }
+            // the K / V tiles are dead after the barrier above: rows [16 w, 16 w + 16) of each stage this wave's 16 keys
+            store_rows_staged(Ks + (w * 16) * SLD, SLD, dk, a.scale, lane, [&](int row) -> bf16_t* {
+                return j0 + k0 + row < Lk ? g.dk + ((size_t)b * Lk + j0 + k0 + row) * g.lddk + h * SHD : nullptr;
+            });
+            store_rows_staged(Vs + (w * 16) * SLD, SLD, dv, 1.0f, lane, [&](int row) -> bf16_t* {
+                return j0 + k0 + row < Lk ? g.dv + ((size_t)b * Lk + j0 + k0 + row) * g.lddv + h * SHD : nullptr;
+            });
         }
     }
     if (row_ok) {
