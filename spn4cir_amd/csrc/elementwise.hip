@@ -566,7 +566,11 @@ int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr,
     if (step < 1) return SPN_ERR_ARG;
     const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
+    // ONE workgroup per CU: the kernel streams seven arrays (3.5 GB for ViT-L/14's 124 M parameters) and is bound by HBM page
+    // locality, not by bytes in flight - 2 048 workgroups: 4.5-4.9 TB/s, 256: 5.4-5.7 (a grid that is not a multiple of the
+    // CU count loses 20 %: every workgroup does the same share in one round).  SPN_ADAMW_CAP overrides the grid.
+    static const int cap = [] { const char* e = getenv("SPN_ADAMW_CAP"); return e ? atoi(e) : device_cu_count(); }();
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
                        (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf);
     SPN_CHECK_LAUNCH();
     return SPN_OK;

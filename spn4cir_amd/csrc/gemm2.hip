@@ -1589,7 +1589,7 @@ int gemm_tn2(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, 
     return SPN_OK;
 }
 
-static int device_cu_count() {
+int device_cu_count() {
     static const int n = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 256;

@@ -66,6 +66,7 @@ struct TnProblem {
 };
 constexpr int TN_GROUP_MAX = 48;
 size_t gemm_tn_grouped_workspace_bytes(int Kr);
+int device_cu_count();   // compute units of the current device (256 on MI355X)
 int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
 bool gemm_use_v1();
