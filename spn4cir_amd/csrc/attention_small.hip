@@ -14,6 +14,9 @@
 
 namespace spn {
 
+#ifndef SPN_ATTN_ABL
+#define SPN_ATTN_ABL 0   // ablation builds of attention_small_bwd_kernel: 1 = no phase 1, 2 = no phase 2 MFMAs, 4 = no output stores
+#endif
 static constexpr int SHD = 64;       // head dim
 static constexpr int SLD = 72;       // LDS row stride (elements) of the [row][64] tiles: 144 B
 
@@ -114,12 +117,15 @@ __device__ __forceinline__ void store_rows_staged(bf16_t* st, int ld, const f32x
         const int row = it * 8 + (lane >> 3);
         const bf16x8 x = *(const bf16x8*)(st + row * ld + (lane & 7) * 8);
         bf16_t* p = dst_row(row);
-        if (p) *(bf16x8*)(p + (lane & 7) * 8) = x;
+        if (p && !((SPN_ATTN_ABL & 4) && x[0] != (bf16_t)123.0f)) *(bf16x8*)(p + (lane & 7) * 8) = x;
     }
 }
 
 // NT = number of 16-row tiles (= waves); keys are padded to KP = 32*ceil(NT/2) rows of zeros
-template <int NT>
+// BIAS (compile time): an additive per-key bias (BERT's padding mask) is present.  As a run-time test per logit the
+// compiler turned it into one branch + global load + vmcnt(0) per element, which cut the softmax phase into ~20 basic
+// blocks per wave (backward, L = 77: phase 1 took 31 of 74 us).
+template <int NT, bool BIAS>
 __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a) {
     constexpr int KS = (NT + 1) / 2, KP = KS * 32;     // 32-deep key steps, padded key rows
     constexpr int PLD = KP + 8;                         // P row stride (elements)
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
     const bf16_t* qb = a.q + row0 * a.ldq + h * SHD;
     const bf16_t* kb = a.k + row0 * a.ldk + h * SHD;
     const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
+    [[maybe_unused]] const float* kbias = BIAS ? a.key_bias + (size_t)b * a.Lq : nullptr;
     {
         const bf16_t* const bases[2] = {kb, vb};
         const int lds_[2] = {a.ldk, a.ldv};
@@ -168,8 +174,10 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
         for (int r = 0; r < 4; ++r) {
             const int key = kt * 16 + (lane >> 4) * 4 + r;
             float v = s[kt][r] * a.scale;
-            if (kbias && key < L) v += kbias[key];
-            if (kt >= nkt || key >= L || (a.causal && key > qrow)) v = -INFINITY;
+            if constexpr (BIAS) v += kbias[min(key, max(L - 1, 0))];     // clamped, unconditional load; masked below
+            // '|' on purpose: the short-circuit form compiles to three exec-mask branches per logit
+            const bool dead = (kt >= nkt) | (key >= L) | ((a.causal != 0) & (key > qrow));
+            v = dead ? -INFINITY : v;
             s[kt][r] = v;
             mx = fmaxf(mx, v);
         }
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_fwd_kernel(AttnArgs a
         a.lse[((size_t)b * a.H + h) * a.Lq + qrow] = sum > 0.f ? mx + __logf(sum) : -INFINITY;
 }
 
-template <int NT>
+template <int NT, bool BIAS>
 __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArgs g) {
     const AttnArgs& a = g.f;
     constexpr int KS = (NT + 1) / 2, KP = KS * 32;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
     const bf16_t* kb = a.k + row0 * a.ldk + h * SHD;
     const bf16_t* vb = a.v + row0 * a.ldv + h * SHD;
     const bf16_t* dob = g.d_o + row0 * g.lddo + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * a.Lq : nullptr;
+    [[maybe_unused]] const float* kbias = BIAS ? a.key_bias + (size_t)b * a.Lq : nullptr;
     {
         const bf16_t* const bases[4] = {qb, kb, vb, dob};
         const int lds_[4] = {a.ldq, a.ldk, a.ldv, g.lddo};
@@ -263,6 +271,11 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
 
     // ---------------- phase 1: this wave's 16 queries against all visible keys
     f32x4 dq[4];                                             // stored after the barrier, through the then dead K tile
+#if SPN_ATTN_ABL & 1
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = f32x4{0, 0, 0, 0};
+    if (false)
+#endif
     {
         const int q0 = w * 16, qrow = q0 + (lane & 15);
         const bool row_ok = qrow < L;
@@ -290,8 +303,9 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + (lane >> 4) * 4 + r;
                 float v = s[kt][r] * a.scale;
-                if (kbias && key < L) v += kbias[key];
-                if (kt >= nkt || key >= L || (a.causal && key > qrow) || !row_ok) v = -INFINITY;
+                if constexpr (BIAS) v += kbias[min(key, max(L - 1, 0))];     // clamped, unconditional load; masked below
+                const bool dead = (kt >= nkt) | (key >= L) | ((a.causal != 0) & (key > qrow)) | !row_ok;   // no short circuit
+                v = dead ? -INFINITY : v;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
         const int qs0 = a.causal ? w / 2 : 0;            // first 32-query step with q >= k0
 #pragma unroll
         for (int qs = 0; qs < KS; ++qs) {
-            if (qs >= qs0) {
+            if (qs >= qs0 && !(SPN_ATTN_ABL & 2)) {
                 // B operands: P^T / dS^T [k = query][j = key]  (transposed reads of the [q][key] matrices)
                 const bf16x8 pf = tfrag(Pm, PLD, qs * 32, k0, lane, ZR);
                 const bf16x8 df = tfrag(Dm, PLD, qs * 32, k0, lane, ZR);
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(NT * 64) void attention_small_bwd_kernel(AttnBwdArg
 // Same shape class as attention_cross_bwd_kernel: one block per (sequence, head), one wave per 16 queries (Q fragments
 // in registers), keys / values streamed in tiles of 64 with the next tile's loads in flight, online softmax, P.V from
 // the row-major V tile through transpose reads (no transposed LDS copy).
-template <int NQ>
+template <int NQ, bool BIAS>
 __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a) {
     constexpr int KR = 64, PLD2 = KR + 8, NTH = NQ * 64;
     constexpr int ITER = (KR * 8 + NTH - 1) / NTH;
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
     const bf16_t* qb = a.q + (size_t)b * Lq * a.ldq + h * SHD;
     const bf16_t* kb = a.k + (size_t)b * Lk * a.ldk + h * SHD;
     const bf16_t* vb = a.v + (size_t)b * Lk * a.ldv + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * Lk : nullptr;
+    [[maybe_unused]] const float* kbias = BIAS ? a.key_bias + (size_t)b * Lk : nullptr;
     bf16x8 kreg[ITER], vreg[ITER];
     auto fetch = [&](int j0) {
 #pragma unroll
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
             for (int r = 0; r < 4; ++r) {
                 const int key = j0 + kt * 16 + (lane >> 4) * 4 + r;
                 float v = s[kt][r] * a.scale;
-                if (kbias && key < Lk) v += kbias[key];
+                if constexpr (BIAS) v += kbias[key < Lk ? key : Lk - 1];
                 if (key >= Lk) v = -INFINITY;
                 s[kt][r] = v;
                 mt = fmaxf(mt, v);
@@ -495,10 +509,16 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
 int attention_cross_fwd(const AttnArgs& a, hipStream_t st) {
     const dim3 grid(a.B * a.H);
     switch ((a.Lq + 15) / 16) {
-        case 1: hipLaunchKernelGGL(attention_cross_fwd_kernel<1>, grid, dim3(64), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(attention_cross_fwd_kernel<2>, grid, dim3(128), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(attention_cross_fwd_kernel<3>, grid, dim3(192), 0, st, a); break;
-        default: hipLaunchKernelGGL(attention_cross_fwd_kernel<4>, grid, dim3(256), 0, st, a); break;
+#define SPN_CROSS_FWD(NQ_)                                                                                      \
+    do {                                                                                                        \
+        if (a.key_bias) hipLaunchKernelGGL((attention_cross_fwd_kernel<NQ_, true>), grid, dim3(NQ_ * 64), 0, st, a); \
+        else hipLaunchKernelGGL((attention_cross_fwd_kernel<NQ_, false>), grid, dim3(NQ_ * 64), 0, st, a);      \
+    } while (0)
+        case 1: SPN_CROSS_FWD(1); break;
+        case 2: SPN_CROSS_FWD(2); break;
+        case 3: SPN_CROSS_FWD(3); break;
+        default: SPN_CROSS_FWD(4); break;
+#undef SPN_CROSS_FWD
     }
     SPN_CHECK_LAUNCH();
     return SPN_OK;
@@ -510,7 +530,7 @@ int attention_cross_fwd(const AttnArgs& a, hipStream_t st) {
 // while the current one is processed) and produces dQ (accumulated over the tiles in registers), dK and dV (complete
 // per tile: all queries of the head live in this block) in ONE pass over K and V - the tiled kernels in attention.hip
 // read K and V twice and re-load the query tile for every key tile.  Needs delta = rowsum(dO * O) and lse.
-template <int NQ>
+template <int NQ, bool BIAS>
 __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArgs g) {
     const AttnArgs& a = g.f;
     constexpr int QR = NQ * 16, ZRQ = QR, TRQ = QR + 1;      // query rows, zero row, rows of the query-side tiles
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
     const bf16_t* kb = a.k + (size_t)b * Lk * a.ldk + h * SHD;
     const bf16_t* vb = a.v + (size_t)b * Lk * a.ldv + h * SHD;
     const bf16_t* dob = g.d_o + (size_t)b * Lq * g.lddo + h * SHD;
-    const float* kbias = a.key_bias ? a.key_bias + (size_t)b * Lk : nullptr;
+    [[maybe_unused]] const float* kbias = BIAS ? a.key_bias + (size_t)b * Lk : nullptr;
     {
         const bf16_t* const bases[2] = {qb, dob};
         const int lds_[2] = {a.ldq, g.lddo};
@@ -603,8 +623,10 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = j0 + kt * 16 + (lane >> 4) * 4 + r;
-                float p = 0.f;
-                if (row_ok && key < Lk) p = __expf(s[r] * a.scale + (kbias ? kbias[key] : 0.f) - lse);
+                float kb = 0.f;
+                if constexpr (BIAS) kb = kbias[key < Lk ? key : Lk - 1];
+                float p = __expf(s[r] * a.scale + kb - lse);
+                p = (row_ok && key < Lk) ? p : 0.f;
                 pb[r] = f2bf(p);
                 db[r] = f2bf(p * (dp[r] - dlt));
             }
@@ -664,7 +686,8 @@ template <int NQ>
 static int launch_cross_bwd(const AttnBwdArgs& g, hipStream_t st) {
     constexpr int TRQ = NQ * 16 + 1, TRK = 65, PLD2 = 72;
     constexpr int LDS = (2 * TRQ * SLD + 2 * TRK * SLD + 2 * TRQ * PLD2) * 2;
-    hipLaunchKernelGGL(attention_cross_bwd_kernel<NQ>, dim3(g.f.B * g.f.H), dim3(NQ * 64), LDS, st, g);
+    if (g.f.key_bias) hipLaunchKernelGGL((attention_cross_bwd_kernel<NQ, true>), dim3(g.f.B * g.f.H), dim3(NQ * 64), LDS, st, g);
+    else hipLaunchKernelGGL((attention_cross_bwd_kernel<NQ, false>), dim3(g.f.B * g.f.H), dim3(NQ * 64), LDS, st, g);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -684,7 +707,8 @@ bool attention_small_ok(const AttnArgs& a) { return a.Lq == a.Lk && a.Lq <= 128;
 
 template <int NT>
 static int launch_small_fwd(const AttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(attention_small_fwd_kernel<NT>, dim3(a.B * a.H), dim3(NT * 64), 0, st, a);
+    if (a.key_bias) hipLaunchKernelGGL((attention_small_fwd_kernel<NT, true>), dim3(a.B * a.H), dim3(NT * 64), 0, st, a);
+    else hipLaunchKernelGGL((attention_small_fwd_kernel<NT, false>), dim3(a.B * a.H), dim3(NT * 64), 0, st, a);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -693,14 +717,18 @@ template <int NT>
 static int launch_small_bwd(const AttnBwdArgs& g, hipStream_t st) {
     constexpr int KS = (NT + 1) / 2, KP = KS * 32, PLD = KP + 8, TR_ = NT * 16 + 1;
     constexpr int LDS = (4 * TR_ * SLD + 2 * TR_ * PLD) * 2;
-    auto kern = attention_small_bwd_kernel<NT>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)attention_small_bwd_kernel<NT, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)attention_small_bwd_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.f.B * g.f.H), dim3(NT * 64), LDS, st, g);
+    if (g.f.key_bias) hipLaunchKernelGGL((attention_small_bwd_kernel<NT, true>), dim3(g.f.B * g.f.H), dim3(NT * 64), LDS, st, g);
+    else hipLaunchKernelGGL((attention_small_bwd_kernel<NT, false>), dim3(g.f.B * g.f.H), dim3(NT * 64), LDS, st, g);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

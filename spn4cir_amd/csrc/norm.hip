@@ -8,72 +8,62 @@ namespace spn {
 
 static constexpr int LN_MAXV_LIMIT = 8;   // float4 per lane -> W <= 2048
 
-// y = (x - mean) * rstd * gamma + beta.  One wave normalises LN_ROWS consecutive rows at a time.  Measured at W = 768,
-// 19 712 rows: one row per wave 19.3 us (4.7 TB/s), two rows 21.3 us - the extra loads in flight per wave do not pay for
-// the halved number of waves, so LN_ROWS stays 1.
-static constexpr int LN_ROWS = 1;
+// y = (x - mean) * rstd * gamma + beta.  Measured at W = 768, 19 712 rows (inputs rotated through 480 MB): one row per wave
+// and launch slot 17.8-19.3 us (4.7-5.1 TB/s); two rows per wave 21.3 us; the persistent walk below with 768 workgroups
+// (3 per CU) 17.8 us, 256: 33 us, 512: 21.6, 1 024: 18.1, 2 048: 19.3.
 template <int LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int rows, int W, float eps) {
+    // persistent: wave w walks rows w, w + nwaves, ... with the next row's loads in flight under the current row's two
+    // reductions and stores
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
-    if (row0 >= rows) return;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int nv = W >> 2;   // float4 count per row
-    f32x4 v[LN_ROWS][LN_MAXV];
-    float s[LN_ROWS];
+    f32x4 gm[LN_MAXV], bt[LN_MAXV], v[LN_MAXV], nx[LN_MAXV];
 #pragma unroll
-    for (int r = 0; r < LN_ROWS; ++r) {
-        s[r] = 0.f;
-        const bool live = row0 + r < rows;                      // wave-uniform
-        const float* xr = x + (size_t)(row0 + r) * W;
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        gm[i] = c < nv ? *(const f32x4*)(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bt[i] = c < nv ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = (wave < rows && c < nv) ? *(const f32x4*)(x + (size_t)wave * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = wave; row < rows; row += nwaves) {
+        const int nrow = row + nwaves;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (live && c < nv) {
-                v[r][i] = *(const f32x4*)(xr + c * 4);
-                s[r] += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
-            }
+            nx[i] = (nrow < rows && c < nv) ? *(const f32x4*)(x + (size_t)nrow * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    }
-    float mu[LN_ROWS], q[LN_ROWS], rs[LN_ROWS];
+        float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < LN_ROWS; ++r) mu[r] = wave_sum(s[r]) / (float)W;
-#pragma unroll
-    for (int r = 0; r < LN_ROWS; ++r) {
-        q[r] = 0.f;
+        for (int i = 0; i < LN_MAXV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];     // lanes past the row hold zeros
+        const float mu = wave_sum(s) / (float)W;
+        float q = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = v[r][i][e] - mu[r];
-                    q[r] += d * d;
+                    const float d = v[i][e] - mu;
+                    q += d * d;
                 }
             }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < LN_ROWS; ++r) rs[r] = rsqrtf(wave_sum(q[r]) / (float)W + eps);
-#pragma unroll
-    for (int r = 0; r < LN_ROWS; ++r) {
-        const int row = row0 + r;
-        if (row >= rows) break;
+        const float rs = rsqrtf(wave_sum(q) / (float)W + eps);
         if (lane == 0) {
-            if (mean) mean[row] = mu[r];
-            if (rstd) rstd[row] = rs[r];
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
         }
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
             if (c < nv) {
-                const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mu[r]) * rs[r] * g[e] + b[e];
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
                 if (yf) *(f32x4*)(yf + (size_t)row * W + c * 4) = o;
                 if (yb) {
                     bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
@@ -81,6 +71,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) v[i] = nx[i];
     }
 }
 
@@ -88,9 +80,11 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
                   float* rstd, int rows, int W, float eps, hipStream_t st) {
     if (rows <= 0) return SPN_ERR_ARG;
     if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
+    static const int cap = [] { const char* e = getenv("SPN_LNF_BLOCKS"); return e ? atoi(e) : 768; }();
+    const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
 #define SPN_LN_FWD(V_)                                                                                          \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3((rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS)), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, \
-                       mean, rstd, rows, W, eps)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, mean, rstd, \
+                       rows, W, eps)
     if (W <= 256) SPN_LN_FWD(1);
     else if (W <= 512) SPN_LN_FWD(2);
     else if (W <= 768) SPN_LN_FWD(3);
