@@ -11,7 +11,9 @@ static constexpr int LN_MAXV_LIMIT = 8;   // float4 per lane -> W <= 2048
 // y = (x - mean) * rstd * gamma + beta.  Measured at W = 768, 19 712 rows (inputs rotated through 480 MB): one row per wave
 // and launch slot 17.8-19.3 us (4.7-5.1 TB/s); two rows per wave 21.3 us; the persistent walk below with 768 workgroups
 // (3 per CU) 17.8 us, 256: 33 us, 512: 21.6, 1 024: 18.1, 2 048: 19.3.
-template <int LN_MAXV>
+// EXACT: W == 256 * LN_MAXV (768, 1024, ...): every lane owns LN_MAXV full column quads, no bounds tests (each one was
+// an exec-mask branch around its load / store)
+template <int LN_MAXV, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
@@ -25,16 +27,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + i * 64;
-        gm[i] = c < nv ? *(const f32x4*)(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        bt[i] = c < nv ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        v[i] = (wave < rows && c < nv) ? *(const f32x4*)(x + (size_t)wave * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        gm[i] = (EXACT || c < nv) ? *(const f32x4*)(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bt[i] = (EXACT || c < nv) ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = (wave < rows && (EXACT || c < nv)) ? *(const f32x4*)(x + (size_t)wave * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int row = wave; row < rows; row += nwaves) {
         const int nrow = row + nwaves;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            nx[i] = (nrow < rows && c < nv) ? *(const f32x4*)(x + (size_t)nrow * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            nx[i] = (nrow < rows && (EXACT || c < nv)) ? *(const f32x4*)(x + (size_t)nrow * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         float s = 0.f;
 #pragma unroll
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (EXACT || c < nv) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = v[i][e] - mu;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (EXACT || c < nv) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
@@ -83,8 +85,14 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
     static const int cap = [] { const char* e = getenv("SPN_LNF_BLOCKS"); return e ? atoi(e) : 768; }();
     const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
 #define SPN_LN_FWD(V_)                                                                                          \
-    hipLaunchKernelGGL(layernorm_fwd_kernel<V_>, dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, mean, rstd, \
-                       rows, W, eps)
+    do {                                                                                                        \
+        if (W == 256 * V_)                                                                                      \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<V_, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, \
+                               mean, rstd, rows, W, eps);                                                       \
+        else                                                                                                    \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<V_, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16,     \
+                               y_f32, mean, rstd, rows, W, eps);                                                \
+    } while (0)
     if (W <= 256) SPN_LN_FWD(1);
     else if (W <= 512) SPN_LN_FWD(2);
     else if (W <= 768) SPN_LN_FWD(3);
@@ -101,7 +109,7 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
 // registers; partials go to ws[nwaves_total][2][W] and are folded by a second kernel.
 static constexpr int LNB_BLOCKS = 1024;
 
-template <typename TDY, int LN_MAXV>
+template <typename TDY, int LN_MAXV, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
         dg[i] = f32x4{0, 0, 0, 0};
         db[i] = f32x4{0, 0, 0, 0};
         const int c = lane + i * 64;
-        gm[i] = c < nv ? *(const f32x4*)(gamma + c * 4) : f32x4{0, 0, 0, 0};
+        gm[i] = (EXACT || c < nv) ? *(const f32x4*)(gamma + c * 4) : f32x4{0, 0, 0, 0};
     }
     for (int row = wave; row < rows; row += nwaves) {
         const float mu = mean[row], rs = rstd[row];
@@ -127,12 +135,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            dprev[i] = (accumulate_dx && c < nv) ? *(const f32x4*)(dx + (size_t)row * W + c * 4) : f32x4{0, 0, 0, 0};
+            dprev[i] = (accumulate_dx && (EXACT || c < nv)) ? *(const f32x4*)(dx + (size_t)row * W + c * 4) : f32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (EXACT || c < nv) {
                 const f32x4 xv = *(const f32x4*)(x + (size_t)row * W + c * 4);
                 f32x4 d;
                 if constexpr (sizeof(TDY) == 2) {
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (EXACT || c < nv) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
-            if (c < nv) {
+            if (EXACT || c < nv) {
                 *(f32x4*)(lnred + (size_t)wv * 2 * W + c * 4) = dg[i];
                 *(f32x4*)(lnred + (size_t)wv * 2 * W + W + c * 4) = db[i];
             }
@@ -215,11 +223,17 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     const size_t lds = want_param ? (size_t)4 * 2 * W * sizeof(float) : 0;
 #define SPN_LN_BWD(V_)                                                                                           \
     do {                                                                                                         \
-        if (dy_bf16)                                                                                             \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
+        if (dy_bf16 && W == 256 * V_)                                                                            \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_, true>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+        else if (dy_bf16)                                                                                        \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_, false>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+        else if (W == 256 * V_)                                                                                  \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_, true>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
                                mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
         else                                                                                                     \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_, false>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
                                mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
     } while (0)
     if (W <= 256) SPN_LN_BWD(1);
