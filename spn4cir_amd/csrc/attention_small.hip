@@ -418,12 +418,18 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
-            kreg[it] = zero8s();
-            vreg[it] = zero8s();
-            if (i < KR * 8 && j0 + r < Lk) {
-                kreg[it] = *(const bf16x8*)(kb + (size_t)(j0 + r) * a.ldk + ch * 8);
-                vreg[it] = *(const bf16x8*)(vb + (size_t)(j0 + r) * a.ldv + ch * 8);
+            // unconditional loads of a clamped row + a select: a bounds test compiles to an exec-mask branch per load
+            const int rr = min(j0 + r, Lk - 1);
+            u32x4 kx = *(const u32x4*)(kb + (size_t)rr * a.ldk + ch * 8);
+            u32x4 vx = *(const u32x4*)(vb + (size_t)rr * a.ldv + ch * 8);
+            const bool live = (i < KR * 8) & (j0 + r < Lk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kx[e] = live ? kx[e] : 0u;
+                vx[e] = live ? vx[e] : 0u;
             }
+            kreg[it] = __builtin_bit_cast(bf16x8, kx);
+            vreg[it] = __builtin_bit_cast(bf16x8, vx);
         }
     };
     fetch(0);
@@ -574,12 +580,18 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int i = tid + it * NTH, r = i >> 3, ch = i & 7;
-            kreg[it] = zero8s();
-            vreg[it] = zero8s();
-            if (i < KR * 8 && j0 + r < Lk) {
-                kreg[it] = *(const bf16x8*)(kb + (size_t)(j0 + r) * a.ldk + ch * 8);
-                vreg[it] = *(const bf16x8*)(vb + (size_t)(j0 + r) * a.ldv + ch * 8);
+            // unconditional loads of a clamped row + a select: a bounds test compiles to an exec-mask branch per load
+            const int rr = min(j0 + r, Lk - 1);
+            u32x4 kx = *(const u32x4*)(kb + (size_t)rr * a.ldk + ch * 8);
+            u32x4 vx = *(const u32x4*)(vb + (size_t)rr * a.ldv + ch * 8);
+            const bool live = (i < KR * 8) & (j0 + r < Lk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kx[e] = live ? kx[e] : 0u;
+                vx[e] = live ? vx[e] : 0u;
             }
+            kreg[it] = __builtin_bit_cast(bf16x8, kx);
+            vreg[it] = __builtin_bit_cast(bf16x8, vx);
         }
     };
     fetch(0);
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
         dof[ks] = rfrag(Os, SLD, q0, ks * 32, lane);
     }
     const size_t srow = ((size_t)b * a.H + h) * Lq + (row_ok ? qrow : 0);
-    const float lse = row_ok ? a.lse[srow] : 0.f, dlt = row_ok ? g.delta[srow] : 0.f;
+    const float lse = row_ok ? a.lse[srow] : INFINITY, dlt = row_ok ? g.delta[srow] : 0.f;
     f32x4 dq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dq[d] = f32x4{0, 0, 0, 0};
@@ -625,8 +637,8 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_bwd_kernel(AttnBwdArg
                 const int key = j0 + kt * 16 + (lane >> 4) * 4 + r;
                 float kb = 0.f;
                 if constexpr (BIAS) kb = kbias[key < Lk ? key : Lk - 1];
-                float p = __expf(s[r] * a.scale + kb - lse);
-                p = (row_ok && key < Lk) ? p : 0.f;
+                float p = __expf(s[r] * a.scale + kb - lse);             // rows past Lq: lse = +inf, p = 0 without a branch
+                p = key < Lk ? p : 0.f;
                 pb[r] = f2bf(p);
                 db[r] = f2bf(p * (dp[r] - dlt));
             }
