@@ -38,7 +38,8 @@ def quick_gelu(x):
 
 
 # ------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (308, 192, 128), (462, 64, 256), (1000, 2304, 768), (77, 512, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (308, 192, 128), (462, 64, 256), (1000, 2304, 768), (77, 512, 3072),
+                                   (2050, 2304, 192)])
 def test_gemm_nt_plain_and_bias(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a, b = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g))
@@ -62,9 +63,11 @@ def test_gemm_nt_is_not_transposed(ops):
     assert torch.equal(out.cpu().double(), ref)
 
 
-def test_gemm_nt_epilogues(ops):
+@pytest.mark.parametrize("M,N", [(300, 256),        # fewer 128x128 tiles than CUs: the 64-row tiles of the 128-wide kernel
+                                 (2100, 2048)])     # 272 tiles of 128x128, 72 of 256x256: its 128-row tiles
+def test_gemm_nt_epilogues(ops, M, N):
     g = torch.Generator().manual_seed(5)
-    M, N, K = 300, 256, 128
+    K = 128
     a, b = bf(torch.randn(M, K, generator=g) * 0.5), bf(torch.randn(N, K, generator=g) * 0.2)
     bias = torch.randn(N, generator=g) * 0.1
     resid = torch.randn(M, N, generator=g)
@@ -193,7 +196,7 @@ def attn_ref(q, k, v, B, H, Lq, Lk, causal, key_bias, scale):
                                                    (1, 2, 257, 257, False, False), (2, 2, 9, 577, False, False),
                                                    (3, 2, 20, 20, False, True), (2, 1, 130, 130, True, False),
                                                    (2, 2, 32, 577, False, True), (1, 3, 64, 200, False, False),
-                                                   (2, 1, 40, 100, False, True)])
+                                                   (2, 1, 40, 100, False, True), (2, 2, 77, 77, True, True)])
 def test_attention_fwd_bwd(ops, B, H, Lq, Lk, causal, bias):
     g = torch.Generator().manual_seed(B * 1000 + Lq)
     W = H * 64
