@@ -251,24 +251,22 @@ int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, fl
 
 // dtok[ids[b,l],:] += dx[b,l,:] for l <= eot[b] (rows after the EOT token have zero gradient under
 // the causal mask and are skipped); dtok must be zero on entry.  dpos[l,:] = sum_b dx[b,l,:].
-__global__ void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ eot,
-                                     const float* __restrict__ dx, float* __restrict__ dtok, int BL, int L, int W,
-                                     int vocab, int skip_id) {
-    const int w4 = W >> 2;
-    const size_t total = (size_t)BL * w4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
-        const int b = row / L, l = row % L;
-        if (eot && l > eot[b]) continue;
+// One wave per token row: dead rows (after the EOT token, or the skipped id) leave at once; a live row is added with
+// lane-contiguous atomics (one instruction = 256 contiguous bytes; the earlier 4-floats-per-lane form spread each
+// instruction over 16 cache lines: 73 us at B = 256, L = 77, this: see DESIGN.md).
+__global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ eot,
+                                                           const float* __restrict__ dx, float* __restrict__ dtok, int BL,
+                                                           int L, int W, int vocab, int skip_id) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < BL; row += gridDim.x * 4) {
+        const int b = row / L, l = row - b * L;
+        if (eot && l > eot[b]) continue;                    // wave-uniform
         int id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         if (id == skip_id) continue;
-        const f32x4 g = *(const f32x4*)(dx + (size_t)row * W + c);
-        float* d = dtok + (size_t)id * W + c;
-        atomicAdd(d + 0, g[0]);
-        atomicAdd(d + 1, g[1]);
-        atomicAdd(d + 2, g[2]);
-        atomicAdd(d + 3, g[3]);
+        const float* src = dx + (size_t)row * W;
+        float* dst = dtok + (size_t)id * W;
+        for (int c = lane; c < W; c += 64) atomicAdd(dst + c, src[c]);
     }
 }
 
@@ -285,7 +283,7 @@ int embed_bwd(const int32_t* ids, const int32_t* eot, const float* dx, float* dt
               int vocab, hipStream_t st) {
     if (W % 4) return SPN_ERR_SHAPE;
     if (dtok) {
-        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, eot, dx,
+        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * 64, 256, 8192)), dim3(256), 0, st, ids, eot, dx,
                            dtok, B * L, L, W, vocab, -1);
         SPN_CHECK_LAUNCH();
     }
@@ -320,7 +318,7 @@ int embed_bwd_all(const int32_t* ids, const float* dx, float* dtok, float* dpos,
                   float* ws, size_t ws_bytes, hipStream_t st) {
     if (W % 4) return SPN_ERR_SHAPE;
     if (ws_bytes < embed_bwd_all_ws_bytes(B, L, W)) return SPN_ERR_WORKSPACE;
-    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * (W / 4))), dim3(256), 0, st, ids, nullptr, dx, dtok,
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid_for((size_t)B * L * 64, 256, 8192)), dim3(256), 0, st, ids, nullptr, dx, dtok,
                        B * L, L, W, vocab, hot_id);
     SPN_CHECK_LAUNCH();
     const int slabs = (B * L + EB_SLAB - 1) / EB_SLAB;
