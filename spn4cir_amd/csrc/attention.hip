@@ -111,14 +111,25 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
         }
         // s[nt][r] = S[qrow][key = j0 + nt*16 + (lane>>4)*4 + r]
         float mt = -INFINITY;
+        // the key bias is fetched under ONE wave-uniform test per tile (clamped index) and the mask is a predicate: as
+        // per-logit `if`s both compiled to exec-mask branches with their own waits (see attention_small.hip)
+        f32x4 kb4[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) kb4[nt] = f32x4{0, 0, 0, 0};
+        if (kbias) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kb4[nt][r] = kbias[min(j0 + nt * 16 + (lane >> 4) * 4 + r, a.Lk - 1)];
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = j0 + nt * 16 + (lane >> 4) * 4 + r;
-                float v = s[nt][r] * a.scale;
-                if (kbias && key < a.Lk) v += kbias[key];
-                if (key >= a.Lk || (a.causal && key > qrow)) v = -INFINITY;
+                float v = s[nt][r] * a.scale + kb4[nt][r];
+                const bool dead = (key >= a.Lk) | ((a.causal != 0) & (key > qrow));
+                v = dead ? -INFINITY : v;
                 s[nt][r] = v;
                 mt = fmaxf(mt, v);
             }
@@ -268,9 +279,10 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int key = j0 + nt * 16 + (lane >> 4) * 4 + r;
                 float v = s[r] * a.scale;
-                if (kbias && key < a.Lk) v += kbias[key];
-                const bool masked = key >= a.Lk || (a.causal && key > qrow) || !row_ok;
-                const float p = masked ? 0.f : __expf(v - lse);
+                if (kbias) v += kbias[min(key, a.Lk - 1)];                       // wave-uniform test, clamped index
+                const bool masked = (key >= a.Lk) | ((a.causal != 0) & (key > qrow)) | !row_ok;
+                float p = __expf(v - lse);
+                p = masked ? 0.f : p;
                 ds[r] = f2bf(p * (dp[r] - dlt));
             }
             *(bf16x4*)(Ds + (lane & 15) * LDT + nt * 16 + (lane >> 4) * 4) = ds;
