@@ -12,6 +12,11 @@ CLIP_TEXT_CONFIGS = {
     "ViT-B/16": (512, 12, 8, 512),
     "ViT-L/14": (768, 12, 12, 768),
     "RN50x4": (640, 12, 10, 640),
+    "RN50": (512, 12, 8, 1024),
+    "RN101": (512, 12, 8, 512),
+    "RN50x16": (768, 12, 12, 768),
+    "RN50x64": (1024, 12, 16, 1024),
+    "ViT-L/14@336px": (768, 12, 12, 768),
 }
 
 
