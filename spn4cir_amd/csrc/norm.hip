@@ -107,7 +107,8 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
 //   dx = rstd * (g - mean_c(g) - xhat * mean_c(g*xhat));  dgamma = sum_r dy*xhat;  dbeta = sum_r dy
 // Each wave walks rows wave_id, wave_id+nwaves, ... and keeps per-column dgamma/dbeta partials in
 // registers; partials go to ws[nwaves_total][2][W] and are folded by a second kernel.
-static constexpr int LNB_BLOCKS = 1024;
+// grid of the backward kernel: ONE workgroup per CU (like AdamW, the kernel is bound by HBM page locality: at [19 712, 768]
+// 256 workgroups 41.5 us, 512: 42.9, 1 024: 46.0, 2 048: 52.6 with the parameter-gradient fold); SPN_LNB_BLOCKS overrides
 
 template <typename TDY, int LN_MAXV, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 
 static int lnb_blocks(int rows) {
     int b = (rows + 3) / 4;
-    return b > LNB_BLOCKS ? LNB_BLOCKS : b;
+    static const int cap = [] { const char* e = getenv("SPN_LNB_BLOCKS"); return e ? atoi(e) : device_cu_count(); }();
+    return b > cap ? cap : b;
 }
 
 int layernorm_bwd_partial_rows(int rows) { return lnb_blocks(rows); }
@@ -238,8 +240,7 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     } while (0)
     if (W <= 256) SPN_LN_BWD(1);
     else if (W <= 512) SPN_LN_BWD(2);
-    else if (W <= 768) SPN_LN_BWD(3);      // the text towers' width: 144 -> <= 128 registers, 4 instead of 3 waves per SIMD,
-                                           // so all 1024 workgroups are resident in ONE round
+    else if (W <= 768) SPN_LN_BWD(3);      // the text towers' width: 144 -> <= 128 registers
     else if (W <= 1024) SPN_LN_BWD(4);
     else SPN_LN_BWD(8);
 #undef SPN_LN_BWD
