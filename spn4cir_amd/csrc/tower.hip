@@ -749,7 +749,15 @@ int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, con
     // + ln_final backward of every row, accumulated into dx (and its bf16 mirror) and into ln_final's gradients
     SPN_TRY(layernorm_bwd(nullptr, dtokens, A.x_final, params + t.lnf_g, tok_mean, tok_rstd, w.dx, 1, w.dxb, grads + t.lnf_g,
                           grads + t.lnf_b, 1, c.B * c.L, c.W, w.opws, w.opws_bytes, st));
-    for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    if (!tn_group_on()) {
+        for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+    } else {       // as text_bwd: data path of every block first, then the weight gradients in grouped launches
+        for (int l = c.layers - 1; l >= 0; --l)
+            SPN_TRY(text_bwd_layer_deferred(c, params, wb, acts, grads, l, ws, ws_bytes, st));
+        constexpr int PER = TN_GROUP_MAX / 4;
+        for (int e = c.layers; e > 0; e -= PER)
+            SPN_TRY(text_bwd_wgrad(c, acts, grads, e > PER ? e - PER : 0, e, ws, ws_bytes, st));
+    }
     return text_bwd_tail_impl(c, ids, acts, grads, ws, ws_bytes, true, st);
 }
 
