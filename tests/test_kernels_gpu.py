@@ -298,6 +298,31 @@ def test_bank_label_smoothing_and_shards(ops):
     assert rel_err(d0 + d1, qd.grad) < 1.5e-2
 
 
+def test_bank_shards_large_batch_gemm_path(ops):
+    """The per-rank shape of the data-parallel step (BASELINE configs 3-5): ALL gathered queries (B >= 128, so the forward
+    runs on the GEMM path) against ONE contiguous shard of the bank, labels in global row numbers; the shards' statistics
+    and query gradients combine to the single-bank result."""
+    B, M, D, tau = 512, 8000, 768, 0.02
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 4242)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    bank_b = ops.prepare_bank(dev(bank))
+    qr, br = qb[:, :D].cpu().float(), bank_b[:, :D].cpu().float()
+    qd = qr.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy((qd @ br.double().t()) / tau, labels)
+    ref.backward()
+    cuts = [0, 3000, 3001, 8000]                       # a one-row shard in the middle
+    parts = [ops.bank_stats_fwd(qb, bank_b[a:b].contiguous(), dev(labels), 1.0 / tau, m_begin=a)
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    lse, row, mean = ops.bank_loss_finalize(torch.stack(parts), M)
+    assert abs(mean.item() - ref.item()) < 3e-4
+    whole = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau)
+    lse1, row1, mean1 = ops.bank_loss_finalize(whole, M)
+    assert (lse - lse1).abs().max().item() < 2e-4
+    dq = sum(ops.bank_grad_q(qb, bank_b[a:b].contiguous(), dev(labels), 1.0 / tau, lse, 1.0 / B, M_total=M, m_begin=a)
+             for a, b in zip(cuts[:-1], cuts[1:]))
+    assert rel_err(dq[:, :D], qd.grad) < 1.5e-2
+
+
 def test_bank_matches_golden_loss_cases(ops, golden_dir):
     import os
     from cases import LOSS_CASES, loss_case_inputs
