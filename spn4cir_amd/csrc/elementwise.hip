@@ -496,43 +496,52 @@ int embed_fwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* ro
     return SPN_OK;
 }
 
-__global__ void embed_bwd_tok_packed_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ row_b,
-                                            const int32_t* __restrict__ row_l, const float* __restrict__ dx,
-                                            float* __restrict__ dtok, int T, int L, int W, int vocab) {
-    const int w4 = W >> 2;
-    const size_t total = (size_t)T * w4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+// one wave per packed row, lane-contiguous atomics (see embed_bwd_tok_kernel)
+__global__ __launch_bounds__(256) void embed_bwd_tok_packed_kernel(const int32_t* __restrict__ ids,
+                                                                  const int32_t* __restrict__ row_b,
+                                                                  const int32_t* __restrict__ row_l,
+                                                                  const float* __restrict__ dx, float* __restrict__ dtok,
+                                                                  int T, int L, int W, int vocab) {
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
         int id = ids[(size_t)row_b[row] * L + row_l[row]];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-        const f32x4 g = *(const f32x4*)(dx + (size_t)row * W + c);
-        float* d = dtok + (size_t)id * W + c;
-        atomicAdd(d + 0, g[0]); atomicAdd(d + 1, g[1]); atomicAdd(d + 2, g[2]); atomicAdd(d + 3, g[3]);
+        const float* src = dx + (size_t)row * W;
+        float* dst = dtok + (size_t)id * W;
+        for (int c = lane; c < W; c += 64) atomicAdd(dst + c, src[c]);
     }
 }
 
-__global__ void embed_bwd_pos_packed_kernel(const float* __restrict__ dx, const int32_t* __restrict__ cu,
-                                            float* __restrict__ dpos, int B, int W) {
-    const int l = blockIdx.x;
+// dpos[l, :] = sum over the sequences that are longer than l of dx[cu[b] + l, :].  Workgroup (l, g) sums the sequences
+// b = g, g + G, ... into part[g][l][:]; fold_rows adds the G partials (one workgroup per position looping over all B
+// sequences took 76 us at B = 256).
+static constexpr int EBP_GROUPS = 16;
+__global__ __launch_bounds__(256) void embed_bwd_pos_packed_kernel(const float* __restrict__ dx, const int32_t* __restrict__ cu,
+                                                                  float* __restrict__ part, int B, int L, int W) {
+    const int l = blockIdx.x, g = blockIdx.y;
     for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
         f32x4 s = {0, 0, 0, 0};
-        for (int b = 0; b < B; ++b) {
+        for (int b = g; b < B; b += EBP_GROUPS) {
             const int r0 = cu[b];
             if (l < cu[b + 1] - r0) s += *(const f32x4*)(dx + (size_t)(r0 + l) * W + c);
         }
-        *(f32x4*)(dpos + (size_t)l * W + c) = s;
+        *(f32x4*)(part + ((size_t)g * L + l) * W + c) = s;
     }
 }
 
+size_t embed_bwd_packed_ws_bytes(int L, int W) { return (size_t)EBP_GROUPS * L * W * sizeof(float); }
+
 int embed_bwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const int32_t* cu, const float* dx,
-                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, hipStream_t st) {
+                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, float* ws, size_t ws_bytes,
+                     hipStream_t st) {
     if (W % 4) return SPN_ERR_SHAPE;
-    hipLaunchKernelGGL(embed_bwd_tok_packed_kernel, dim3(grid_for((size_t)T * (W / 4))), dim3(256), 0, st, ids, row_b,
+    if (ws_bytes < embed_bwd_packed_ws_bytes(L, W)) return SPN_ERR_WORKSPACE;
+    hipLaunchKernelGGL(embed_bwd_tok_packed_kernel, dim3(grid_for((size_t)T * 64, 256, 8192)), dim3(256), 0, st, ids, row_b,
                        row_l, dx, dtok, T, L, W, vocab);
     SPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(embed_bwd_pos_packed_kernel, dim3(L), dim3(256), 0, st, dx, cu, dpos, B, W);
+    hipLaunchKernelGGL(embed_bwd_pos_packed_kernel, dim3(L, EBP_GROUPS), dim3(192), 0, st, dx, cu, ws, B, L, W);
     SPN_CHECK_LAUNCH();
-    return SPN_OK;
+    return fold_rows(ws, (size_t)L * W, EBP_GROUPS, (size_t)L * W, dpos, 1.0f, 0, st);
 }
 
 __global__ void gather_rows_abs_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows,

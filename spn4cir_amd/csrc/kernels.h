@@ -110,8 +110,10 @@ int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx
 int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st);
 int embed_fwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const float* tok_emb,
                      const float* pos_emb, float* x, int T, int L, int W, int vocab, hipStream_t st);
+size_t embed_bwd_packed_ws_bytes(int L, int W);
 int embed_bwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const int32_t* cu, const float* dx,
-                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, hipStream_t st);
+                     float* dtok, float* dpos, int T, int B, int L, int W, int vocab, float* ws, size_t ws_bytes,
+                     hipStream_t st);
 int gather_rows_abs(const float* x, const int32_t* rows, float* out, int B, int W, hipStream_t st);
 int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_row, float* dx, bf16_t* dx_bf16, int T,
                      int W, hipStream_t st);

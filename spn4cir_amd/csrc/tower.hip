@@ -464,7 +464,8 @@ size_t text_ws_bytes(const TextCfg& c) {
     if (tp > op) op = tp;
     const size_t lb = align256(layernorm_bwd_workspace_bytes(c.B, c.W));
     if (lb > op) op = lb;
-    const size_t eb = align256(embed_bwd_all_ws_bytes(c.B, c.L, c.W));   // text_bwd_tokens' embedding backward
+    size_t eb = align256(embed_bwd_all_ws_bytes(c.B, c.L, c.W));         // text_bwd_tokens' embedding backward
+    if (align256(embed_bwd_packed_ws_bytes(c.L, c.W)) > eb) eb = align256(embed_bwd_packed_ws_bytes(c.L, c.W));
     if (eb > op) op = eb;
     return b + op;
 }
@@ -719,7 +720,7 @@ static int text_bwd_tail_impl(const TextCfg& c, const int32_t* ids, char* acts, 
     if (he != hipSuccess) return (int)he;
     if (c.T > 0)
         SPN_TRY(embed_bwd_packed(ids, A.row_b, A.row_l, A.cu, w.dx, grads + t.tok, grads + t.pos, c.T, c.B, c.L, c.W, c.vocab,
-                                 st));
+                                 w.opws, w.opws_bytes, st));
     else if (all_rows)   // id 0 = CLIP's padding (clip/clip.py:236: zeros): the hot row
         SPN_TRY(embed_bwd_all(ids, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, 0, w.opws, w.opws_bytes, st));
     else SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
