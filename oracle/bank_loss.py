@@ -49,6 +49,22 @@ def dequantize_e4m3(data, scale):
     return data.view(torch.float8_e4m3fn).float() * scale[:, None]
 
 
+def split_query_e4m3(q):
+    """The query side of the fp8-MFMA bank pass (spn4cir_amd/csrc/bank.hip, bank_fp8_fwd_kernel; BASELINE config 5): the
+    matrix instruction takes both operands in e4m3, so every query row is carried by TWO e4m3 terms with one scale,
+        q ~= s * hi + (s / 16) * lo,   s = max|q| / 448 (1 for a zero row),   r = 1 / s,
+        hi = e4m3(q * r),   lo = e4m3((q - hi * s) * (16 * r)),
+    all in fp32 (every product and the difference rounded separately) with round-to-nearest-even casts.  Returns the
+    fp32 value the kernel's two products represent."""
+    q = q.float()
+    mx = q.abs().amax(dim=1)
+    s = torch.where(mx > 0, mx / 448.0, torch.ones_like(mx))[:, None]
+    r = 1.0 / s
+    hi = (q * r).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    lo = ((q - hi * s) * (r * 16.0)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return hi * s + lo * (s * 0.0625)
+
+
 def inbatch_step(refer_feats, text_feats, target_feats, tau):
     """clip4cir/models.py:151-167 with wo_bank=True (BASELINE config 1): in-batch B x B InfoNCE between
     normalize(refer + text) and normalize(target), labels = arange(B)."""

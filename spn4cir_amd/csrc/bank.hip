@@ -430,6 +430,263 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     }
 }
 
+// ------------------------------------------------------------------ fp8 bank, forward pass on the fp8 MFMA
+// BASELINE config 5 ("fp8 MFMA sim-matmul"): the e4m3 bank tile goes from HBM to LDS (1 byte per element) and from LDS
+// straight into v_mfma_f32_16x16x32_fp8_fp8 - no dequantised bf16 image, no extra LDS pass or barrier.  The MFMA needs
+// both operands in fp8, so the block's 32 bf16 queries are split once, in registers, into TWO e4m3 terms with one scale
+// per query:  q ~= sq * hi + (sq / 16) * lo,  sq = max|q| / 448, hi = e4m3(q * (1 / sq)), lo = e4m3((q - sq hi) * (16 / sq))
+// (|q - sq hi| <= half an ulp of hi <= 16 sq, so lo never saturates; the pair carries q to ~2^-8, the bf16 level).
+// logit = sb[key] * sq * (acc_hi + acc_lo / 16) / tau.  Same block / chunk geometry and statistics as bank_stream_kernel.
+// LDS image of the raw tile [TR rows][D bytes]: 16-byte chunk c of row r sits at position c ^ x(r) of its aligned
+// group - x = r & 15 when a row is a multiple of 256 B (every row starts on bank 0), (r >> 1) & 7 when it is an odd
+// multiple of 128 B (rows alternate between two bank halves): the 16 rows of a fragment read fall in 16 distinct
+// 16-byte bank groups.
+template <int D>
+__device__ __forceinline__ int fp8_swz(int r) {
+    if constexpr (D % 256 == 0) return r & 15;
+    else return (r >> 1) & 7;
+}
+
+__device__ __forceinline__ long pack_fp8x8(const float (&v)[8]) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+
+__device__ __forceinline__ void unpack_fp8x8(long p, float (&v)[8]) {
+    const int lo = (int)(unsigned)((unsigned long)p & 0xffffffffu), hi = (int)(unsigned)((unsigned long)p >> 32);
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = d[0]; v[7] = d[1];
+}
+
+static constexpr int FP8_MAX_CHUNK_ROWS = 2048;   // rows of a block's chunk whose scales are kept in LDS (8 KB)
+static constexpr int FP8_STAGES = 4;     // raw tiles in flight per block: a chunk is ~5 tiles, so nearly all of it is
+                                         // requested at once (two stages: one DMA latency per tile, 22.9 us at B = 32)
+template <int D>
+__global__ __launch_bounds__(256, 1) void bank_fp8_fwd_kernel(BankArgs a, BankChunking ck, float* __restrict__ ws) {
+    constexpr int DW = D / 4;            // columns per wave
+    constexpr int KSW = DW / 32;         // 32-deep k-steps per wave
+    constexpr int RAW_B = TR * D;        // bytes of one raw tile
+    constexpr int S = FP8_STAGES, NDMA = D / 128;         // DMA instructions per wave and tile
+    static_assert(D % 128 == 0 && RAW_B % 1024 == 0 && (S - 1) * NDMA <= 63, "bank width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tiles = smem;                                   // S x RAW_B
+    float* Sp = (float*)(smem + S * RAW_B);               // [4 waves][2 mt][2 nt][64 lanes][4]; reused as Fin at the end
+    float* Qm = (float*)(smem + S * RAW_B + 4 * 4096);    // [4 waves][32 queries] partial max |q|
+    float* Ssc = Qm + 4 * 32;                             // per-row scales of the block's chunk (<= FP8_MAX_CHUNK_ROWS)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
+    const int q0 = qi * BQ;
+    const int m_lo = mi * ck.rows;
+    const int m_hi = min(a.M, m_lo + ck.rows);
+    const int ntiles = m_hi > m_lo ? (m_hi - m_lo + TR - 1) / TR : 0;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)D);
+
+    auto stage = [&](int t, int buf) {
+        const int mrow0 = m_lo + t * TR;
+        char* dst = tiles + buf * RAW_B;
+#pragma unroll
+        for (int i = 0; i < D / 128; ++i) {
+            const int ii = w * (D / 128) + i;
+            const int p = ii * 1024 + lane * 16;
+            const int r = p / D, cp = (p % D) >> 4;
+            const int c = cp ^ fp8_swz<D>(r);
+            glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)D + (uint32_t)c * 16u);
+        }
+    };
+    // the chunk's row scales into LDS once (a global load where a scale is needed costs the tile an L2 round trip, and
+    // VMEM loads inside the loop would disturb the counted waits of the tile ring); visible after the barrier below
+    for (int i = tid; i < ntiles * TR; i += 256) Ssc[i] = a.bank_scale[min(m_lo + i, a.M - 1)];
+    // ---- this wave's d-slice of the 32 queries -> two e4m3 terms (B operand: j = query, k = d)
+    long qh[2][KSW], ql[2][KSW];
+    float sq[2];
+    {
+        bf16x8 qf[2][KSW];
+        float am[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int qr = q0 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                if (qr < a.B) {
+                    qf[mt][ks] = *(const bf16x8*)(a.q + (size_t)qr * a.ldq + w * DW + ks * 32 + (lane >> 4) * 8);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[mt][ks][e] = (bf16_t)0.0f;
+                }
+            }
+        }
+        // the first S-1 tiles go out behind the query loads (vmcnt retires in order: the split below waits for the
+        // queries only) and land while the queries are split
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t)
+            if (t < ntiles) stage(t, t);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am[mt] = fmaxf(am[mt], fabsf(bf2f(qf[mt][ks][e])));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 16, 64));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 32, 64));
+            if ((lane >> 4) == 0) Qm[w * 32 + mt * 16 + lane] = am[mt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float m = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) m = fmaxf(m, Qm[ww * 32 + mt * 16 + (lane & 15)]);
+            sq[mt] = m > 0.f ? m / 448.0f : 1.0f;
+            // one division per query; every element is scaled by the reciprocal (192 fp32 divisions per lane cost 4 us).
+            // Separate multiply and subtract (no fma contraction): oracle/bank_loss.py split_query_e4m3 does the same.
+            const float rh = 1.0f / sq[mt], rl = rh * 16.0f;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                float v[8], hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(__fmul_rn(bf2f(qf[mt][ks][e]), rh), -448.0f), 448.0f);
+                qh[mt][ks] = pack_fp8x8(v);
+                unpack_fp8x8(qh[mt][ks], hv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float res = __fsub_rn(bf2f(qf[mt][ks][e]), __fmul_rn(hv[e], sq[mt]));
+                    v[e] = fminf(fmaxf(__fmul_rn(res, rl), -448.0f), 448.0f);
+                }
+                ql[mt][ks] = pack_fp8x8(v);
+            }
+        }
+    }
+
+    // softmax-phase ownership as in bank_stream_kernel
+    const int mt_o = w >> 1, nt_o = w & 1;
+    const int q_o = q0 + mt_o * 16 + (lane & 15);
+    const bool q_ok = q_o < a.B;
+    const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;
+    const float zs = sq[mt_o] * a.inv_tau;                // query scale x 1 / tau
+    float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t % S;
+        if (t + S - 1 < ntiles) stage(t + S - 1, (t + S - 1) % S);    // into the buffer of tile t-1 (all waves are past it)
+        const int behind = min(S - 1, ntiles - 1 - t);               // tiles requested after tile t
+        if (behind >= 3) wait_vmcnt<3 * NDMA>();
+        else if (behind == 2) wait_vmcnt<2 * NDMA>();
+        else if (behind == 1) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __syncthreads();
+        const char* T = tiles + buf * RAW_B;
+        f32x4 sh[2][2], sl4[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sh[mt][nt] = f32x4{0, 0, 0, 0};
+                sl4[mt][nt] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int r = nt * 16 + (lane & 15);
+                const int kb = w * DW + ks * 32 + (lane >> 4) * 8;               // byte offset of this lane's 8 values
+                const long bfr = *(const long*)(T + r * D + (((kb >> 4) ^ fp8_swz<D>(r)) << 4) + (kb & 8));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    sh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, qh[mt][ks], sh[mt][nt], 0, 0, 0);
+                    sl4[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, ql[mt][ks], sl4[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = sh[mt][nt] + sl4[mt][nt] * 0.0625f;
+        __syncthreads();
+        f32x4 sv = {0, 0, 0, 0};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
+        const int key0 = m_lo + t * TR + nt_o * 16 + (lane >> 4) * 4;           // shard-local row of sv[0]
+        const f32x4 sb4 = *(const f32x4*)(Ssc + t * TR + nt_o * 16 + (lane >> 4) * 4);
+        float tm = -INFINITY;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = (key0 + r < a.M) ? sv[r] * sb4[r] * zs : -INFINITY;
+            tm = fmaxf(tm, v[r]);
+        }
+        if (tm > -INFINITY) {
+            const float mn = fmaxf(st_m, tm);
+            float add = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = key0 + r < a.M;
+                add += live ? __expf(v[r] - mn) : 0.f;
+                st_sl += live ? v[r] : 0.f;
+                st_lab = (live && (int64_t)(key0 + r) == label) ? v[r] : st_lab;
+            }
+            st_l = st_l * __expf(st_m - mn) + add;
+            st_m = mn;
+        }
+    }
+    // combine the 4 lane groups (lane>>4) and the 2 key-half waves of each query row
+    __syncthreads();
+    float* Fin = Sp;
+    float* f = Fin + ((w * 64 + lane) * 4);
+    f[0] = st_m; f[1] = st_l; f[2] = st_sl; f[3] = st_lab;
+    __syncthreads();
+    if (tid < BQ) {
+        const int mt = tid >> 4, ql_ = tid & 15;
+        float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+        for (int nt = 0; nt < 2; ++nt)
+            for (int g = 0; g < 4; ++g) {
+                const float* p = Fin + (((mt * 2 + nt) * 64 + g * 16 + ql_) * 4);
+                const float mn = fmaxf(m, p[0]);
+                if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+                m = mn;
+                sl += p[2];
+                lab = fmaxf(lab, p[3]);
+            }
+        const int q = q0 + tid;
+        if (q < a.B) {
+            float* o = ws + ((size_t)mi * a.B + q) * 4;
+            o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+        }
+    }
+}
+
+template <int D>
+static int launch_bank_fp8_fwd(const BankArgs& a, const BankChunking& c, float* ws, hipStream_t st) {
+    const size_t lds = FP8_STAGES * (size_t)TR * D + 4 * 4096 + 4 * 32 * sizeof(float) + FP8_MAX_CHUNK_ROWS * sizeof(float);
+    auto kern = bank_fp8_fwd_kernel<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        const double bytes = (double)a.M * D + 4.0 * a.M + (double)a.B * D * 2 + (double)a.B * 16;
+        ProfScope prof(PK_BANK_FWD, bytes, st);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, ws);
+    }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// SPN_BANK_FP8_MFMA=0 keeps the forward pass of an fp8 bank on the dequantise-to-bf16 path (A/B switch)
+static bool bank_fp8_mfma_on() {
+    static const bool on = [] {
+        const char* e = getenv("SPN_BANK_FP8_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // ------------------------------------------------------------------ token-max bank, wave-private tiles
 // Same contract as bank_stream_kernel<.., GRP = true>, restructured for small D (the Q-Former's 256): the
 // block kernel above splits D over its four waves and pays three block barriers per 16 KB tile.  Here every wave owns
@@ -839,6 +1096,16 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     if (tokmax_wave_path(a)) {
         rc = a.D == 128 ? launch_tokmax<128, false>(a, c, nullptr, 0.f, 0.f, ws, st)
                         : launch_tokmax<256, false>(a, c, nullptr, 0.f, 0.f, ws, st);
+    } else if (a.bank_scale && !a.group && bank_fp8_mfma_on() && c.rows <= FP8_MAX_CHUNK_ROWS) {
+        switch (a.D) {
+            case 128: rc = launch_bank_fp8_fwd<128>(a, c, ws, st); break;
+            case 256: rc = launch_bank_fp8_fwd<256>(a, c, ws, st); break;
+            case 512: rc = launch_bank_fp8_fwd<512>(a, c, ws, st); break;
+            case 640: rc = launch_bank_fp8_fwd<640>(a, c, ws, st); break;
+            case 768: rc = launch_bank_fp8_fwd<768>(a, c, ws, st); break;
+            case 1024: rc = launch_bank_fp8_fwd<1024>(a, c, ws, st); break;
+            default: return SPN_ERR_SHAPE;
+        }
     } else {
         SPN_BANK_DISPATCH(false, a, c, nullptr, 0.f, 0.f, ws, st)
     }

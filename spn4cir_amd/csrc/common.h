@@ -67,6 +67,10 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_ba
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // LDS transpose read: within each 16-lane group the 16 lanes address a 4x16 block of 16-bit
 // elements (lane i -> row i>>2, columns (i&3)*4..+3, 8 bytes each); lane i receives column i

@@ -41,11 +41,6 @@ __device__ __forceinline__ int stage_slot(int unit, int r) {
     return ((unit >> 1) | ((unit & 1) * (BN / 8))) ^ (r & 15);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // ----------------------------------------------------------------------------------- NT
 // LDS image of a [rows][64 k] bf16 tile: row r at byte r*128, logical 16-B k-chunk c at
 // position c ^ ((r>>1)&7) (conflict-free for the 32-row ds_read_b128 fragments).

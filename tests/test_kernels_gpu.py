@@ -431,11 +431,16 @@ def test_bank_fp8(ops, B, M, D, tau):
     assert torch.equal(fb.data[:, :D].cpu(), data_ref) and not fb.data[:, D:].any()
     assert torch.equal(fb.scale.cpu(), scale_ref)
     qr = qb[:, :D].cpu().float()
-    br = bf(bank_loss.dequantize_e4m3(data_ref, scale_ref)).float()       # the kernel rounds the dequantised tile to bf16
-    lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+    br = bf(bank_loss.dequantize_e4m3(data_ref, scale_ref)).float()       # the dequantising kernels round the tile to bf16
+    if B < 128:     # streaming forward on the fp8 MFMA: exact e4m3 bank x scale, queries as two e4m3 terms
+        lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(bank_loss.split_query_e4m3(qr),
+                                                            bank_loss.dequantize_e4m3(data_ref, scale_ref), labels, tau)
+    else:           # large batches: the shard is expanded to bf16 once and the bf16 GEMM path runs on it
+        lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
     stats = ops.bank_stats_fwd(qb, fb, dev(labels), 1.0 / tau)
     lse, row, mean = ops.bank_loss_finalize(stats, M)
     assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+    assert (stats[:, 3].cpu().double() - lab_ref).abs().max() < 2e-4
     assert abs(mean.item() - row_ref.mean().item()) < 2e-4
     dq = ops.bank_grad_q(qb, fb, dev(labels), 1.0 / tau, lse, 1.0 / B)
     assert rel_err(dq[:, :D], bank_loss.infonce_grad_q(qr, br, labels, tau)) < 1.5e-2
