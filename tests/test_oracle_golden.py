@@ -235,3 +235,20 @@ def test_tgcir_oracle_image_side_matches_reference(golden_dir):
     emb, pooled = tgcir_head.img_embed(vsd, ihead, images)
     assert (emb - torch.from_numpy(z["img_tokens"])).abs().max() < 2e-5
     assert (pooled - torch.from_numpy(z["img_pooled"])).abs().max() < 2e-6
+
+
+def test_query_split_e4m3_model():
+    """oracle.bank_loss.split_query_e4m3 (the model of the fp8-MFMA bank pass): two e4m3 terms carry a query to ~2^-8 of its
+    largest element, a zero row stays zero, and the split of an exactly representable row is exact."""
+    from oracle import bank_loss
+    g = torch.Generator().manual_seed(11)
+    q = torch.nn.functional.normalize(torch.randn(64, 768, generator=g), dim=1).bfloat16().float()
+    m = bank_loss.split_query_e4m3(q)
+    err = (m - q).abs().amax(dim=1) / q.abs().amax(dim=1)
+    assert err.max().item() < 2.0 ** -7
+    one = bank_loss.split_query_e4m3(q[:1])                 # per-row: independent of the other rows
+    assert torch.equal(one, m[:1])
+    z = torch.zeros(2, 768)
+    assert torch.equal(bank_loss.split_query_e4m3(z), z)
+    exact = torch.tensor([[448.0, -224.0, 1.0, 0.5, 0.0, 28.0, -0.015625, 2.0]])      # e4m3 values at scale 1
+    assert torch.equal(bank_loss.split_query_e4m3(exact), exact)
