@@ -196,7 +196,14 @@ def attn_ref(q, k, v, B, H, Lq, Lk, causal, key_bias, scale):
                                                    (1, 2, 257, 257, False, False), (2, 2, 9, 577, False, False),
                                                    (3, 2, 20, 20, False, True), (2, 1, 130, 130, True, False),
                                                    (2, 2, 32, 577, False, True), (1, 3, 64, 200, False, False),
-                                                   (2, 1, 40, 100, False, True), (2, 2, 77, 77, True, True)])
+                                                   (2, 1, 40, 100, False, True), (2, 2, 77, 77, True, True),
+                                                   # every wave count of the whole-head kernels, tile-edge lengths
+                                                   (2, 2, 1, 1, True, False), (2, 2, 16, 16, False, False),
+                                                   (2, 2, 17, 17, True, False), (1, 2, 48, 48, True, True),
+                                                   (2, 1, 64, 64, False, False), (1, 1, 65, 65, True, False),
+                                                   (1, 2, 96, 96, False, True), (1, 2, 113, 113, False, True),
+                                                   (1, 1, 128, 128, True, False), (2, 2, 16, 577, False, False),
+                                                   (1, 2, 64, 65, False, True), (1, 1, 33, 100, False, False)])
 def test_attention_fwd_bwd(ops, B, H, Lq, Lk, causal, bias):
     g = torch.Generator().manual_seed(B * 1000 + Lq)
     W = H * 64
