@@ -255,6 +255,15 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
             // latency hides behind the LDS staging of the accumulators instead of stalling every row
             [[maybe_unused]] bf16x8 pf_aux[ITERS];
             [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
+            [[maybe_unused]] int64_t bs_lab[ITERS];            // BANKSTATS: the rows' labels, fetched ahead of the staging
+            if constexpr (MODE == GEMM_BANKSTATS) {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int rr = wid * RPI + lane / LPR + it * NW * RPI;
+                    const int m = min(m0 + ch * CHUNK + rr, M - 1);
+                    bs_lab[it] = ep.bs_labels[m] - (int64_t)ep.bs_m_begin;
+                }
+            }
             if constexpr (MODE == GEMM_DACT || MODE == GEMM_RESID) {
 #pragma unroll
                 for (int it = 0; it < ITERS; ++it) {
@@ -314,19 +323,17 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                 if constexpr (MODE == GEMM_BANKSTATS) {
                     // this lane's 8 logits of row m -> {max, sum exp, sum, label logit}, merged over the LPR lanes
                     // that share the row (consecutive lanes: xor shuffles below LPR stay inside the row)
-                    const int64_t lab = ep.bs_labels[m] - (int64_t)ep.bs_m_begin;
+                    const int64_t lab = bs_lab[it];
                     float mx = -INFINITY, sl = 0.f, lv = -INFINITY, l = 0.f;
                     float z[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
+                    for (int e = 0; e < 8; ++e) {          // predicates, not branches (one exec-mask branch per logit otherwise)
                         const float x = (e < 4 ? v0[e] : v1[e - 4]) * ep.bs_inv_tau;
                         const bool ok = n + e < N;
                         z[e] = ok ? x : -INFINITY;
-                        if (ok) {
-                            mx = fmaxf(mx, x);
-                            sl += x;
-                            if ((int64_t)(n + e) == lab) lv = x;
-                        }
+                        mx = fmaxf(mx, z[e]);
+                        sl += ok ? x : 0.f;
+                        lv = (ok & ((int64_t)(n + e) == lab)) ? x : lv;
                     }
                     // row maximum over the tile first (shuffles only), then ONE exponential per logit against it: the
                     // pairwise online merge cost two more exponentials per lane and shuffle stage (18 instead of 8)
