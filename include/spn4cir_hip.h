@@ -366,6 +366,17 @@ int spn_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, i
 int spn_attnpool_tokens_f32(const float* x_nhwc, const float* pos, float* tok, int B, int HW, int C, void* stream);
 int spn_attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, void* stream);
 
+/* ModifiedResNet, bf16 fast path (same reference lines; throughput mode for bank extraction / validation, the fp32 calls
+ * above stay the exact mode).  NHWC bf16 activations with the channel count padded to a multiple of 64 (Cp; pad channels
+ * hold zeros); a 3x3 convolution is spn_im2col3x3_nhwc_bf16 -> [B*Ho*Wo, 9*Cp] (column = tap * Cp + channel) or, for the
+ * stem's first convolution on the fp32 NCHW image, spn_im2col3x3_stem_bf16 -> [B*Ho*Wo, 64] (column = tap * 3 + channel,
+ * 27 used), followed by spn_gemm_nt (BatchNorm folded into the bf16 weight and the fp32 bias by the host);
+ * spn_relu_add_bf16: y = relu(y + resid) in place (resid may be NULL, n % 8 == 0); spn_avgpool_nhwc_bf16 = nn.AvgPool2d(k). */
+int spn_im2col3x3_nhwc_bf16(const void* x, void* out, int B, int H, int W, int Cp, int stride, void* stream);
+int spn_im2col3x3_stem_bf16(const float* image_nchw, void* out, int B, int H, int W, int stride, void* stream);
+int spn_relu_add_bf16(void* y, const void* resid, size_t n, void* stream);
+int spn_avgpool_nhwc_bf16(const void* x, void* y, int B, int H, int W, int Cp, int k, void* stream);
+
 /* ---------------------------------------------------------------- BLIP fusion encoder
  * blip4cir/med.py BertModel(mode='multimodal') + text_proj (blip_cir.py:82-98): the query producer of
  * blip4cir/models.py:95-105.  ids [B,L] int32 (ids[:,0] = [ENC]), mask [B,L] int32 {0,1} (may be NULL),

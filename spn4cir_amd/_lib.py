@@ -129,6 +129,10 @@ _SIGS = {
     "spn_im2col3x3_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "spn_avgpool_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "spn_attnpool_tokens_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "spn_im2col3x3_nhwc_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "spn_im2col3x3_stem_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "spn_relu_add_bf16": (i32, [vp, vp, C.c_size_t, vp]),
+    "spn_avgpool_nhwc_bf16": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "spn_attnpool_attend_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),

@@ -505,6 +505,22 @@ int spn_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, i
     return avgpool_nhwc_f32(x, y, B, H, W, C, k, ST(stream));
 }
 
+int spn_im2col3x3_nhwc_bf16(const void* x, void* out, int B, int H, int W, int Cp, int stride, void* stream) {
+    return im2col3x3_nhwc_bf16((const bf16_t*)x, (bf16_t*)out, B, H, W, Cp, stride, ST(stream));
+}
+
+int spn_im2col3x3_stem_bf16(const float* image, void* out, int B, int H, int W, int stride, void* stream) {
+    return im2col3x3_stem_bf16(image, (bf16_t*)out, B, H, W, stride, ST(stream));
+}
+
+int spn_relu_add_bf16(void* y, const void* resid, size_t n, void* stream) {
+    return relu_add_bf16((bf16_t*)y, (const bf16_t*)resid, n, ST(stream));
+}
+
+int spn_avgpool_nhwc_bf16(const void* x, void* y, int B, int H, int W, int Cp, int k, void* stream) {
+    return avgpool_nhwc_bf16((const bf16_t*)x, (bf16_t*)y, B, H, W, Cp, k, ST(stream));
+}
+
 int spn_attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int HW, int C, void* stream) {
     if (!x || !pos || !tok) return SPN_ERR_ARG;
     return attnpool_tokens_f32(x, pos, tok, B, HW, C, ST(stream));

@@ -139,6 +139,11 @@ int gemm_f32(const float* A, const float* B, int M, int N, int K, int lda, int l
              const float* resid, int ldr, float* C, int ldc, float alpha, hipStream_t st);
 int im2col3x3_f32(const float* x, float* out, int B, int H, int W, int C, int stride, int nchw, int ldk, hipStream_t st);
 int avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int k, hipStream_t st);
+// bf16 fast path (resnet.hip)
+int im2col3x3_nhwc_bf16(const bf16_t* x, bf16_t* out, int B, int H, int W, int Cp, int stride, hipStream_t st);
+int im2col3x3_stem_bf16(const float* image, bf16_t* out, int B, int H, int W, int stride, hipStream_t st);
+int relu_add_bf16(bf16_t* y, const bf16_t* resid, size_t n, hipStream_t st);
+int avgpool_nhwc_bf16(const bf16_t* x, bf16_t* y, int B, int H, int W, int Cp, int k, hipStream_t st);
 int attnpool_tokens_f32(const float* x, const float* pos, float* tok, int B, int HW, int C, hipStream_t st);
 int attnpool_attend_f32(const float* q, const float* k, const float* v, float* out, int B, int S, int H, hipStream_t st);
 size_t text_exact_ws_bytes(const TextCfg& c);

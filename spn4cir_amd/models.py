@@ -125,7 +125,7 @@ class CIRPlus(nn.Module):
                                                                                                    requires_grad=False))
             if "visual.layer1.0.conv1.weight" in sd and "visual.attnpool.positional_embedding" in sd:
                 from .resnet_tower import ResNetTower          # ModifiedResNet (RN50x4 = train_negplus.py's default)
-                self.vision = ResNetTower(sd, self.device)
+                self.vision = ResNetTower(sd, self.device, fast=True)     # bf16 like the ViT tower; exact_eval -> fp32
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self.combining_function = self.element_wise_sum
         self.tau = tau
@@ -199,7 +199,8 @@ class CIRPlus(nn.Module):
         elif self.vision is not None:
             from .resnet_tower import ResNetTower
             vis = {k[len("clip."):]: v for k, v in self.state_dict().items() if k.startswith("clip.visual.")}
-            self.vision = ResNetTower({k.replace("downsample.avgpool", "downsample.-1"): v for k, v in vis.items()}, self.device)
+            self.vision = ResNetTower({k.replace("downsample.avgpool", "downsample.-1"): v for k, v in vis.items()}, self.device,
+                                      fast=True)
 
     # ---------------------------------------------------------------------------- banks
     @property

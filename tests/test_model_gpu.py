@@ -372,6 +372,36 @@ def test_resnet_tower_matches_reference(golden_dir):
     assert (1 - cos).max() < 1e-6
 
 
+def test_resnet_tower_fast_path(golden_dir):
+    """ModifiedResNet bf16 throughput mode (channels padded to 64, bf16 MFMA convolutions, csrc/resnet.hip) against the
+    reference's encode_image on the tiny RN CLIP and against the tower's own fp32 path on a wider synthetic one:
+    1 - cos < 2e-3 (bf16 activations through every convolution), forward_exact() still gives the fp32 result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import sys
+    import numpy as np
+    from spn4cir_amd.resnet_tower import ResNetTower
+    z = np.load(os.path.join(golden_dir, "tiny_clip_resnet.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    t = ResNetTower(sd, "cuda", fast=True)
+    img = torch.from_numpy(z["image"])
+    ref = torch.from_numpy(z["image_feats"])
+    out = t.forward(img).cpu()
+    cos = torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)
+    assert (1 - cos).max() < 2e-3, (1 - cos).max()
+    assert (t.forward_exact(img).cpu() - ref).abs().max() < 1e-4 * ref.abs().max()
+    # a wider geometry (odd widths exercise the channel padding: 24 -> 64, 96 -> 128, ...), strides and downsampling
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from vision_bench import resnet_state_dict
+    sd2 = resnet_state_dict((2, 2, 2, 2), 24, 96, 256, seed=3)
+    t2 = ResNetTower(sd2, "cuda", fast=True)
+    img2 = torch.randn(3, 3, 96, 96, generator=torch.Generator().manual_seed(5))
+    a, b = t2.forward(img2).cpu(), t2.forward_exact(img2).cpu()
+    cos2 = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1)
+    assert (1 - cos2).max() < 2e-3, (1 - cos2).max()
+
+
 def test_cirplus_with_resnet_image_tower(golden_dir):
     """A checkpoint whose visual tower is a ModifiedResNet (train_negplus.py's default RN50x4 family): encode_image
     goes through ResNetTower, input_dim follows the attention pool's grid."""
@@ -386,8 +416,11 @@ def test_cirplus_with_resnet_image_tower(golden_dir):
     sd.update({k[4:]: torch.from_numpy(zr[k]) for k in zr.files if k.startswith("sd::")})
     model = CIRPlus(sd, device=torch.device("cuda"))
     assert model.input_dim == 64
-    out = model.encode_image(torch.from_numpy(zr["image"]).cuda()).cpu()
     ref = torch.from_numpy(zr["image_feats"])
+    out = model.encode_image(torch.from_numpy(zr["image"]).cuda()).cpu()          # bf16 throughput mode (as the ViT tower)
+    assert (1 - torch.nn.functional.cosine_similarity(out.double(), ref.double(), dim=-1)).max() < 2e-3
+    model.exact_eval = True                                                       # fp32 path
+    out = model.encode_image(torch.from_numpy(zr["image"]).cuda()).cpu()
     assert (out - ref).abs().max() < 1e-4 * ref.abs().max()
 
 

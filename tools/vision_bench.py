@@ -59,11 +59,12 @@ def main():
     ap.add_argument("--model", default="ViT-L/14")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--fast", action="store_true", help="ModifiedResNet towers: the bf16 throughput mode")
     a = ap.parse_args()
     if a.model in RN_CFG:
         from spn4cir_amd.resnet_tower import ResNetTower
         layers, width, res, D = RN_CFG[a.model]
-        t = ResNetTower(resnet_state_dict(layers, width, res, D), "cuda")
+        t = ResNetTower(resnet_state_dict(layers, width, res, D), "cuda", fast=a.fast)
         img = torch.randn(a.batch, 3, res, res).cuda()
         t.forward(img)
         torch.cuda.synchronize()
@@ -72,7 +73,8 @@ def main():
             t.forward(img)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
-        print(json.dumps({"model": a.model + " (ModifiedResNet, fp32 path)", "batch": a.batch,
+        print(json.dumps({"model": a.model + (" (ModifiedResNet, bf16 fast path)" if a.fast else " (ModifiedResNet, fp32 path)"),
+                          "batch": a.batch,
                           "images_per_s": round(a.batch / dt, 1), "ms_per_batch": round(dt * 1e3, 2)}))
         return
     W, layers, H, p, res, D, kind = CFG[a.model]
