@@ -198,6 +198,10 @@ int attention_fwd(const AttnArgs& a, hipStream_t st) {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         return attention_cross_fwd(a, st);
     }
+    if (!a.causal && !a.cu && !attn_force_flash()) {       // the image towers (257 / 577 tokens)
+        ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
+        return attention_cross_fwd_blocks(a, st);
+    }
     {
         ProfScope prof(PK_ATTN_FWD, 4.0 * a.B * a.H * a.Lq * a.Lk * HD, st);
         hipLaunchKernelGGL(attention_fwd_kernel, dim3((a.Lq + 63) / 64, a.B * a.H), dim3(256), 0, st, a);

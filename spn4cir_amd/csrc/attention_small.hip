@@ -433,7 +433,7 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
         }
     };
     fetch(0);
-    const int q0 = w * 16, qrow = q0 + (lane & 15);
+    const int q0 = blockIdx.y * (NQ * 16) + w * 16, qrow = q0 + (lane & 15);      // grid.y: blocks of NQ * 16 queries
     const bool row_ok = qrow < Lq;
     bf16x8 qf[2];
 #pragma unroll
@@ -510,6 +510,36 @@ __global__ __launch_bounds__(NQ * 64) void attention_cross_fwd_kernel(AttnArgs a
     if (!row_ok) return;
     if (a.lse && (lane >> 4) == 0)
         a.lse[((size_t)b * a.H + h) * Lq + qrow] = l_run > 0.f ? m_run + __logf(l_run) : -INFINITY;
+}
+
+// Non-causal attention with MORE than 64 queries (the ViT image towers: 257 / 577 tokens): the same kernel with 64-query
+// blocks in grid.y - K / V tiles prefetched into registers and read with the LDS transpose instruction, where the tiled
+// kernel of attention.hip loads each tile synchronously and transposes V with 2-byte LDS stores.
+template <int NQ>
+static int launch_cross_fwd_blocks(const AttnArgs& a, hipStream_t st) {
+    const dim3 grid(a.B * a.H, (a.Lq + NQ * 16 - 1) / (NQ * 16));
+    if (a.key_bias) hipLaunchKernelGGL((attention_cross_fwd_kernel<NQ, true>), grid, dim3(NQ * 64), 0, st, a);
+    else hipLaunchKernelGGL((attention_cross_fwd_kernel<NQ, false>), grid, dim3(NQ * 64), 0, st, a);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+int attention_cross_fwd_blocks(const AttnArgs& a, hipStream_t st) {
+    // waves per block (16 queries each): the fewest query blocks (every block streams all of K and V), then the fewest idle
+    // waves - 257 tokens: 3 blocks of 6 waves (18 slots for 17 row tiles), 577: 5 blocks of 8
+    const int tiles = (a.Lq + 15) / 16;
+    int best = 4, best_blocks = (tiles + 3) / 4;
+    for (int nq = 5; nq <= 8; ++nq) {
+        const int nb = (tiles + nq - 1) / nq;
+        if (nb < best_blocks || (nb == best_blocks && nb * nq < best_blocks * best)) { best = nq; best_blocks = nb; }
+    }
+    switch (best) {
+        case 4: return launch_cross_fwd_blocks<4>(a, st);
+        case 5: return launch_cross_fwd_blocks<5>(a, st);
+        case 6: return launch_cross_fwd_blocks<6>(a, st);
+        case 7: return launch_cross_fwd_blocks<7>(a, st);
+        default: return launch_cross_fwd_blocks<8>(a, st);
+    }
 }
 
 int attention_cross_fwd(const AttnArgs& a, hipStream_t st) {

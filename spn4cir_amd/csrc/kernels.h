@@ -158,6 +158,7 @@ int attention_small_bwd(const AttnBwdArgs& a, hipStream_t st);
 bool attention_cross_ok(const AttnArgs& a);
 int attention_cross_bwd(const AttnBwdArgs& a, hipStream_t st);
 int attention_cross_fwd(const AttnArgs& a, hipStream_t st);
+int attention_cross_fwd_blocks(const AttnArgs& a, hipStream_t st);   // non-causal, any Lq: 64-query blocks in grid.y
 
 // bank.hip
 int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
