@@ -16,18 +16,23 @@ from .distributed import BankLossDP, GradBucketReducer, _world, shard_range
 
 def wgrad_groups(layers, world):
     """How the backward pass batches the weight gradients of its blocks (TextTower.backward_phased): one process takes
-    all of them in one grouped launch (<= 12 blocks per launch); data-parallel ranks use two groups, so that the first
-    group's gradient all-reduce still runs under the second group's backward (7 + 5 of 12 blocks: 756 and 540 tiles of
-    256x256, i.e. 2.95 and 2.11 rounds of 256 CUs - the remainders are split over the reduction by the kernel).
+    all of them in one grouped launch (<= 12 blocks per launch); data-parallel ranks use three groups (7 + 3 + 2 of 12
+    blocks), so that each group's gradient all-reduce runs under the backward of the following ones (partial rounds of
+    256 CUs are split over the reduction by the kernel).
     SPN_WGRAD_GROUPS="a,b,.." overrides; "0" = no deferral (one grouped launch per block)."""
     import os
     env = os.environ.get("SPN_WGRAD_GROUPS")
     if env is not None:
         return None if env.strip() in ("", "0") else [int(x) for x in env.split(",")]
     if world > 1 and 4 <= layers <= 24:
+        # three groups: the all-reduce of a group runs under the data path and weight gradients of the next ones, the
+        # embedding gradients' (Stage2Trainer: reported before the LAST group's launch) under that launch, and only the
+        # small last group's own all-reduce is left for the AdamW update of everything else to cover
         first = min(12, (7 * layers + 11) // 12)
-        rest = layers - first
-        return [first] + ([rest] if rest <= 12 else [12, rest - 12])
+        last = max(1, min(layers - first, (layers + 3) // 6))
+        mid = layers - first - last
+        groups = [first] + ([mid] if 0 < mid <= 12 else ([12, mid - 12] if mid > 12 else [])) + [last]
+        return groups
     groups, left = [], layers
     while left > 0:
         groups.append(min(12, left))
@@ -80,19 +85,26 @@ class Stage2Trainer:
                                    self.model.label_smoothing)
         dq = self.loss_dp.backward(ctx)
         dtext = ops.combine_l2norm_bwd(q, inv, dq[:, :t.embed_dim].contiguous())
-        # Data parallel: the embedding gradients (the head of the flat buffer, 38 M of the 124 M parameters) are only
-        # final when backward ends, so their all-reduce cannot hide behind backward.  It gets its own bucket and runs
-        # under the AdamW update of everything else (HBM-bound vs link-bound), then the embeddings are updated.
-        tail_end = t.layer_spans()[-1][1]
+        # Data parallel: the embedding gradients (the head of the flat buffer, 38 M of the 124 M parameters) need the data
+        # path of block 0, i.e. the end of backward - but not the deferred weight gradients: they are computed and their
+        # all-reduce is started BEFORE the last group's grouped launch (backward_phased(embed_early=True)) and runs under
+        # it.  What is left in flight at the end is the last group's own (small) bucket: it runs under the AdamW update
+        # of everything else (HBM-bound vs link-bound), then that range is updated.
+        spans = t.layer_spans()
+        groups = wgrad_groups(t.layers, self.world)
+        split = self.world > 1 and not self.check_finite and groups is not None
+        # flat range of the last group's blocks (blocks 0 .. groups[-1]-1): contiguous behind the embeddings
+        keep = (spans[-1][1], spans[-1 - groups[-1]][1]) if split else None
 
         def on_span(start, end):
-            if start == 0 and self.world > 1 and not self.check_finite:
-                self.reducer.flush()                      # everything before the tail goes out as its own bucket(s)
+            if start == 0 and split:
+                self.reducer.flush()                      # everything before the embeddings goes out as its own bucket(s)
             self.reducer.on_span_ready(start, end)
+            if start == 0 and split:
+                self.reducer.flush()                      # ... and so do the embeddings, now
 
-        t.backward_phased(dtext, on_span, wgrad_groups(t.layers, self.world))
-        split = self.world > 1 and not self.check_finite
-        pending = self.reducer.finish(keep_span=(0, tail_end) if split else None)
+        t.backward_phased(dtext, on_span, groups, embed_early=split)
+        pending = self.reducer.finish(keep_span=keep)
         self.step_count += 1
         found = None
         if self.check_finite:
@@ -100,13 +112,16 @@ class Stage2Trainer:
             ops.grad_check_finite(t.grads, self.found_inf)
             found = self.found_inf
         if split and pending:
-            s = tail_end
-            ops.adamw_step(t.params[s:], t.grads[s:], self.m[s:], self.v[s:], self.step_count, self.lr, self.betas, self.eps,
-                           self.wd, 1.0, None)
+            lo, hi = keep
+
+            def upd(a, b):
+                ops.adamw_step(t.params[a:b], t.grads[a:b], self.m[a:b], self.v[a:b], self.step_count, self.lr, self.betas,
+                               self.eps, self.wd, 1.0, None)
+            upd(0, lo)
+            upd(hi, t.params.numel())
             for w in pending:
                 w.wait()
-            ops.adamw_step(t.params[:s], t.grads[:s], self.m[:s], self.v[:s], self.step_count, self.lr, self.betas, self.eps,
-                           self.wd, 1.0, None)
+            upd(lo, hi)
         else:
             ops.adamw_step(t.params, t.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd,
                            1.0, found)

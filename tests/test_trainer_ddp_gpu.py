@@ -16,7 +16,8 @@ W, LAYERS, D, VOCAB, B, M, TAU, LR = 128, 2, 128, 600, 16, 901, 0.03, 1e-3
 
 def _setup():
     from spn4cir_amd import synthetic
-    sd = synthetic.text_state_dict(W, LAYERS, D, vocab=VOCAB, seed=0)
+    layers = int(os.environ.get("SPN_TEST_DDP_LAYERS", LAYERS))     # inherited by the spawned ranks
+    sd = synthetic.text_state_dict(W, layers, D, vocab=VOCAB, seed=0)
     target, refer = synthetic.banks(M, D)
     ids = synthetic.token_ids(B, vocab=VOCAB, seed=1)
     ridx, labels = synthetic.triplet_indices(B, M)
@@ -52,10 +53,12 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sharded", "replicated"])
-def test_two_ranks_match_single_process(mode):
+@pytest.mark.parametrize("mode,layers", [("sharded", 2), ("replicated", 2),
+                                         ("sharded", 6)])    # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
+def test_two_ranks_match_single_process(mode, layers, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("SPN_TEST_DDP_LAYERS", str(layers))
     from spn4cir_amd.models import CIRPlus
     from spn4cir_amd.trainer import Stage2Trainer
     sd, target, refer, ids, ridx, labels = _setup()
@@ -79,8 +82,13 @@ def test_two_ranks_match_single_process(mode):
     for rank, losses, params in res:
         for a, b in zip(losses, ref_losses):
             assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (mode, rank, losses, ref_losses)
-        # same update as the single-process run: differences only from bf16 rounding of partial sums
-        assert (params - ref_params).abs().max() < 2e-3, (mode, rank, (params - ref_params).abs().max().item())
+        # same update as the single-process run: differences only from bf16 rounding of partial sums.  AdamW moves every
+        # element by ~lr per step whatever the gradient's size, so an element whose gradient is rounding noise can differ
+        # by 2 lr per step (opposite signs); the deeper model has a few of those: bound = 2 steps x 2 lr, and all but a
+        # handful of elements within the 2-block bound
+        diff = (params - ref_params).abs()
+        assert diff.max() < (2e-3 if layers == 2 else 4.2e-3), (mode, rank, diff.max().item())
+        assert (diff > 2e-3).float().mean() < 1e-4
     assert (res[0][2] - res[1][2]).abs().max() == 0.0       # replicas stay bit-identical
 
 
