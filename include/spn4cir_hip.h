@@ -184,6 +184,12 @@ int spn_inbatch_grad_t(const void* q_bf16, const void* t_bf16, int ld, const flo
  * skipped when *found_inf != 0 (GradScaler.step).  step is 1-based. */
 int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float inv_scale, const float* found_inf, void* stream);
+/* the same with the gradient (loss) scale read on the DEVICE: g is divided by *grad_scale (NULL = 1) - what
+ * torch.amp.GradScaler hands an optimizer that declares _step_supports_amp_scaling (optimizer.grad_scale /
+ * optimizer.found_inf, both 1-element device tensors), so the reference's scaler.step(optimizer) needs no host sync. */
+int spn_adamw_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
+                          void* stream);
 int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream);
 
 /* ---------------------------------------------------------------- Recall@K (validate.py:28-33)

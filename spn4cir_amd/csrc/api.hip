@@ -235,6 +235,14 @@ int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float
     return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, inv_scale, found_inf, ST(stream));
 }
 
+int spn_adamw_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
+                          void* stream) {
+    if (!p || !g || !m || !v) return SPN_ERR_ARG;
+    return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, 1.0f, found_inf, ST(stream), grad_scale);
+}
+
+
 int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream) {
     if (!g || !found_inf) return SPN_ERR_ARG;
     return grad_unscale_check(const_cast<float*>(g), n, 1.0f, found_inf, ST(stream));

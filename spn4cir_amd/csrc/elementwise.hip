@@ -591,8 +591,10 @@ int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_
 // *found_inf != 0 (GradScaler.step semantics).
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float rsqrt_bc2, float inv_scale, const float* __restrict__ found_inf) {
+                             float bc1, float rsqrt_bc2, float inv_scale, const float* __restrict__ found_inf,
+                             const float* __restrict__ grad_scale) {
     if (found_inf && *found_inf != 0.f) return;
+    if (grad_scale) inv_scale /= *grad_scale;            // GradScaler's scale, read on the device (no host sync)
     const size_t n4 = n >> 2;
     const float step_size = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -624,7 +626,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st) {
+               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st, const float* grad_scale) {
     if (n == 0) return SPN_OK;
     if (step < 1) return SPN_ERR_ARG;
     const double bc1 = 1.0 - pow((double)b1, (double)step);
@@ -634,7 +636,7 @@ int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr,
     // CU count loses 20 %: every workgroup does the same share in one round).  SPN_ADAMW_CAP overrides the grid.
     static const int cap = [] { const char* e = getenv("SPN_ADAMW_CAP"); return e ? atoi(e) : device_cu_count(); }();
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
-                       (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf);
+                       (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf, grad_scale);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

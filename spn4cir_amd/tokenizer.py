@@ -44,6 +44,8 @@ class ClipTokenizer:
         self.byte_id = {b: i for i, b in enumerate(_byte_order())}
         self.context_length = context_length
         self._cache = {}
+        self._text_cache = {}          # whole captions: a training set repeats its captions every epoch
+        self._text_cache_max = 1 << 20
 
     def _bpe(self, word_bytes):
         ids = [self.byte_id[b] for b in word_bytes]
@@ -70,6 +72,15 @@ class ClipTokenizer:
         return ids
 
     def encode(self, text):
+        hit = self._text_cache.get(text)
+        if hit is not None:
+            return hit
+        out = self._encode(text)
+        if len(self._text_cache) < self._text_cache_max:
+            self._text_cache[text] = out
+        return out
+
+    def _encode(self, text):
         text = html.unescape(html.unescape(text)).strip()
         text = " ".join(text.split()).lower()
         out = []
@@ -91,16 +102,20 @@ class ClipTokenizer:
         if isinstance(texts, str):
             texts = [texts]
         L = context_length or self.context_length
-        result = torch.zeros(len(texts), L, dtype=torch.int32)
-        for i, t in enumerate(texts):
-            ids = [SOT] + self.encode(t) + [EOT]
-            if len(ids) > L:
+        result = np.zeros((len(texts), L), dtype=np.int32)      # filled through numpy: one small torch.tensor per row
+        for i, t in enumerate(texts):                           # cost more than the BPE itself
+            ids = self.encode(t)
+            n = len(ids) + 2
+            if n > L:
                 if not truncate:
                     raise RuntimeError(f"Input {t} is too long for context length {L}")
-                ids = ids[:L]
-                ids[-1] = EOT
-            result[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
-        return result
+                ids = ids[:L - 2]
+                n = L
+            row = result[i]
+            row[0] = SOT
+            row[1:n - 1] = ids
+            row[n - 1] = EOT
+        return torch.from_numpy(result)
 
 
 _default = None

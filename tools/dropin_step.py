@@ -18,7 +18,11 @@ def main():
              "lighter green collar buttons casual formal the same but different style material lace silk cotton").split()
     caps = [" ".join(random.choice(words) for _ in range(random.randint(5, 30))) for _ in range(B)]
     ridx, labels = synthetic.triplet_indices(B, M, seed=4)
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-5, betas=(0.9, 0.999), eps=1e-7)
+    if "--fused-optim" in sys.argv:          # the one-line change of INTEGRATION.md: same arguments, one fused launch
+        from spn4cir_amd.optim import AdamW
+        opt = AdamW(model.parameters(), lr=2e-5, betas=(0.9, 0.999), eps=1e-7)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-5, betas=(0.9, 0.999), eps=1e-7)
     scaler = torch.cuda.amp.GradScaler()
     def step():
         opt.zero_grad(set_to_none=True)
