@@ -72,6 +72,22 @@ class AdamW(torch.optim.Optimizer):
                 out.append(dict(params=r, p_flat=_flat_view(r[0], n), m=m, v=v, numel=n))
             self._runs.append(out)
 
+    def load_state_dict(self, state_dict):
+        """torch semantics; the loaded per-parameter moments are copied into the flat state of the runs."""
+        super().load_state_dict(state_dict)
+        loaded = {p: dict(st) for p, st in self.state.items()}
+        self._build_runs()                                   # fresh flat state, self.state[p] re-pointed at its views
+        steps = 0
+        for p, old in loaded.items():
+            st = self.state[p]
+            if "exp_avg" in old:
+                st["exp_avg"].copy_(old["exp_avg"].to(st["exp_avg"].device, torch.float32).view_as(st["exp_avg"]))
+                st["exp_avg_sq"].copy_(old["exp_avg_sq"].to(st["exp_avg_sq"].device, torch.float32).view_as(st["exp_avg_sq"]))
+            if "step" in old:
+                st["step"] = torch.as_tensor(float(old["step"]), dtype=torch.float32)
+                steps = max(steps, int(float(old["step"])))
+        self._steps = steps
+
     @staticmethod
     def _grads_flat(run):
         """The run's gradients as one flat tensor if they are consecutive slices of one buffer, else None."""

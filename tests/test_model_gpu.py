@@ -664,6 +664,22 @@ def test_fused_adamw_arithmetic_matches_torch():
     for kind in ("fused", "groups", "elsewhere"):
         assert (out[kind] - out["torch"]).abs().max().item() < 2e-6, kind
     assert (out["torch"] - p0.cuda()).abs().max().item() > 1e-3
+    # state_dict round trip: a fresh optimizer that loads the state after step 1 continues like the uninterrupted one
+    flat, gflat, ps, opt = build("fused")
+    gflat.copy_(grads[0].cuda())
+    for p, gv in ps:
+        p.grad = gv
+    opt.step()
+    sd = opt.state_dict()
+    flat2, gflat2, ps2, opt2 = build("fused")
+    flat2.copy_(flat)
+    opt2.load_state_dict(sd)
+    for f_, g_, pp, o_ in ((flat, gflat, ps, opt), (flat2, gflat2, ps2, opt2)):
+        g_.copy_(grads[1].cuda())
+        for p, gv in pp:
+            p.grad = gv
+        o_.step()
+    assert torch.equal(flat, flat2)
 
 
 def test_fused_adamw_in_the_reference_loop(golden_dir):
