@@ -261,7 +261,9 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": name, "launches": dn, "avg_us": round(dms / dn * 1e3, 1),
                     "share_of_step": round(dms / dn * launches_total / (dt * 1e3), 3),
-                    "timed": f"HIP-event pairs around every {max(1, args.prof_every)}-th launch inside the timed region"}
+                    "timed": f"HIP-event pairs around every {max(1, args.prof_every)}-th launch inside the timed region",
+                    "clock_note": "peak is the 2.4 GHz dense bf16 figure; the matrix kernels run power-limited at 1.6-2.0 GHz "
+                                  "on this part (rocm-smi samples: profiles/r02_gemm_power_clock.txt)"}
         if per_kernel:
             pass_ms = sum(k["total_ms"] for k in per_kernel.values())
             dom = max((k for k in per_kernel.values() if k["bound"] == "mfma"), key=lambda k: k["total_ms"])
