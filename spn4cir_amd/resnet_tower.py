@@ -223,14 +223,14 @@ class ResNetTower:
             # itself stays fp32
             if not hasattr(self, "_proj_bf16"):
                 self._proj_bf16 = {n: w.to(torch.bfloat16).contiguous() for n, (w, _) in self.proj.items()}
-            tb = tok.to(torch.bfloat16)
+            tb = _ops.cast_bf16(tok)
             q = _ops.gemm_nt(tb.view(B, S, Cc)[:, 0].contiguous(), self._proj_bf16["q"], self.proj["q"][1], out_dtype=torch.float32)
             k = _ops.gemm_nt(tb, self._proj_bf16["k"], self.proj["k"][1], out_dtype=torch.float32)
             v = _ops.gemm_nt(tb, self._proj_bf16["v"], self.proj["v"][1], out_dtype=torch.float32)
             o = torch.empty(B, Cc, dtype=torch.float32, device=self.device)
             check(lib().spn_attnpool_attend_f32(_p(q), _p(k), _p(v), _p(o), B, S, Cc // 64, _stream()), "attnpool_attend")
             if self.embed_dim % 8 == 0:
-                return _ops.gemm_nt(o.to(torch.bfloat16), self._proj_bf16["c"], self.proj["c"][1], out_dtype=torch.float32)
+                return _ops.gemm_nt(_ops.cast_bf16(o), self._proj_bf16["c"], self.proj["c"][1], out_dtype=torch.float32)
             return self._gemm(o, self.proj["c"][0], self.proj["c"][1], B, self.embed_dim, Cc, Cc)
         q = self._gemm(tok, self.proj["q"][0], self.proj["q"][1], B, Cc, Cc, S * Cc)          # rows b*S: the pooled token
         k = self._gemm(tok, self.proj["k"][0], self.proj["k"][1], B * S, Cc, Cc, Cc)
