@@ -21,6 +21,12 @@ def test_tokenizer_matches_reference(golden_dir):
     t = tok("word " * 100, truncate=True)
     assert t[0, -1].item() == 49407 and (t[0] != 0).all()
     assert tok("a &amp;amp; b")[0, :5].tolist() == tok("a & b")[0, :5].tolist()      # double html unescape
+    # the whole-caption cache: a second call returns the same ids (and the truncated form keeps SOT + 75 tokens + EOT)
+    again = tok(captions)
+    assert np.array_equal(again.numpy(), z["ids"]) and np.array_equal(tok(captions).numpy(), z["ids"])
+    t2 = tok("word " * 100, truncate=True)
+    assert torch.equal(t, t2) and t2[0, 0].item() == 49406 and t2.shape == (1, 77)
+    assert len(tok._text_cache) >= len(set(captions))
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/clip4cir/clip/simple_tokenizer.py"), reason="reference absent")
