@@ -190,6 +190,14 @@ int spn_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float
 int spn_adamw_step_scaled(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int step, const float* grad_scale, const float* found_inf,
                           void* stream);
+/* the same with the STEP COUNT on the device as well: step_dev is a 1-element fp32 device counter advanced by
+ * spn_adamw_tick once per optimizer step (before the spn_adamw_step_dev launches of that step) unless *found_inf != 0,
+ * so a step GradScaler skips does not advance the bias correction - torch does not call optimizer.step() on overflow
+ * (torch/amp/grad_scaler.py: _maybe_opt_step), its fused path subtracts found_inf from the per-parameter step. */
+int spn_adamw_tick(float* step_dev, const float* found_inf, void* stream);
+int spn_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, const float* step_dev, const float* grad_scale, const float* found_inf,
+                       void* stream);
 int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream);
 
 /* ---------------------------------------------------------------- Recall@K (validate.py:28-33)

@@ -85,6 +85,8 @@ _SIGS = {
     "spn_bank_grad_q_tokmax": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_adamw_step": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "spn_adamw_step_scaled": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, vp, vp]),
+    "spn_adamw_tick": (i32, [vp, vp, vp]),
+    "spn_adamw_step_dev": (i32, [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, vp, vp, vp, vp]),
     "spn_grad_check_finite": (i32, [vp, sz, vp, vp]),
     "spn_cosine_scores_f64": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "spn_topk_from_scores": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),

@@ -242,6 +242,15 @@ int spn_adamw_step_scaled(float* p, const float* g, float* m, float* v, size_t n
     return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, 1.0f, found_inf, ST(stream), grad_scale);
 }
 
+int spn_adamw_tick(float* step_dev, const float* found_inf, void* stream) { return adamw_tick(step_dev, found_inf, ST(stream)); }
+
+int spn_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, const float* step_dev, const float* grad_scale, const float* found_inf,
+                       void* stream) {
+    if (!p || !g || !m || !v || !step_dev) return SPN_ERR_ARG;
+    return adamw_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, 0, 1.0f, found_inf, ST(stream), grad_scale, step_dev);
+}
+
 
 int spn_grad_check_finite(const float* g, size_t n, float* found_inf, void* stream) {
     if (!g || !found_inf) return SPN_ERR_ARG;

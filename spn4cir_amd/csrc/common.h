@@ -14,6 +14,17 @@
         if (e__ != hipSuccess) return (int)e__;              \
     } while (0)
 
+#include <stdlib.h>
+// integer tuning knob from the environment: values < 1 or unparsable text fall back to the default (a zero-block grid
+// would fail the launch or leave outputs unwritten)
+static inline int env_int_min1(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return (end == e || v < 1 || v > (1 << 24)) ? dflt : (int)v;
+}
+
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

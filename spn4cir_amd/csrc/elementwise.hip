@@ -592,9 +592,14 @@ int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float rsqrt_bc2, float inv_scale, const float* __restrict__ found_inf,
-                             const float* __restrict__ grad_scale) {
+                             const float* __restrict__ grad_scale, const float* __restrict__ step_dev) {
     if (found_inf && *found_inf != 0.f) return;
     if (grad_scale) inv_scale /= *grad_scale;            // GradScaler's scale, read on the device (no host sync)
+    if (step_dev) {                                      // step count kept on the device (adamw_tick): skipped steps do not count
+        const double t = (double)*step_dev;
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    }
     const size_t n4 = n >> 2;
     const float step_size = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -626,17 +631,33 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st, const float* grad_scale) {
+               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st, const float* grad_scale,
+               const float* step_dev) {
     if (n == 0) return SPN_OK;
-    if (step < 1) return SPN_ERR_ARG;
+    if (step < 1 && !step_dev) return SPN_ERR_ARG;
+    if (step < 1) step = 1;
     const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
     // ONE workgroup per CU: the kernel streams seven arrays (3.5 GB for ViT-L/14's 124 M parameters) and is bound by HBM page
     // locality, not by bytes in flight - 2 048 workgroups: 4.5-4.9 TB/s, 256: 5.4-5.7 (a grid that is not a multiple of the
     // CU count loses 20 %: every workgroup does the same share in one round).  SPN_ADAMW_CAP overrides the grid.
-    static const int cap = [] { const char* e = getenv("SPN_ADAMW_CAP"); return e ? atoi(e) : device_cu_count(); }();
+    static const int cap = env_int_min1("SPN_ADAMW_CAP", device_cu_count());
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256, cap)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd,
-                       (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf, grad_scale);
+                       (float)bc1, (float)(1.0 / sqrt(bc2)), inv_scale, found_inf, grad_scale, step_dev);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// *step_dev += 1 unless the step is skipped (GradScaler.step does not call optimizer.step() on overflow, so torch's
+// per-parameter `step` does not advance either).  Launched once per optimizer step, before the adamw_step launches.
+__global__ void adamw_tick_kernel(float* __restrict__ step_dev, const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.f) return;
+    *step_dev += 1.0f;
+}
+
+int adamw_tick(float* step_dev, const float* found_inf, hipStream_t st) {
+    if (!step_dev) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, step_dev, found_inf);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -302,7 +302,10 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     b += fa(TS * 2 * W * 2);                                     // dkv2
     b += fa((size_t)c.B * c.H * c.L * 4);                        // delta
     b += fa((size_t)c.B * c.Dp * 2) + fa((size_t)c.B * W * 4);   // dproj bf16, dh0
-    b += fusion_defer_layer_bytes(c) * c.layers;                 // per-layer dY operands of the deferred weight gradients
+    // per-layer dY operands of the deferred weight gradients; only when that path is on (SPN_TN_GROUP != 0 and few
+    // enough layers for the grouped launches - the same test as spn_fusion_bwd's)
+    const bool grouped = fusion_tn_group_on() && c.layers * 6 <= 2 * TN_GROUP_MAX && c.layers <= TN_GROUP_MAX;
+    b += fusion_defer_layer_bytes(c) * (grouped ? c.layers : 0);
     size_t op = 0;
     auto mx = [&](size_t v) { if (v > op) op = v; };
     mx(gemm_tn_workspace_bytes((int)T, (int)W, (int)I));
@@ -340,8 +343,8 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     float* dh0 = (float*)take((size_t)c.B * W * 4);
     char* defer_base = p;
     const size_t defer_stride = fusion_defer_layer_bytes(c);
-    p += defer_stride * c.layers;
     const bool grouped = fusion_tn_group_on() && c.layers * 6 <= 2 * TN_GROUP_MAX && c.layers <= TN_GROUP_MAX;
+    p += defer_stride * (grouped ? c.layers : 0);
     TnProblem qT[2 * TN_GROUP_MAX], qS[TN_GROUP_MAX];
     int nT = 0, nS = 0;
     const size_t lnp = fa(layernorm_bwd_workspace_bytes(T, W));

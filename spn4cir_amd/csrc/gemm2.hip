@@ -16,6 +16,14 @@
 #include "prof.h"
 #include "gemm3_nt_clobbers.inc"
 
+// in-kernel probes (clock / phase timers, bottleneck-elimination switches; several overwrite output bytes) exist only in
+// -DSPN_GEMM_PROBES experiment builds: in the shipped library the tests fold to constants and the code is gone
+#ifdef SPN_GEMM_PROBES
+#define SPN_DBG(ep_) ((ep_).dbg)
+#else
+#define SPN_DBG(ep_) 0
+#endif
+
 namespace spn {
 
 static constexpr int BK2 = 64;
@@ -219,7 +227,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
     if constexpr (MODE != GEMM_BANKSTATS && BM == 256 && BN == 256 && LDS_BYTES >= 131072) {
         // full tile with 16-byte aligned rows and one of the usual output combinations: the straight-line path
         const bool full = !ep.direct_store && m0 + BM <= M && n0 + BN <= N && ep.ldc % 8 == 0 &&
-                          (MODE != GEMM_RESID || ep.ldr % 4 == 0) && !(ep.dbg & 256);
+                          (MODE != GEMM_RESID || ep.ldr % 4 == 0) && !(SPN_DBG(ep) & 256);
         if (full) {
             const bool f32o = ep.out_f32 != nullptr, b16o = ep.out_bf16 != nullptr, aux = ep.aux_out != nullptr;
 #define SPN_EPI_FULL(F_, B_, A_) \
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // SPN_GEMM_DBG bit 64: phase times (shader cycles) of a mid-grid block - setup / prologue (first DMA + wait) /
     // k loop / epilogue - written over the first 16 bytes of the output
-    const uint64_t ph0 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t ph0 = (SPN_DBG(ep) & 64) ? __builtin_readcyclecounter() : 0;
     uint64_t ph2 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
@@ -510,8 +518,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 
     // SPN_GEMM_DBG bit 32: clock probe - shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) spent in
     // the main loop of the last tile, written over the first 8 bytes of the bf16 output
-    const uint64_t dbg_c0 = (ep.dbg & (32 | 64)) ? __builtin_readcyclecounter() : 0;
-    const uint64_t dbg_r0 = (ep.dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
+    const uint64_t dbg_c0 = (SPN_DBG(ep) & (32 | 64)) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_r0 = (SPN_DBG(ep) & 32) ? __builtin_amdgcn_s_memrealtime() : 0;
 
     const int nk = K / BKT;
     auto stage = [&](int kt, int buf) {
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         if (nk > 1) { chunk(0, 1); chunk(1, 1); }
         wait_first(nk > 1);
         __builtin_amdgcn_s_barrier();
-        if (ep.dbg & 64) ph2 = __builtin_readcyclecounter();
+        if (SPN_DBG(ep) & 64) ph2 = __builtin_readcyclecounter();
         if (wr == 1) SPN_SLOT_BAR(2);                  // stagger the lower half by one barrier (event)
         bf16x8 a[2][4], b0[4], b1[4];
         const int arow = wr * TM + (lane & 31), brow = wc * TN + (lane & 31), cl = lane >> 5;
@@ -604,12 +612,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
 #ifndef SPN_GEMM_LOOP_DBG
 #define SPN_GEMM_LOOP_DBG 0
 #endif
-        const bool dma = SPN_GEMM_LOOP_DBG ? !(ep.dbg & 2) : true;
+        const bool dma = SPN_GEMM_LOOP_DBG ? !(SPN_DBG(ep) & 2) : true;
         for (int kt = 0; kt < nk; ++kt) {
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sB = sA + A_BYTES;
             const bool n1 = kt + 1 < nk && dma, n2 = kt + 2 < nk && dma;
-            const bool rd = SPN_GEMM_LOOP_DBG ? (!(ep.dbg & 4) || kt == 0) : true;
+            const bool rd = SPN_GEMM_LOOP_DBG ? (!(SPN_DBG(ep) & 4) || kt == 0) : true;
             // slot 0
             if (rd) {
 #pragma unroll
@@ -663,16 +671,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         // SCHED 1: the DMA of tile kt+STAGES-1 is spread over the four k16 steps (after each step's LDS reads,
         // before its MFMAs) instead of being issued as one burst behind the barrier (SCHED 0), where both waves
         // of a SIMD would stall the matrix pipe together.
-        const bool do_stage = kt + STAGES - 1 < nk && !(ep.dbg & 2);
+        const bool do_stage = kt + STAGES - 1 < nk && !(SPN_DBG(ep) & 2);
         char* sF = smem + fill * STAGE;
-        const int kf = (ep.dbg & 1) ? 0 : (kt + STAGES - 1) * BKT;
+        const int kf = (SPN_DBG(ep) & 1) ? 0 : (kt + STAGES - 1) * BKT;
         const char* sA = smem + cur * STAGE;
         const char* sB = sA + A_BYTES;
         bf16x8 a[MI], b[NJ];
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int c = kk * 2 + (lane >> 5);
-            if (!(ep.dbg & 4) || kk == 0) {
+            if (!(SPN_DBG(ep) & 4) || kk == 0) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) a[i] = nt2_frag<BKT>(sA, wr * TM + i * 32 + (lane & 31), c);
 #pragma unroll
@@ -682,10 +690,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
                 if (do_stage) {
 #pragma unroll
                     for (int q = kk * ((GA + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GA + KSTEPS - 1) / KSTEPS) && q < GA; ++q)
-                        nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q, ep.dbg & 16);
+                        nt2_stage_one<GA, BKT>(rsA, sF, m0, lda, kf, wid, lane, q, SPN_DBG(ep) & 16);
 #pragma unroll
                     for (int q = kk * ((GB + KSTEPS - 1) / KSTEPS); q < (kk + 1) * ((GB + KSTEPS - 1) / KSTEPS) && q < GB; ++q)
-                        nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q, ep.dbg & 16);
+                        nt2_stage_one<GB, BKT>(rsB, sF + A_BYTES, n0, ldb, kf, wid, lane, q, SPN_DBG(ep) & 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else if (kk == 0 && do_stage) {
@@ -706,13 +714,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     // Stores straight from that layout touch 16 B per row per instruction, so the accumulators are
     // first staged through LDS (fp32, 16-B units XOR-swizzled by row) and the epilogue math + all
     // global traffic run row-major: one wave instruction = one or two whole rows, fully coalesced.
-    if ((ep.dbg & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
+    if ((SPN_DBG(ep) & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
         uint32_t* o = (uint32_t*)ep.out_bf16;
         o[0] = (uint32_t)(__builtin_readcyclecounter() - dbg_c0);
         o[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
         return;
     }
-    if (ep.dbg & 8) {
+    if (SPN_DBG(ep) & 8) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -723,9 +731,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         if (t == 12345.678f && ep.out_f32) ep.out_f32[0] = t;
         return;
     }
-    const uint64_t ph3 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t ph3 = (SPN_DBG(ep) & 64) ? __builtin_readcyclecounter() : 0;
     nt_epilogue<BM, BN, WM, WN, STAGES * STAGE, MODE, ACT>(acc, smem, M, N, m0, n0, wr, wc, wid, lane, ep);
-    if ((ep.dbg & 64) && blockIdx.x == gridDim.x / 2 && tid == 0) {
+    if ((SPN_DBG(ep) & 64) && blockIdx.x == gridDim.x / 2 && tid == 0) {
         const uint64_t ph4 = __builtin_readcyclecounter();
         uint32_t* o = ep.out_f32 ? (uint32_t*)ep.out_f32 : (uint32_t*)ep.out_bf16;
         o[0] = (uint32_t)(dbg_c0 - ph0);
@@ -895,7 +903,7 @@ template <int MODE, int ACT, int VAR>
 __global__ __launch_bounds__(256, 1) void gemm_nt3_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                           int M, int N, int K, int lda, int ldb, GemmEpilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint64_t dbg_t0 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_t0 = (SPN_DBG(ep) & 64) ? __builtin_readcyclecounter() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt3_kernel(const bf16_t* __restri
     const int nk = K / 64;
     const uint32_t lds_base = (uint32_t)(uintptr_t)LDS_PTR(smem);
     uint32_t cyc, ticks;
-    const uint64_t dbg_t1 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_t1 = (SPN_DBG(ep) & 64) ? __builtin_readcyclecounter() : 0;
 #define SPN_NT3_OPERANDS                                                                                              \
         : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),       \
           "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),       \
@@ -923,7 +931,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt3_kernel(const bf16_t* __restri
         asm volatile(
 #include "gemm3_nt_loop.inc"
             SPN_NT3_OPERANDS);
-    } else if constexpr (VAR == 1) {
+    }
+#ifdef SPN_NT3_ABL   // experiment builds only (tools/gen_gemm3.py --ablation, tools/build_variant.sh): results are wrong by design
+    else if constexpr (VAR == 1) {
         asm volatile(
 #include "gemm3_nt_loop_nodma.inc"
             SPN_NT3_OPERANDS);
@@ -940,19 +950,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt3_kernel(const bf16_t* __restri
 #include "gemm3_nt_loop_mfma.inc"
             SPN_NT3_OPERANDS);
     }
+#endif
 #undef SPN_NT3_OPERANDS
     // SPN_GEMM_DBG bit 32: clock probe of the k loop of the last tile (same convention as gemm_nt2_kernel)
-    if ((ep.dbg & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
+    if ((SPN_DBG(ep) & 32) && blockIdx.x == gridDim.x - 1 && tid == 0 && ep.out_bf16) {
         uint32_t* o = (uint32_t*)ep.out_bf16;
         o[0] = cyc;
         o[1] = ticks;
         return;
     }
-    const uint64_t dbg_t2 = (ep.dbg & 64) ? __builtin_readcyclecounter() : 0;
+    const uint64_t dbg_t2 = (SPN_DBG(ep) & 64) ? __builtin_readcyclecounter() : 0;
     nt3_epilogue<MODE, ACT>(acc, smem, m0, n0, wr, wc, wid, lane, ep);
     // SPN_GEMM_DBG bit 64: phase times of the first block (shader cycles): setup, asm statement (prologue DMA + k loop),
     // epilogue, and the k loop alone - written over the first 16 bytes of the fp32 / bf16 output
-    if ((ep.dbg & 64) && blockIdx.x == 0 && tid == 0) {
+    if ((SPN_DBG(ep) & 64) && blockIdx.x == 0 && tid == 0) {
         const uint64_t t3 = __builtin_readcyclecounter();
         uint32_t* o = ep.out_f32 ? (uint32_t*)ep.out_f32 : (uint32_t*)ep.out_bf16;
         o[0] = (uint32_t)(dbg_t1 - dbg_t0);
@@ -989,8 +1000,9 @@ static bool nt3_ok(int M, int N, int mode, const GemmEpilogue& ep) {
 static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
                         const GemmEpilogue& ep, hipStream_t st) {
 #define SPN_NT3(MODE_, ACT_) launch_nt3<MODE_, ACT_>(A, B, M, N, K, lda, ldb, ep, st)
-    // SPN_NT3_VAR (plain-store kernel only): ablation variants of the main loop, results are wrong by design -
-    // 1 no DMA, 2 no fragment reads, 3 no barrier, 4 MFMA only
+#ifdef SPN_NT3_ABL
+    // SPN_NT3_VAR (-DSPN_NT3_ABL experiment builds, plain-store kernel only): ablation variants of the main loop, results
+    // are wrong by design - 1 no DMA, 2 no fragment reads, 3 no barrier, 4 MFMA only.  Not in the shipped library.
     static const int var = [] {
         const char* e = getenv("SPN_NT3_VAR");
         return e ? atoi(e) : 0;
@@ -1003,6 +1015,7 @@ static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
             default: return launch_nt3<GEMM_STORE, ACT_NONE, 4>(A, B, M, N, K, lda, ldb, ep, st);
         }
     }
+#endif
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) return SPN_NT3(GEMM_STORE, ACT_NONE);
         if (ep.act == ACT_QUICKGELU) return SPN_NT3(GEMM_STORE, ACT_QUICKGELU);
@@ -1095,10 +1108,16 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
         const char* e = getenv("SPN_GEMM_EPI_DIRECT");
         return (e && e[0] == '1') ? 1 : 0;
     }();
+    // SPN_GEMM_DBG: in-kernel probes / bottleneck-elimination switches (some overwrite the first bytes of the output):
+    // compiled only into -DSPN_GEMM_PROBES experiment builds (tools/build_variant.sh), never into the shipped library
+#ifdef SPN_GEMM_PROBES
     static const int dbg = [] {
         const char* e = getenv("SPN_GEMM_DBG");
         return e ? atoi(e) : 0;
     }();
+#else
+    constexpr int dbg = 0;
+#endif
     GemmEpilogue e2 = ep;
     e2.direct_store = direct;
     e2.dbg = dbg;

@@ -118,7 +118,9 @@ int gather_rows_abs(const float* x, const int32_t* rows, float* out, int B, int 
 int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_row, float* dx, bf16_t* dx_bf16, int T,
                      int W, hipStream_t st);
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
-               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st, const float* grad_scale = nullptr);
+               float wd, int step, float inv_scale, const float* found_inf, hipStream_t st, const float* grad_scale = nullptr,
+               const float* step_dev = nullptr);
+int adamw_tick(float* step_dev, const float* found_inf, hipStream_t st);
 int grad_unscale_check(float* g, size_t n, float inv_scale, float* found_inf, hipStream_t st);
 
 // norm.hip

@@ -82,7 +82,7 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
                   float* rstd, int rows, int W, float eps, hipStream_t st) {
     if (rows <= 0) return SPN_ERR_ARG;
     if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
-    static const int cap = [] { const char* e = getenv("SPN_LNF_BLOCKS"); return e ? atoi(e) : 768; }();
+    static const int cap = env_int_min1("SPN_LNF_BLOCKS", 768);
     const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
 #define SPN_LN_FWD(V_)                                                                                          \
     do {                                                                                                        \
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
 
 static int lnb_blocks(int rows) {
     int b = (rows + 3) / 4;
-    static const int cap = [] { const char* e = getenv("SPN_LNB_BLOCKS"); return e ? atoi(e) : device_cu_count(); }();
+    static const int cap = env_int_min1("SPN_LNB_BLOCKS", device_cu_count());
     return b > cap ? cap : b;
 }
 

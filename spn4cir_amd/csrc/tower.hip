@@ -458,7 +458,10 @@ size_t text_ws_bytes(const TextCfg& c) {
     b += align256((size_t)c.B * c.D * 2);    // dfeats bf16
     b += align256((size_t)c.B * c.W * 4);    // dln_e
     b += align256((size_t)c.B * c.W * 4);    // de
-    b += text_defer_layer_bytes(bc) * c.layers;   // per-layer dY operands of the deferred weight gradients
+    // per-layer dY operands of the deferred weight gradients (9 T W bf16 + LayerNorm partials per block: 3.3 GB for
+    // ViT-L/14 text at B = 256, linear in the batch); absent when the deferred path is switched off (SPN_TN_GROUP=0:
+    // spn_text_bwd_layer_deferred / spn_text_bwd_wgrad then return SPN_ERR_WORKSPACE, spn_text_bwd_layer needs none)
+    b += text_defer_layer_bytes(bc) * (tn_group_on() ? c.layers : 0);
     size_t op = block_op_ws_bytes(bc);
     const size_t tp = align256(gemm_tn_workspace_bytes(c.B, c.W, c.D));
     if (tp > op) op = tp;
@@ -584,7 +587,8 @@ static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w
     w->dln = (float*)take((size_t)c.B * c.W * 4);
     w->de = (float*)take((size_t)c.B * c.W * 4);
     w->defer_stride = text_defer_layer_bytes(bc);
-    w->defer = p; p += w->defer_stride * c.layers;
+    w->defer = tn_group_on() ? p : nullptr;
+    p += w->defer_stride * (tn_group_on() ? c.layers : 0);
     w->opws = (float*)p;
     w->opws_bytes = ws_bytes - (size_t)(p - ws);
     return SPN_OK;
@@ -654,6 +658,7 @@ int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t*
     if (l < 0 || l >= c.layers) return SPN_ERR_ARG;
     TextBwdWs w;
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    if (!w.defer) return SPN_ERR_WORKSPACE;          // SPN_TN_GROUP=0: the workspace holds no deferred buffers
     TextLayout t;
     text_layout(c, &t);
     BlockCfg bc = text_block_cfg(c);
@@ -678,6 +683,7 @@ int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int 
     if (l_begin < 0 || l_end > c.layers || l_begin >= l_end || (l_end - l_begin) * 4 > TN_GROUP_MAX) return SPN_ERR_ARG;
     TextBwdWs w;
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
+    if (!w.defer) return SPN_ERR_WORKSPACE;
     TextLayout t;
     text_layout(c, &t);
     BlockCfg bc = text_block_cfg(c);

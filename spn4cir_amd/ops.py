@@ -376,6 +376,17 @@ def adamw_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=
                                inv_scale, _p(found_inf), _stream()), "adamw_step")
 
 
+def adamw_tick(step_dev, found_inf=None):
+    """step_dev (1-element fp32 device counter) += 1 unless *found_inf != 0; call once per optimizer step."""
+    check(lib().spn_adamw_tick(_p(step_dev), _p(found_inf), _stream()), "adamw_tick")
+
+
+def adamw_step_dev(p, g, m, v, step_dev, lr, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, grad_scale=None, found_inf=None):
+    """adamw_step with the bias-correction step read from the device counter (skipped steps do not count)."""
+    check(lib().spn_adamw_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                   _p(step_dev), _p(grad_scale), _p(found_inf), _stream()), "adamw_step_dev")
+
+
 def grad_check_finite(g, found_inf):
     check(lib().spn_grad_check_finite(_p(g), g.numel(), _p(found_inf), _stream()), "grad_check_finite")
 

@@ -5,7 +5,10 @@
 The models' nn.Parameters are slices of ONE flat fp32 buffer per tower and their `.grad`s are slices of one flat gradient
 buffer (gradsink.py), so the whole update is a single launch of the fused AdamW kernel (spn_adamw_step_scaled, the kernel
 Stage2Trainer uses) instead of torch's ~10 multi-tensor passes (2.9 ms -> 0.6 ms per step for ViT-L/14's text tower).
-Same arithmetic as torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the square root).
+Same arithmetic as torch.optim.AdamW (decoupled weight decay, bias correction, eps outside the square root).  The step
+count that enters the bias correction lives on the DEVICE (one fp32 counter shared by every parameter's state["step"],
+advanced by spn_adamw_tick only when found_inf == 0): a step GradScaler skips on overflow does not advance it, exactly as
+torch - which does not call optimizer.step() on such a step - leaves its per-parameter counters alone.
 
 torch.amp.GradScaler: the class declares `_step_supports_amp_scaling`, so `scaler.step(optimizer)` hands over
 `optimizer.grad_scale` / `optimizer.found_inf` (device tensors) and the kernel unscales the gradients and skips the step on
@@ -35,11 +38,13 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._on_step = on_step             # e.g. model.parameters_changed (the models also notice the update themselves)
         self._runs = None                   # per group: [dict(params, p_flat, m, v, numel)]
-        self._steps = 0
+        self._step_dev = None               # 0-dim fp32 device counter of APPLIED steps (shared by every state["step"])
 
     # -------------------------------------------------------------------------------- layout
     def _build_runs(self):
         self._runs = []
+        dev = next(p.device for g in self.param_groups for p in g["params"])
+        self._step_dev = torch.zeros((), dtype=torch.float32, device=dev)
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             for p in ps:
@@ -65,7 +70,7 @@ class AdamW(torch.optim.Optimizer):
                 off = 0
                 for p in r:                                  # torch-compatible per-parameter state (views of the run's state)
                     st = self.state[p]
-                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["step"] = self._step_dev
                     st["exp_avg"] = m[off:off + p.numel()].view_as(p)
                     st["exp_avg_sq"] = v[off:off + p.numel()].view_as(p)
                     off += p.numel()
@@ -77,16 +82,15 @@ class AdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         loaded = {p: dict(st) for p, st in self.state.items()}
         self._build_runs()                                   # fresh flat state, self.state[p] re-pointed at its views
-        steps = 0
+        steps = 0.0
         for p, old in loaded.items():
             st = self.state[p]
             if "exp_avg" in old:
                 st["exp_avg"].copy_(old["exp_avg"].to(st["exp_avg"].device, torch.float32).view_as(st["exp_avg"]))
                 st["exp_avg_sq"].copy_(old["exp_avg_sq"].to(st["exp_avg_sq"].device, torch.float32).view_as(st["exp_avg_sq"]))
             if "step" in old:
-                st["step"] = torch.as_tensor(float(old["step"]), dtype=torch.float32)
-                steps = max(steps, int(float(old["step"])))
-        self._steps = steps
+                steps = max(steps, float(old["step"]))
+        self._step_dev.fill_(steps)
 
     @staticmethod
     def _grads_flat(run):
@@ -106,9 +110,9 @@ class AdamW(torch.optim.Optimizer):
     # -------------------------------------------------------------------------------- step
     def _launch(self, p, g, m, v, group, scale, found):
         b1, b2 = group["betas"]
-        check(lib().spn_adamw_step_scaled(_p(p), _p(g), _p(m), _p(v), p.numel(), float(group["lr"]), float(b1), float(b2),
-                                          float(group["eps"]), float(group["weight_decay"]), self._steps, _p(scale),
-                                          _p(found), _stream()), "adamw_step_scaled")
+        check(lib().spn_adamw_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), float(group["lr"]), float(b1), float(b2),
+                                       float(group["eps"]), float(group["weight_decay"]), _p(self._step_dev), _p(scale),
+                                       _p(found), _stream()), "adamw_step_dev")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -123,7 +127,7 @@ class AdamW(torch.optim.Optimizer):
         for t in (scale, found):
             if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != 1):
                 raise TypeError("grad_scale / found_inf must be 1-element fp32 CUDA tensors")
-        self._steps += 1
+        check(lib().spn_adamw_tick(_p(self._step_dev), _p(found), _stream()), "adamw_tick")
         for group, runs in zip(self.param_groups, self._runs):
             for run in runs:
                 if all(p.grad is None for p in run["params"]):
@@ -141,8 +145,7 @@ class AdamW(torch.optim.Optimizer):
                                          scale, found)
                         off += n
                 run["params"][0].view(-1)[:0].zero_()       # bump the buffer's version counter: the models re-derive
-                for p in run["params"]:                      # their bf16 operands when it has moved
-                    self.state[p]["step"] += 1
+                                                             # their bf16 operands when it has moved
         if self._on_step is not None:
             self._on_step()
         return loss

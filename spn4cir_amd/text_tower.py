@@ -7,6 +7,7 @@ state-dict keys.  bf16 mirrors (+ transposes) of the GEMM weights are refreshed 
 optimizer step.  Forward/backward are single C-ABI calls that enqueue the whole launch chain.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -237,6 +238,8 @@ class TextTower:
         check(lib().spn_text_bwd_head(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats),
                                       _p(self.grads), ws, n, _stream()), "text_bwd_head")
         on_span_ready(*spans[0])
+        if os.environ.get("SPN_TN_GROUP", "1")[:1] == "0":
+            wgrad_groups = None                     # the library's workspace then holds no deferred buffers
         if wgrad_groups is None:
             for i, l in enumerate(reversed(range(self.layers))):
                 check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),

@@ -74,10 +74,10 @@ class ClipTokenizer:
     def encode(self, text):
         hit = self._text_cache.get(text)
         if hit is not None:
-            return hit
+            return list(hit)                # a fresh list per call: callers may mutate the result
         out = self._encode(text)
         if len(self._text_cache) < self._text_cache_max:
-            self._text_cache[text] = out
+            self._text_cache[text] = tuple(out)
         return out
 
     def _encode(self, text):

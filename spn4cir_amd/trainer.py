@@ -53,6 +53,7 @@ class Stage2Trainer:
         self.step_count = 0
         self.check_finite = check_finite
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.tower.device)
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.tower.device)   # applied steps (check_finite mode)
         self.reducer = GradBucketReducer(self.tower.grads, group)
         self._bank = None
         self._m_begin, self._M_total = 0, 0
@@ -122,8 +123,13 @@ class Stage2Trainer:
             for w in pending:
                 w.wait()
             upd(lo, hi)
+        elif found is not None:
+            # a skipped step must not advance the bias correction (GradScaler.step semantics): the count lives on the device
+            ops.adamw_tick(self.step_dev, found)
+            ops.adamw_step_dev(t.params, t.grads, self.m, self.v, self.step_dev, self.lr, self.betas, self.eps, self.wd,
+                               None, found)
         else:
             ops.adamw_step(t.params, t.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd,
-                           1.0, found)
+                           1.0, None)
         t.refresh()
         return ctx["loss"]

@@ -608,8 +608,10 @@ def test_external_optimizer_step_is_noticed_without_parameters_changed(golden_di
 def test_fused_adamw_arithmetic_matches_torch():
     """spn4cir_amd.optim.AdamW against torch.optim.AdamW on identical gradients: parameters that are consecutive slices of
     one flat buffer with gradients that are the matching slices of another (one fused launch), the same parameters in two
-    groups with broken runs (more launches), and gradients that live elsewhere (per-tensor path) - three steps each,
-    with the GradScaler hand-over (optimizer.grad_scale / found_inf) on the second step and an overflow on the third."""
+    groups with broken runs (more launches), and gradients that live elsewhere (per-tensor path) - four steps each,
+    with the GradScaler hand-over (optimizer.grad_scale / found_inf) from the second step on and an overflow on the SECOND
+    step, followed by normal steps: a skipped step must not advance the bias correction (torch does not call
+    optimizer.step() on overflow)."""
     _need_gpu()
     from spn4cir_amd import optim as spn_optim
     hp = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01)
@@ -617,7 +619,8 @@ def test_fused_adamw_arithmetic_matches_torch():
     n = sum(int(np.prod(sh)) for sh in shapes)
     g = torch.Generator().manual_seed(3)
     p0 = torch.randn(n, generator=g)
-    grads = [torch.randn(n, generator=g) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=g)) for _ in range(3)]
+    grads = [torch.randn(n, generator=g) * 10.0 ** float(torch.randint(-6, 2, (1,), generator=g)) for _ in range(4)]
+    overflow_at = 1
 
     def build(kind):
         flat, gflat = p0.clone().cuda(), torch.zeros(n, device="cuda")
@@ -643,12 +646,12 @@ def test_fused_adamw_arithmetic_matches_torch():
         flat, gflat, ps, opt = build(kind)
         for it, gr in enumerate(grads):
             scale = torch.tensor([1.0 if it == 0 else 512.0], device="cuda")
-            found = torch.tensor([1.0 if it == 2 else 0.0], device="cuda")
+            found = torch.tensor([1.0 if it == overflow_at else 0.0], device="cuda")
             gflat.copy_(gr.cuda() * scale)
             for p, gv in ps:
                 p.grad = gv.clone() if kind == "elsewhere" else gv
             if kind == "torch":
-                if it == 2:
+                if it == overflow_at:
                     continue                                 # overflow: GradScaler skips the step
                 for p, _ in ps:
                     p.grad = p.grad / scale
@@ -658,6 +661,8 @@ def test_fused_adamw_arithmetic_matches_torch():
                 opt.step()
                 del opt.grad_scale, opt.found_inf
         out[kind] = flat.clone()
+        if kind != "torch":
+            assert float(opt.state[ps[0][0]]["step"]) == 3.0    # applied steps only, as torch counts them
         if kind == "fused":
             assert len(opt._runs[0]) == 1                    # one flat run -> one launch per step
             assert flat._version > 0                         # the buffer's version counter moved (staleness detection)

@@ -27,6 +27,9 @@ def test_tokenizer_matches_reference(golden_dir):
     t2 = tok("word " * 100, truncate=True)
     assert torch.equal(t, t2) and t2[0, 0].item() == 49406 and t2.shape == (1, 77)
     assert len(tok._text_cache) >= len(set(captions))
+    e = tok.encode("is red and has long sleeves")
+    e.append(1)                                                    # a caller mutating its result must not poison the cache
+    assert tok.encode("is red and has long sleeves") == e[:-1]
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/clip4cir/clip/simple_tokenizer.py"), reason="reference absent")

@@ -1,4 +1,6 @@
-"""Bottleneck elimination on the NT GEMM: time shapes under SPN_GEMM_DBG bit masks (results are wrong by design)."""
+"""Bottleneck elimination on the NT GEMM: time shapes under SPN_GEMM_DBG bit masks (results are wrong by design).
+Needs a probe build: tools/build_variant.sh probes "-DSPN_GEMM_PROBES -DSPN_GEMM_LOOP_DBG=1" and
+SPN_LIB_PATH=spn4cir_amd/libspn4cir_hip_probes.so (the shipped library compiles the probes out)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(19712, 3072, 768), (19712, 768, 3072), (19712, 768, 768), (8192, 8192, 8192)]

@@ -282,8 +282,15 @@ VARIANTS = {           # name -> OPT overrides; "" is the shipped loop
 
 
 if __name__ == "__main__":
-    base = sys.argv[1] if len(sys.argv) > 1 else "spn4cir_amd/csrc/gemm3_nt"
+    # default: only the production loop (the one the shipped library compiles).  --ablation also writes the four
+    # ablation loops (results wrong by design), used only by -DSPN_NT3_ABL experiment builds (tools/build_variant.sh);
+    # they are generated files and are not kept in the repository.
+    args = [a for a in sys.argv[1:] if a != "--ablation"]
+    ablation = "--ablation" in sys.argv[1:]
+    base = args[0] if args else "spn4cir_amd/csrc/gemm3_nt"
     for name, over in VARIANTS.items():
+        if name and not ablation:
+            continue
         OPT.update(dict(dma=True, read=True, barrier=True))
         OPT.update(over)
         text = generate()
