@@ -252,3 +252,25 @@ def test_query_split_e4m3_model():
     assert torch.equal(bank_loss.split_query_e4m3(z), z)
     exact = torch.tensor([[448.0, -224.0, 1.0, 0.5, 0.0, 28.0, -0.015625, 2.0]])      # e4m3 values at scale 1
     assert torch.equal(bank_loss.split_query_e4m3(exact), exact)
+
+
+def test_blip_vit_oracle_matches_reference(golden_dir):
+    """oracle.blip_vit vs vectors captured from blip4cir/vit.py's own Block / Attention / VisionTransformer.forward
+    (tests/golden/make_golden_blipvit.py): block outputs, the attention branch alone, the tower's token sequence and the
+    pooled feature."""
+    import os
+    from oracle import blip_vit
+    z = np.load(os.path.join(golden_dir, "blip_vit.npz"))
+    for tag in ("blkA", "blkB"):
+        sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + ".sd.")}
+        x, heads = torch.from_numpy(z[tag + ".x"]), int(z[tag + ".heads"])
+        W = x.shape[-1]
+        y = blip_vit.block(sd, "", x, heads)
+        assert (y - torch.from_numpy(z[tag + ".y"])).abs().max() < 2e-5, tag
+        h = torch.nn.functional.layer_norm(x, (W,), sd["norm1.weight"], sd["norm1.bias"], 1e-6)
+        a = blip_vit.attention(sd, "", h, heads)
+        assert (a - torch.from_numpy(z[tag + ".attn_out"])).abs().max() < 2e-5, tag
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")}
+    tokens, pooled = blip_vit.img_embed(sd, torch.from_numpy(z["image"]), int(z["heads"]))
+    assert (tokens - torch.from_numpy(z["tokens"])).abs().max() < 2e-5
+    assert (pooled - torch.from_numpy(z["pooled"])).abs().max() < 2e-6
