@@ -95,8 +95,9 @@ def tokmax_infonce(fusion_feats, target_feats, target_indexs, temp):
     """blip24cir/lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py:253-265 (forward_stage2, loss_qtc):
     per sample i, sim[m, k] = <fusion_feats[i], target_feats[m, k, :]> over the 32 Q-Former tokens of every bank
     target, logit[m] = max_k sim[m, k] / temp, cross entropy against target_indexs[i]; mean over the batch.
-    PARITY UNPINNED: LAVIS is not importable offline (omegaconf / timm / fairscale absent), so this follows the
-    source by reading; tests cross-check the per-sample loop below against a batched formulation."""
+    PINNED: tests/golden/make_golden_blip2.py runs the reference's own forward_stage2 (module loaded with import-only
+    stand-ins for its LAVIS imports, the Q-Former output as a fixed input) and tests/test_oracle_golden.py checks this
+    function against the captured loss and gradients (tests/golden/blip2_stage2.npz)."""
     bs = target_indexs.shape[0]
     loss = torch.zeros((), dtype=fusion_feats.dtype)
     for i in range(bs):

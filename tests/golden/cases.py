@@ -101,3 +101,20 @@ class StubFusion:
         out = self.q[self.pos:self.pos + n].to(ref_token.device) + 0.05 * ref_token.mean(dim=1)
         self.pos += n
         return out
+
+
+# ----------------------------------------------------------------------------- BLIP-2 stage-2 loss (blip2_stage2.npz)
+BLIP2_CASES = {"small": dict(B=6, M=37, H=96, D=256, L=8, seed=0, ties=True),
+               "m1000": dict(B=16, M=1000, H=96, D=256, L=8, seed=1, ties=False)}
+
+
+def blip2_target_feats(tag):
+    """The static token bank [M, 32, D] of a case (too big to store for M = 1000): its own seeded generator; `ties` plants
+    equal token rows inside two targets (several arg-max rows: torch.max takes the first)."""
+    c = BLIP2_CASES[tag]
+    g = torch.Generator().manual_seed(1000 + c["seed"])
+    t = torch.nn.functional.normalize(torch.randn(c["M"], 32, c["D"], generator=g), dim=-1)
+    if c["ties"]:
+        t[3, 5] = t[3, 17]
+        t[7, :] = t[7, 0]
+    return t

@@ -274,3 +274,22 @@ def test_blip_vit_oracle_matches_reference(golden_dir):
     tokens, pooled = blip_vit.img_embed(sd, torch.from_numpy(z["image"]), int(z["heads"]))
     assert (tokens - torch.from_numpy(z["tokens"])).abs().max() < 2e-5
     assert (pooled - torch.from_numpy(z["pooled"])).abs().max() < 2e-6
+
+
+def test_tokmax_oracle_matches_reference(golden_dir):
+    """oracle.bank_loss.tokmax_infonce vs the reference's forward_stage2 (blip2_qformer_cir_align_prompt.py:247-268,
+    captured by tests/golden/make_golden_blip2.py): loss, d loss / d fusion_feats, d loss / d temp - including the case
+    with tied token rows inside a target."""
+    import os
+    from cases import BLIP2_CASES, blip2_target_feats
+    from oracle import bank_loss
+    z = np.load(os.path.join(golden_dir, "blip2_stage2.npz"))
+    for tag in BLIP2_CASES:
+        feats = torch.from_numpy(z[f"{tag}.fusion_feats"]).clone().requires_grad_(True)
+        temp = torch.tensor(float(z[f"{tag}.temp"]), requires_grad=True)
+        loss = bank_loss.tokmax_infonce(feats, blip2_target_feats(tag), torch.from_numpy(z[f"{tag}.target_indexs"]), temp)
+        loss.backward()
+        assert abs(loss.item() - float(z[f"{tag}.loss_qtc"])) < 2e-5 * max(1.0, abs(loss.item())), tag
+        ref = torch.from_numpy(z[f"{tag}.d_fusion_feats"])
+        assert (feats.grad - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item()), tag
+        assert abs(temp.grad.item() - float(z[f"{tag}.d_temp"])) < 1e-4 * max(1.0, abs(float(z[f"{tag}.d_temp"]))), tag
