@@ -65,6 +65,11 @@ def parse():
     p.add_argument("--kernel-pass-steps", type=int, default=3,
                    help="extra steps AFTER the timed region with every kernel class timed, for the kernels[] breakdown")
     p.add_argument("--no-packed", action="store_true", help="skip the extra (not headline) packed-EOT measurement")
+    p.add_argument("--no-recall", action="store_true", help="skip the Recall@10 / top-K identity block")
+    p.add_argument("--recall-queries", type=int, default=256,
+                   help="queries of the synthetic retrieval check (SURVEY 8d names 2 000; the CPU oracle encodes every one "
+                        "of them in fp32, ~0.05 s each on 32 threads, so the default is a bounded sample)")
+    p.add_argument("--recall-gallery", type=int, default=6000)
     p.add_argument("--cpu-batch", type=int, default=16)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--cpu-threads", type=int, default=32)
@@ -120,6 +125,86 @@ def cpu_baseline(args, sd, target, refer):
                       f"D={target.shape[1]}, fp32, torch CPU kernels, {threads} threads of {avail} available cores), "
                       f"after 1 warm-up step",
             "ms_per_step": round(dt * 1e3, 1)}
+
+
+def recall_block(args, sd, model, dev):
+    """BASELINE's metric is "triplets/sec + Recall@10": the validate.py:19-51 surface on a synthetic FashionIQ-shaped
+    retrieval task (6 000 x 768 gallery), scored against the CPU oracle (oracle/clip_text.py fp32 tower +
+    oracle/recall.py fp64 ranking).  Gallery = seeded random unit rows; a query = normalize(gallery[ref] + text(caption))
+    (validate.py:84-95); each query's target row is PLANTED at normalize(q_oracle + 0.222 * noise), i.e. at the cosine
+    (~0.16) of the best random rows, so that Recall@10 is neither 0 nor 1 and moves with the feature error.  Reported
+    for the validation default (fp32-exact tower) and for the bf16 training tower: Recall@10/50 of the HIP path and of the
+    oracle, and the fraction of queries whose top-10 / top-50 index SETS (reference row removed, validate.py:39) are
+    identical to the oracle's (north_star: identical top-K index sets)."""
+    import numpy as np
+    from oracle import clip_text, recall
+    from spn4cir_amd import ops, synthetic
+    nq, ng = args.recall_queries, args.recall_gallery
+    D = model.tower.embed_dim
+    if nq <= 0 or nq > ng // 2:
+        return None
+    g = torch.Generator().manual_seed(12)
+    gallery = torch.nn.functional.normalize(torch.randn(ng, D, generator=g))
+    ref_idx = torch.randint(0, ng // 2, (nq,), generator=g)
+    tgt_idx = ng // 2 + torch.randperm(ng - ng // 2, generator=g)[:nq]
+    ids = synthetic.token_ids(nq, seed=11)
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads)))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        t_cpu = torch.cat([clip_text.encode_text(sd, ids[i:i + 64]) for i in range(0, nq, 64)])
+    cpu_s = time.perf_counter() - t0
+    q_cpu = torch.nn.functional.normalize(gallery[ref_idx] + t_cpu)
+    gallery[tgt_idx] = torch.nn.functional.normalize(q_cpu + 0.222 * torch.randn(nq, D, generator=g))
+    order, _ = recall.ranked_indices(q_cpu.numpy(), gallery.numpy())
+    ref_np, tgt_np = ref_idx.numpy(), tgt_idx.numpy()
+
+    def top_sets(order_rows):                         # drop the reference row, keep the first 50 (validate.py:39-45)
+        out = []
+        for i in range(nq):
+            row = order_rows[i]
+            out.append(row[row != ref_np[i]][:50])
+        return np.stack(out)
+
+    top_cpu = top_sets(order[:, :52])
+    gal_d, ref_d = gallery.to(dev), ref_idx.to(dev)
+    excl = ref_idx.to(dev, torch.int32)
+
+    def gpu_top(text_feats):
+        q, _, _ = ops.combine_l2norm_fwd(gal_d, ref_d, text_feats.float().contiguous())
+        gn, _, _ = ops.combine_l2norm_fwd(None, None, gal_d)
+        idx, _ = ops.topk_from_scores(ops.cosine_scores_f64(q, gn), 50, exclude=excl)
+        return idx.cpu().numpy()
+
+    def report(top):
+        r = {}
+        for K in (10, 50):
+            r[f"recall_at_{K}"] = round(float((top[:, :K] == tgt_np[:, None]).any(1).mean() * 100), 3)
+            r[f"topk_identical_frac_{K}"] = round(float(np.mean([set(top[i, :K]) == set(top_cpu[i, :K]) for i in range(nq)])), 5)
+        return r
+
+    ids_d = ids.to(dev)
+    model.tower.load_clip_state_dict(sd)              # the timed steps moved the weights: back to the oracle's
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        t_exact = torch.cat([model.tower.forward_exact(ids_d[i:i + 256].contiguous()) for i in range(0, nq, 256)])
+        torch.cuda.synchronize()
+        exact_s = time.perf_counter() - t0
+        t_bf16 = torch.cat([model.tower.forward(ids_d[i:i + 256].contiguous()).clone() for i in range(0, nq, 256)])
+    ex, bf = report(gpu_top(t_exact)), report(gpu_top(t_bf16))
+    cpu = report(top_cpu)
+    cos = torch.nn.functional.cosine_similarity(t_exact.cpu().double(), t_cpu.double(), dim=-1)
+    cosb = torch.nn.functional.cosine_similarity(t_bf16.cpu().double(), t_cpu.double(), dim=-1)
+    return {"recall_at_10": ex["recall_at_10"], "recall_at_50": ex["recall_at_50"],
+            "recall_at_10_oracle": cpu["recall_at_10"], "recall_at_50_oracle": cpu["recall_at_50"],
+            "topk_identical_frac": {"10": ex["topk_identical_frac_10"], "50": ex["topk_identical_frac_50"]},
+            "tower": "fp32-exact (the default of the validate.py surface)",
+            "text_feature_max_1_minus_cos": float((1 - cos).max()),
+            "bf16_training_tower": {"recall_at_10": bf["recall_at_10"], "recall_at_50": bf["recall_at_50"],
+                                    "topk_identical_frac": {"10": bf["topk_identical_frac_10"], "50": bf["topk_identical_frac_50"]},
+                                    "text_feature_max_1_minus_cos": float((1 - cosb).max())},
+            "queries": nq, "gallery_rows": ng, "embed_dim": D,
+            "sample": f"{nq} of SURVEY 8d's 2 000 queries (--recall-queries); oracle encode {cpu_s:.1f} s on the host cores, "
+                      f"exact tower {exact_s * 1e3:.0f} ms on the GPU"}
 
 
 def main():
@@ -301,6 +386,12 @@ def main():
         out.update(extra)
         if packed:
             out["packed_eot"] = packed
+        if not args.no_recall:
+            rec = recall_block(args, sd, model, dev)
+            if rec:
+                out["recall_at_10"] = rec["recall_at_10"]
+                out["topk_identical_frac"] = rec["topk_identical_frac"]
+                out["recall"] = rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
     if world > 1 or force_dp:

@@ -126,6 +126,10 @@ int spn_combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int6
                            float* q_f32, void* q_bf16, float* inv_norm, int B, int D, int ldq, void* stream);
 int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const float* dq, float* dtext, int B, int D,
                            void* stream);
+/* the same with every output multiplied by *scale_dev (1-element device fp32): the d(loss) that autograd hands
+ * `loss.backward()` / GradScaler's scaled loss (train_negplus.py:121) enters here without a host synchronisation */
+int spn_combine_l2norm_bwd_scaled(const float* q_f32, const float* inv_norm, const float* dq, const float* scale_dev,
+                                  float* dtext, int B, int D, void* stream);
 
 /* ---------------------------------------------------------------- bank InfoNCE
  * models_negplus.py:150-154: logits = (q @ bank.T)/tau ; CrossEntropyLoss(logits, labels).

@@ -76,6 +76,7 @@ _SIGS = {
     "spn_embed_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "spn_combine_l2norm_fwd": (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_combine_l2norm_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp]),
+    "spn_combine_l2norm_bwd_scaled": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "spn_bank_stats_fwd": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "spn_bank_loss_finalize": (i32, [vp, i32, i32, i64, f32, vp, vp, vp, vp]),
     "spn_bank_grad_q": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),

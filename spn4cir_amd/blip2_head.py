@@ -55,9 +55,9 @@ class _TokMaxLoss(torch.autograd.Function):
         st = ctx.st
         M = st["bank"].shape[0]
         parts = _shards(st["bank"], lambda sh, t0: ops.bank_grad_q_tokmax(st["qb"], sh, st["labels"], 1.0 / st["tau"], st["lse"],
-                                                                           float(grad_out) / st["B"], targets_total=M, t_begin=t0))
+                                                                           1.0 / st["B"], targets_total=M, t_begin=t0))
         dq = parts[0] if len(parts) == 1 else torch.stack(parts).sum(0)
-        dq = dq[:, :st["D"]].contiguous()
+        dq = dq[:, :st["D"]] * grad_out                      # the incoming d(loss) stays on the device (no host sync)
         # logits = s / temp  =>  dL/dtemp = -(1/temp) * sum_b <q_b, dL/dq_b>   (the max picks rows, it has no scale)
         dtemp = (-(st["q"] * dq).sum() / st["tau"]).reshape(()) if st["temp_is_tensor"] else None
         return dq, dtemp, None, None

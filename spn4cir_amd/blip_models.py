@@ -36,11 +36,13 @@ class _FusionBankStep(torch.autograd.Function):
         m, st = ctx.model, ctx.st
         enc = m.fusion
         bank = m._target_bank_dev
-        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], float(grad_out) / st["B"],
+        # the incoming d(loss) scales the (linear) backward on the device: no host synchronisation on it
+        scale = grad_out.detach().to(torch.float32).reshape(1)
+        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], 1.0 / st["B"],
                              M_total=bank.shape[0])[:, :enc.Dp].contiguous()
-        dtau = (-(st["q"] * dq).sum() / st["tau"]).reshape(())            # models.py:29: tau is an nn.Parameter
+        dtau = (-(st["q"] * dq).sum() / st["tau"] * scale[0]).reshape(())   # models.py:29: tau is an nn.Parameter
         snap = gradsink.snapshot(m._params, enc.grads, enc.named_views)
-        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq))
+        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq, scale=scale))
         gradsink.publish(m._params, flat, enc.named_views, snap)
         return torch.zeros((), device=grad_out.device), dtau, None, None, None, None, None
 

@@ -158,6 +158,12 @@ int spn_combine_l2norm_bwd(const float* q_f32, const float* inv_norm, const floa
     return combine_l2norm_bwd(q_f32, inv_norm, dq, dtext, B, D, ST(stream));
 }
 
+int spn_combine_l2norm_bwd_scaled(const float* q_f32, const float* inv_norm, const float* dq, const float* scale_dev,
+                                  float* dtext, int B, int D, void* stream) {
+    if (!q_f32 || !inv_norm || !dq || !dtext || !scale_dev) return SPN_ERR_ARG;
+    return combine_l2norm_bwd(q_f32, inv_norm, dq, dtext, B, D, ST(stream), scale_dev);
+}
+
 static BankArgs make_bank(const void* q, int ldq, const void* bank, const int64_t* labels, int B, int M, int D,
                           int m_begin, float inv_tau) {
     BankArgs a;

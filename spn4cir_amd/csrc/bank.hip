@@ -85,8 +85,11 @@ int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t 
 }
 
 // x = r + t, q = x * inv  =>  dx = inv * (dq - q * <q, dq>)  (valid while ||x|| > eps); dtext = dx
+// scale_dev (optional): every output is multiplied by *scale_dev - the incoming d(loss) of an autograd backward, read on
+// the device so that the host never synchronises on it (the map dq -> dtext is linear)
 __global__ void combine_l2norm_bwd_kernel(const float* __restrict__ q, const float* __restrict__ inv_norm,
-                                          const float* __restrict__ dq, float* __restrict__ dtext, int B, int D) {
+                                          const float* __restrict__ dq, float* __restrict__ dtext, int B, int D,
+                                          const float* __restrict__ scale_dev) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -96,7 +99,7 @@ __global__ void combine_l2norm_bwd_kernel(const float* __restrict__ q, const flo
         dot += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
     }
     dot = wave_sum(dot);
-    const float inv = inv_norm[b];
+    const float inv = inv_norm[b] * (scale_dev ? *scale_dev : 1.0f);
     for (int c = lane * 4; c < D; c += 256) {
         const f32x4 a = *(const f32x4*)(q + (size_t)b * D + c), g = *(const f32x4*)(dq + (size_t)b * D + c);
         *(f32x4*)(dtext + (size_t)b * D + c) = (g - a * dot) * inv;
@@ -104,10 +107,11 @@ __global__ void combine_l2norm_bwd_kernel(const float* __restrict__ q, const flo
 }
 
 int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, float* dtext, int B, int D,
-                       hipStream_t st) {
+                       hipStream_t st, const float* scale_dev) {
     if (B <= 0 || D <= 0) return SPN_ERR_ARG;
     if (D % 4) return SPN_ERR_SHAPE;
-    hipLaunchKernelGGL(combine_l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, q, inv_norm, dq, dtext, B, D);
+    hipLaunchKernelGGL(combine_l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, q, inv_norm, dq, dtext, B, D,
+                       scale_dev);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -166,7 +166,7 @@ int attention_cross_fwd_blocks(const AttnArgs& a, hipStream_t st);   // non-caus
 int combine_l2norm_fwd(const float* refer_bank, const int64_t* ref_idx, int64_t n_refer, const float* text,
                        float* q_f32, bf16_t* q_bf16, float* inv_norm, int B, int D, int ldq, hipStream_t st);
 int combine_l2norm_bwd(const float* q, const float* inv_norm, const float* dq, float* dtext, int B, int D,
-                       hipStream_t st);
+                       hipStream_t st, const float* scale_dev = nullptr);
 struct BankArgs {
     const bf16_t* q; int ldq;        // [B, D] L2-normalised queries
     const bf16_t* bank;              // [M_local, D] bf16, or e4m3 bytes [M_local, D] when bank_scale != nullptr

@@ -78,14 +78,16 @@ _CLIP_FILES = {"RN50": "RN50.pt", "RN101": "RN101.pt", "RN50x4": "RN50x4.pt", "R
 class CIRPlus(nn.Module):
     def __init__(self, clip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25,
                  device=torch.device("cuda"), plus=False, neg_num=-1, combiner="sum", label_smoothing=0.0,
-                 tokenizer=None, pack_eot=False, wo_bank=False, exact_eval=False):
+                 tokenizer=None, pack_eot=False, wo_bank=False, exact_eval=True):
         """`clip_model_name`: path to a CLIP state-dict file (as clip.load accepts, clip/clip.py:120-123),
         a state-dict, or "synthetic:<name>" (seeded random weights; no pretrained weights exist offline).
         `pack_eot`: run the text tower on the live rows only (everything after a caption's EOT token is dead
         under the causal mask); same loss and gradients, ~L/mean_len fewer rows."""
         super().__init__()
         self.pack_eot = bool(pack_eot)
-        # exact_eval: encode_image / encode_text outside of training run the fp32-exact towers (validation mode)
+        # exact_eval (default): encode_image / encode_text under torch.no_grad() - validation, bank extraction - run the
+        # fp32-exact towers, whose features give the reference's top-K index sets (north_star); False = the bf16 towers
+        # there too (8x the throughput, ~1e-5 feature error: enough to flip near-ties of a ranking).  Training is bf16.
         self.exact_eval = bool(exact_eval)
         self.wo_bank = bool(wo_bank)   # clip4cir/models.py:23: in-batch negatives, visual tower trainable
         self._pack = (None, 0)
@@ -345,11 +347,19 @@ class CIRPlus(nn.Module):
         lse, row, mean = ops.bank_loss_finalize(stats, M, self.label_smoothing)
         return dict(q=q, qb=qb, inv=inv, lse=lse, loss=mean, labels=labels, B=ids.shape[0], M=M)
 
+    @staticmethod
+    def _dev_scale(grad_out, device):
+        """autograd's incoming d(loss) as a 1-element fp32 device tensor: it scales the (linear) backward on the device, so
+        the backward pass starts without a host synchronisation (the reference's GradScaler hands a scaled loss here)."""
+        if torch.is_tensor(grad_out):
+            return grad_out.detach().to(device=device, dtype=torch.float32).reshape(1)
+        return torch.full((1,), float(grad_out), dtype=torch.float32, device=device)
+
     def _step_backward(self, st, grad_out):
-        scale = float(grad_out) if not torch.is_tensor(grad_out) else grad_out.item()
         dq = ops.bank_grad_q(st["qb"], self._target_bank_dev, st["labels"], 1.0 / self.tau, st["lse"],
-                             scale / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing)
-        dtext = ops.combine_l2norm_bwd(st["q"], st["inv"], dq[:, :self.output_dim].contiguous())
+                             1.0 / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing)
+        dtext = ops.combine_l2norm_bwd(st["q"], st["inv"], dq[:, :self.output_dim].contiguous(),
+                                       scale=self._dev_scale(grad_out, self.device))
         snap = gradsink.snapshot(self._params, self.tower.grads, self.tower.named_views)
         flat = self.tower.backward(dtext)
         gradsink.publish(self._params, flat, self.tower.named_views, snap)
@@ -372,13 +382,13 @@ class CIRPlus(nn.Module):
         return dict(q=q, qb=qb, inv_q=inv_q, t=t, tb=tb, inv_t=inv_t, lse=lse, loss=mean, labels=ar, B=B)
 
     def _inbatch_backward(self, st, grad_out):
-        scale = float(grad_out) if not torch.is_tensor(grad_out) else grad_out.item()
+        scale = self._dev_scale(grad_out, self.device)
         B, D = st["B"], self.output_dim
-        gs = scale / B
+        gs = 1.0 / B
         dq = ops.bank_grad_q(st["qb"], st["tb"], st["labels"], 1.0 / self.tau, st["lse"], gs, M_total=B)
         dt = ops.inbatch_grad_t(st["qb"], st["tb"], st["lse"], 1.0 / self.tau, gs, D)
-        dsum = ops.combine_l2norm_bwd(st["q"], st["inv_q"], dq[:, :D].contiguous())      # = d ref_feats = d text_feats
-        dtgt = ops.combine_l2norm_bwd(st["t"], st["inv_t"], dt)
+        dsum = ops.combine_l2norm_bwd(st["q"], st["inv_q"], dq[:, :D].contiguous(), scale=scale)   # = d ref_feats = d text_feats
+        dtgt = ops.combine_l2norm_bwd(st["t"], st["inv_t"], dt, scale=scale)
         snap_t = gradsink.snapshot(self._params, self.tower.grads, self.tower.named_views)
         snap_v = gradsink.snapshot(self._params, self.vision.grads, self.vision.named_views, "visual.")
         flat_t = self.tower.backward(dsum)

@@ -290,9 +290,17 @@ def combine_l2norm_fwd(refer_bank, ref_idx, text, ldq=None):
     return q, qb, inv
 
 
-def combine_l2norm_bwd(q, inv_norm, dq):
+def combine_l2norm_bwd(q, inv_norm, dq, scale=None):
+    """scale: optional 1-element fp32 device tensor multiplied into the result on the device (autograd's incoming
+    d(loss): no host synchronisation on it)."""
     B, D = q.shape
     dtext = torch.empty(B, D, dtype=torch.float32, device=q.device)
+    if scale is not None:
+        if scale.dtype != torch.float32 or not scale.is_cuda or scale.numel() != 1:
+            raise ValueError("scale must be a 1-element fp32 device tensor")
+        check(lib().spn_combine_l2norm_bwd_scaled(_p(q), _p(inv_norm), _p(dq), _p(scale), _p(dtext), B, D, _stream()),
+              "combine_l2norm_bwd_scaled")
+        return dtext
     check(lib().spn_combine_l2norm_bwd(_p(q), _p(inv_norm), _p(dq), _p(dtext), B, D, _stream()), "combine_l2norm_bwd")
     return dtext
 
