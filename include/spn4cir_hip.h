@@ -147,6 +147,22 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
                     int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
                     float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 size_t spn_bank_workspace_bytes(int B, int M, int D);
+/* The same two passes as ONE forward/backward pair that keeps the logits of the step (what autograd keeps for
+ * `(q @ bank.T) / tau`, models_negplus.py:150-153) instead of recomputing them in the backward pass: logits_save is
+ * spn_bank_logits_bytes(B, M) bytes of device scratch written by the forward call and read by the backward call of the
+ * SAME (q, bank, labels, B, M, D, m_begin, inv_tau).  Per-call batches below 128 queries run on barrier-free streaming
+ * kernels (csrc/bank2.hip): the bank goes through HBM exactly once per pass and the backward pass reads
+ * B * M * 4 B of logits on top (8 % of the bank bytes at B = 32, D = 768).  Larger batches (and token-max banks) fall back
+ * to the calls above inside this pair - same results, logits_save untouched.  bank_scale = NULL: bf16 bank;
+ * otherwise the e4m3 bank of spn_bank_quantize_fp8 (ws from spn_bank_workspace_bytes_fp8 then). */
+size_t spn_bank_logits_bytes(int B, int M);
+int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
+                            int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
+                            size_t ws_bytes, void* stream);
+int spn_bank_grad_q_saved(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
+                          int M, int D, int m_begin, float inv_tau, const float* logits_saved, const float* row_lse,
+                          float label_smoothing, int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes,
+                          void* stream);
 /* fp8 bank (BASELINE config 5): the static bank stored as OCP e4m3 bytes [M, Dp] + one fp32 scale per row
  * (row max -> 448), halving the only HBM stream of the loss.  The kernels dequantise a tile into LDS (x scale,
  * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /

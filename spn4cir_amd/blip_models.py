@@ -26,9 +26,10 @@ class _FusionBankStep(torch.autograd.Function):
         proj = enc.forward(ids, mask, tokens)
         q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
         bank = model._target_bank_dev
-        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau)
+        saved = ops.bank_logits_buffer(qb.shape[0], bank.shape[0], qb.device)
+        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
-        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0])
+        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0], saved=saved)
         return mean.reshape(()).clone()
 
     @staticmethod
@@ -39,7 +40,7 @@ class _FusionBankStep(torch.autograd.Function):
         # the incoming d(loss) scales the (linear) backward on the device: no host synchronisation on it
         scale = grad_out.detach().to(torch.float32).reshape(1)
         dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], 1.0 / st["B"],
-                             M_total=bank.shape[0])[:, :enc.Dp].contiguous()
+                             M_total=bank.shape[0], saved=st["saved"])[:, :enc.Dp].contiguous()
         dtau = (-(st["q"] * dq).sum() / st["tau"] * scale[0]).reshape(())   # models.py:29: tau is an nn.Parameter
         snap = gradsink.snapshot(m._params, enc.grads, enc.named_views)
         flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq, scale=scale))

@@ -192,6 +192,27 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
                        M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream));
 }
 
+size_t spn_bank_logits_bytes(int B, int M) { return bank_saved_bytes(B, M); }
+
+int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
+                            int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
+                            size_t ws_bytes, void* stream) {
+    if (!stats || !logits_save) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank, labels, B, M, D, m_begin, inv_tau);
+    a.bank_scale = bank_scale;
+    return bank_stats_fwd(a, stats, (float*)ws, ws_bytes, ST(stream), logits_save);
+}
+
+int spn_bank_grad_q_saved(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
+                          int M, int D, int m_begin, float inv_tau, const float* logits_saved, const float* row_lse,
+                          float label_smoothing, int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes,
+                          void* stream) {
+    if (!logits_saved) return SPN_ERR_ARG;
+    BankArgs a = make_bank(q_bf16, ldq, bank, labels, B, M, D, m_begin, inv_tau);
+    a.bank_scale = bank_scale;
+    return bank_grad_q(a, row_lse, label_smoothing, M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream), logits_saved);
+}
+
 size_t spn_bank_workspace_bytes(int B, int M, int D) { return bank_workspace_bytes(B, M, D); }
 size_t spn_bank_workspace_bytes_fp8(int B, int M, int D) { return bank_workspace_bytes_fp8(B, M, D); }
 

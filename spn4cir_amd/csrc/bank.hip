@@ -933,6 +933,12 @@ __global__ void bank_stats_fold_kernel(const float* __restrict__ ws, int n, int 
     }
 }
 
+int bank_stats_fold(const float* ws, int n, int B, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((B + 3) / 4), dim3(256), 0, st, ws, n, B, stats);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 // loss_row = lse - (1-eps)*label_logit - eps*mean_j logit_j   (CrossEntropyLoss w/ label smoothing)
 __global__ void bank_loss_finalize_kernel(const float* __restrict__ stats, int nshards, int B, float inv_m_total,
                                           float label_smoothing, float* __restrict__ row_lse,
@@ -970,7 +976,9 @@ size_t bank_workspace_bytes(int B, int M, int D) {
     const size_t g = (size_t)gemm_bank_stats_tiles(M) * B * 4 * sizeof(float);   // GEMM-path statistics partials
     if (g > a) a = g;
     const size_t b = (size_t)c.nchunks * B * D * sizeof(float);
-    return a > b ? a : b;
+    if (b > a) a = b;
+    const size_t n = bank2_workspace_bytes(B, M, D);                              // second-generation kernels (bank2.hip)
+    return a > n ? a : n;
 }
 
 template <int D, bool BWD, bool FP8, bool GRP = false>
@@ -1067,13 +1075,16 @@ static bool bank_expand_fp8(const BankArgs& a, float* ws, size_t ws_bytes, BankA
     return true;
 }
 
-int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st) {
+int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st, float* zsave) {
     int rc = bank_check(a);
     if (rc) return rc;
+    // per-GPU batches below 128 queries: the barrier-free row-tile kernel (bank2.hip); zsave (optional) keeps the logits
+    // for bank_grad_q's saved path.  SPN_BANK2=0 keeps everything on the first-generation kernels below.
+    if (bank_saved_path(a)) return bank2_stats_fwd(a, stats, zsave, ws, ws_bytes, st);
     {
         BankArgs b;
         size_t base;
-        if (bank_expand_fp8(a, ws, ws_bytes, &b, &base, st)) return bank_stats_fwd(b, stats, ws, base, st);
+        if (bank_expand_fp8(a, ws, ws_bytes, &b, &base, st)) return bank_stats_fwd(b, stats, ws, base, st, nullptr);
     }
     // Large batches: the logits pass as a 256x256-tile GEMM with a statistics epilogue (the bank is read once, the
     // queries come from L2); the streaming kernel below re-reads every bank tile once per 32 queries, which is the
@@ -1129,15 +1140,18 @@ int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, 
 }
 
 int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
-                float* dq, float* ws, size_t ws_bytes, hipStream_t st) {
+                float* dq, float* ws, size_t ws_bytes, hipStream_t st, const float* zsaved) {
     int rc = bank_check(a);
     if (rc) return rc;
     if (!row_lse || !dq || M_total <= 0) return SPN_ERR_ARG;
+    // logits saved by the forward call of this step: stream the bank once, no recomputation (bank2.hip)
+    if (zsaved && bank_saved_path(a))
+        return bank2_grad_q(a, zsaved, row_lse, label_smoothing, M_total, grad_scale, dq, ws, ws_bytes, st);
     {
         BankArgs b;
         size_t base;
         if (bank_expand_fp8(a, ws, ws_bytes, &b, &base, st))
-            return bank_grad_q(b, row_lse, label_smoothing, M_total, grad_scale, dq, ws, base, st);
+            return bank_grad_q(b, row_lse, label_smoothing, M_total, grad_scale, dq, ws, base, st, nullptr);
     }
     const BankChunking c = bank_chunking(a.B, a.M);
     if (ws_bytes < (size_t)c.nchunks * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;

@@ -182,13 +182,24 @@ struct BankArgs {
 int bank_quantize_fp8(const float* bank, int M, int D, int Dp, uint8_t* out, float* scale, hipStream_t st);
 // forward: per-row partial softmax statistics over this shard
 //   stats[b] = {max, sum exp(l - max), sum l, label logit (or -inf if the label is not in the shard)}
-int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t ws_bytes, hipStream_t st);
+// zsave (optional, bank_saved_bytes()): receives the logits when bank_saved_path(a) - hand it to bank_grad_q as zsaved
+int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t ws_bytes, hipStream_t st,
+                   float* zsave = nullptr);
+int bank_stats_fold(const float* ws, int n, int B, float* stats, hipStream_t st);
+// bank2.hip: barrier-free kernels for batches below 128 queries, backward from saved logits
+bool bank_saved_path(const BankArgs& a);
+int bank_saved_ld(int M);
+size_t bank_saved_bytes(int B, int M);
+size_t bank2_workspace_bytes(int B, int M, int D);
+int bank2_stats_fwd(const BankArgs& a, float* stats, float* zsave, float* ws, size_t ws_bytes, hipStream_t st);
+int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, float label_smoothing, int64_t M_total,
+                 float grad_scale, float* dq, float* ws, size_t ws_bytes, hipStream_t st);
 // finalize on the owner of all shards' stats: row_lse, row_loss and the mean loss
 int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
                        float* row_lse, float* row_loss, float* loss_mean, hipStream_t st);
 // backward: dq[b] (+)= grad_scale * inv_tau * sum_m (softmax - target) bank[m]
 int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, int64_t M_total, float grad_scale,
-                float* dq /*[B,D] fp32*/, float* ws, size_t ws_bytes, hipStream_t st);
+                float* dq /*[B,D] fp32*/, float* ws, size_t ws_bytes, hipStream_t st, const float* zsaved = nullptr);
 size_t bank_workspace_bytes(int B, int M, int D);
 size_t bank_workspace_bytes_fp8(int B, int M, int D);   // + room for the expanded bf16 copy at large batches
 // in-batch negatives (clip4cir/models.py:160-167): dt[j] = grad_scale * inv_tau * sum_i (softmax_i[j] - [i == j]) q[i]

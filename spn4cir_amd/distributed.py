@@ -78,28 +78,38 @@ class BankLossDP:
         rows, `bank` = full bank (replicated) or this rank's shard starting at global row m_begin.
         Returns a ctx dict; ctx['loss'] is the GLOBAL mean loss (identical on every rank)."""
         ops = self.ops
+
+        def stats_fwd(q, labels):
+            # the HIP ops keep the logits of small per-call batches for the backward pass (ops.bank_logits_buffer)
+            mk = getattr(ops, "bank_logits_buffer", None)
+            save = mk(q.shape[0], bank.shape[0], q.device) if mk is not None else None
+            if save is None:
+                return ops.bank_stats_fwd(q, bank, labels, inv_tau, m_begin), None
+            return ops.bank_stats_fwd(q, bank, labels, inv_tau, m_begin, save=save), save
+
         if self.mode == "replicated" or _skip(self.world):
-            stats = ops.bank_stats_fwd(qb_local, bank, labels_local, inv_tau, m_begin)
+            stats, saved = stats_fwd(qb_local, labels_local)
             lse, row, mean = ops.bank_loss_finalize(stats, M_total, label_smoothing)
             loss = row.sum().reshape(1)
             if not _skip(self.world):
                 dist.all_reduce(loss, group=self.group)          # reporting only
             B_global = qb_local.shape[0] * self.world
             return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss / B_global, bank=bank, m_begin=m_begin,
-                        M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False)
+                        M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False, saved=saved)
         q_all = all_gather_cat(qb_local, self.group)
         labels_all = all_gather_cat(labels_local, self.group)
-        stats = ops.bank_stats_fwd(q_all, bank, labels_all, inv_tau, m_begin)           # [B, 4] over my shard
+        stats, saved = stats_fwd(q_all, labels_all)                                     # [B, 4] over my shard
         stats_all = all_gather_cat(stats.unsqueeze(0), self.group)                      # [G, B, 4]
         lse, row, mean = ops.bank_loss_finalize(stats_all, M_total, label_smoothing)    # identical everywhere
         return dict(q=q_all, labels=labels_all, lse=lse, loss=mean, bank=bank, m_begin=m_begin, M_total=M_total,
-                    inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True)
+                    inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True, saved=saved)
 
     def backward(self, ctx, loss_scale=1.0):
         """-> d(loss_scale * global mean loss)/d(q_local)  [B_local, Dp] fp32"""
         gs = loss_scale / ctx["B_global"]
+        kw = {"saved": ctx["saved"]} if ctx.get("saved") is not None else {}
         dq = self.ops.bank_grad_q(ctx["q"], ctx["bank"], ctx["labels"], ctx["inv_tau"], ctx["lse"], gs,
-                                  M_total=ctx["M_total"], label_smoothing=ctx["ls"], m_begin=ctx["m_begin"])
+                                  M_total=ctx["M_total"], label_smoothing=ctx["ls"], m_begin=ctx["m_begin"], **kw)
         if ctx["gathered"]:
             dq = reduce_scatter_rows(dq, self.group)
         return dq

@@ -140,11 +140,12 @@ class BlipBankStep:
         proj = self.enc.forward(ids, mask, ref_tokens)
         q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
         M = bank_bf16.shape[0]
-        stats = ops.bank_stats_fwd(qb, bank_bf16, labels, 1.0 / self.tau)
+        saved = ops.bank_logits_buffer(qb.shape[0], M, qb.device)
+        stats = ops.bank_stats_fwd(qb, bank_bf16, labels, 1.0 / self.tau, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, M, self.ls)
         B = ids.shape[0]
         dq = ops.bank_grad_q(qb, bank_bf16, labels, 1.0 / self.tau, lse, (grad_scale or 1.0) / B, M_total=M,
-                             label_smoothing=self.ls)[:, :self.enc.Dp].contiguous()
+                             label_smoothing=self.ls, saved=saved)[:, :self.enc.Dp].contiguous()
         dtau = -(q * dq).sum() / self.tau
         dproj = ops.combine_l2norm_bwd(q, inv, dq)
         grads = self.enc.backward(dproj)

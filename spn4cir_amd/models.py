@@ -343,9 +343,10 @@ class CIRPlus(nn.Module):
         feats = self.tower.forward(ids, *self._pack)
         q, qb, inv = ops.combine_l2norm_fwd(self._refer_f32, refer_idx, feats)
         M = bank_dev.shape[0]
-        stats = ops.bank_stats_fwd(qb, bank_dev, labels, 1.0 / self.tau)
+        saved = ops.bank_logits_buffer(qb.shape[0], M, qb.device) if torch.is_grad_enabled() else None
+        stats = ops.bank_stats_fwd(qb, bank_dev, labels, 1.0 / self.tau, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, M, self.label_smoothing)
-        return dict(q=q, qb=qb, inv=inv, lse=lse, loss=mean, labels=labels, B=ids.shape[0], M=M)
+        return dict(q=q, qb=qb, inv=inv, lse=lse, loss=mean, labels=labels, B=ids.shape[0], M=M, saved=saved)
 
     @staticmethod
     def _dev_scale(grad_out, device):
@@ -357,7 +358,7 @@ class CIRPlus(nn.Module):
 
     def _step_backward(self, st, grad_out):
         dq = ops.bank_grad_q(st["qb"], self._target_bank_dev, st["labels"], 1.0 / self.tau, st["lse"],
-                             1.0 / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing)
+                             1.0 / st["B"], M_total=st["M"], label_smoothing=self.label_smoothing, saved=st["saved"])
         dtext = ops.combine_l2norm_bwd(st["q"], st["inv"], dq[:, :self.output_dim].contiguous(),
                                        scale=self._dev_scale(grad_out, self.device))
         snap = gradsink.snapshot(self._params, self.tower.grads, self.tower.named_views)

@@ -305,13 +305,38 @@ def combine_l2norm_bwd(q, inv_norm, dq, scale=None):
     return dtext
 
 
-def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0):
+BANK_LOGITS_MAX_BYTES = 1 << 30
+
+
+def bank_logits_buffer(B, M, device):
+    """Scratch for the saved-logits pair (bank_stats_fwd(..., save=buf) / bank_grad_q(..., saved=buf)), or None when the
+    pair would not use it (batches of 128 queries and more recompute the logits) or it would exceed
+    BANK_LOGITS_MAX_BYTES.  One buffer per forward call (torch's caching allocator): it belongs to that call's autograd /
+    step context until its backward has run, so two forwards in flight never share logits."""
+    if B >= 128:
+        return None
+    n = lib().spn_bank_logits_bytes(B, M)
+    if n > BANK_LOGITS_MAX_BYTES:
+        return None
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0, save=None):
+    """save (bank_logits_buffer): keep the logits of this call for bank_grad_q(..., saved=save) - no recomputation in the
+    backward pass (spn_bank_stats_fwd_save)."""
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
     stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
     fp8 = isinstance(bank_bf16, Fp8Bank)
     ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
                    "bank")
+    if save is not None:
+        if not save.is_cuda or save.numel() * save.element_size() < lib().spn_bank_logits_bytes(B, M):
+            raise ValueError("save: device scratch of spn_bank_logits_bytes(B, M) bytes (ops.bank_logits_buffer)")
+        data, scale = (bank_bf16.data, bank_bf16.scale) if fp8 else (bank_bf16, None)
+        check(lib().spn_bank_stats_fwd_save(_p(q_bf16), Dp, _p(data), _p(scale), _p(labels), B, M, Dp, m_begin, inv_tau,
+                                            _p(stats), _p(save), _p(ws), ws.numel(), _stream()), "bank_stats_fwd_save")
+        return stats
     if fp8:
         check(lib().spn_bank_stats_fwd_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
                                            m_begin, inv_tau, _p(stats), _p(ws), ws.numel(), _stream()), "bank_stats_fwd_fp8")
@@ -335,13 +360,21 @@ def bank_loss_finalize(stats, M_total, label_smoothing=0.0):
     return lse, row, mean
 
 
-def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total=None, label_smoothing=0.0, m_begin=0):
+def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total=None, label_smoothing=0.0, m_begin=0,
+                saved=None):
+    """saved: the buffer the matching bank_stats_fwd(..., save=...) call filled (spn_bank_grad_q_saved)."""
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
     dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
     fp8 = isinstance(bank_bf16, Fp8Bank)
     ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
                    "bank")
+    if saved is not None:
+        data, scale = (bank_bf16.data, bank_bf16.scale) if fp8 else (bank_bf16, None)
+        check(lib().spn_bank_grad_q_saved(_p(q_bf16), Dp, _p(data), _p(scale), _p(labels), B, M, Dp, m_begin, inv_tau,
+                                          _p(saved), _p(row_lse), label_smoothing, M_total or M, grad_scale, _p(dq), _p(ws),
+                                          ws.numel(), _stream()), "bank_grad_q_saved")
+        return dq
     if fp8:
         check(lib().spn_bank_grad_q_fp8(_p(q_bf16), Dp, _p(bank_bf16.data), _p(bank_bf16.scale), _p(labels), B, M, Dp,
                                         m_begin, inv_tau, _p(row_lse), label_smoothing, M_total or M, grad_scale, _p(dq),

@@ -283,6 +283,60 @@ def test_bank_infonce(ops, B, M, D, tau):
     assert rel_err(dtext, x.grad) < 1e-5
 
 
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
+@pytest.mark.parametrize("B,M,D,tau", [(32, 40000, 768, 0.02), (4, 500, 128, 0.01), (32, 4099, 512, 0.02), (70, 3000, 768, 0.02),
+                                        (33, 1500, 640, 0.02), (1, 7, 128, 0.02), (3, 33, 256, 0.01), (127, 9001, 1024, 0.05),
+                                        (16, 100000, 768, 0.02)])
+def test_bank_saved_logits_pair(ops, B, M, D, tau, fp8):
+    """The forward/backward pair that keeps the step's logits (spn_bank_stats_fwd_save / spn_bank_grad_q_saved, batches
+    below 128 queries: csrc/bank2.hip): statistics and loss as the oracle on the same (bf16-rounded resp. dequantised)
+    operands, the saved logits themselves, dq against the oracle and against the recomputing backward kernel, two
+    unequal shards with label smoothing, a bank smaller than one tile, rows that end in the middle of a 16-row tile."""
+    from oracle import bank_loss
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 3 * B + M)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    bank_b = ops.prepare_bank(dev(bank), "fp8" if fp8 else "bf16")
+    qr = qb[:, :D].cpu().float()
+    br = (bank_b.dequantize() if fp8 else bank_b)[:, :D].cpu().float()
+    if fp8:          # the logits of an e4m3 bank run on the fp8 MFMA: queries as two e4m3 terms (oracle: split_query_e4m3)
+        qr = bank_loss.split_query_e4m3(qr)
+    lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+    save = ops.bank_logits_buffer(B, M, "cuda")
+    assert save is not None
+    stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau, save=save)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+    assert (stats[:, 3].cpu().double() - lab_ref).abs().max() < 2e-4
+    assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+    ld = (M + 31) // 32 * 32
+    z = save[:B * ld * 4].view(torch.float32).view(B, ld)[:, :M].cpu().double()
+    assert (z - (qr.double() @ br.double().t()) / tau).abs().max() < 5e-4
+    dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B, saved=save)
+    dq_ref = bank_loss.infonce_grad_q(qr, br, labels, tau)
+    assert rel_err(dq[:, :D], dq_ref) < 1.5e-2     # G is rounded to bf16 before the second GEMM
+    assert not dq[:, D:].any()
+    dq_old = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)          # recomputing kernel
+    assert rel_err(dq, dq_old) < 1.5e-2
+    if M >= 64:
+        eps, cut = 0.1, (M // 3) | 1                 # an odd cut: shards that start / end inside a tile
+        qd = qr.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy((qd @ br.double().t()) / tau, labels, label_smoothing=eps)
+        ref.backward()
+        halves = []
+        for a, b in ((0, cut), (cut, M)):
+            if fp8:
+                sh = ops.Fp8Bank(bank_b.data[a:b].contiguous(), bank_b.scale[a:b].contiguous())
+            else:
+                sh = bank_b[a:b].contiguous()
+            sv = ops.bank_logits_buffer(B, b - a, "cuda")
+            halves.append((sh, sv, a, ops.bank_stats_fwd(qb, sh, dev(labels), 1.0 / tau, m_begin=a, save=sv)))
+        lse2, row2, mean2 = ops.bank_loss_finalize(torch.stack([h[3] for h in halves]), M, label_smoothing=eps)
+        assert abs(mean2.item() - ref.item()) < 3e-4
+        d = sum(ops.bank_grad_q(qb, sh, dev(labels), 1.0 / tau, lse2, 1.0 / B, M_total=M, label_smoothing=eps, m_begin=a,
+                                saved=sv) for sh, sv, a, _ in halves)
+        assert rel_err(d[:, :D], qd.grad) < 1.5e-2
+
+
 def test_bank_label_smoothing_and_shards(ops):
     from oracle import bank_loss
     B, M, D, tau, eps = 24, 2500, 256, 0.02, 0.1
