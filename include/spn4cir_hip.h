@@ -150,12 +150,19 @@ size_t spn_bank_workspace_bytes(int B, int M, int D);
 /* The same two passes as ONE forward/backward pair that keeps the logits of the step (what autograd keeps for
  * `(q @ bank.T) / tau`, models_negplus.py:150-153) instead of recomputing them in the backward pass: logits_save is
  * spn_bank_logits_bytes(B, M) bytes of device scratch written by the forward call and read by the backward call of the
- * SAME (q, bank, labels, B, M, D, m_begin, inv_tau).  Per-call batches below 128 queries run on barrier-free streaming
- * kernels (csrc/bank2.hip): the bank goes through HBM exactly once per pass and the backward pass reads
- * B * M * 4 B of logits on top (8 % of the bank bytes at B = 32, D = 768).  Larger batches (and token-max banks) fall back
- * to the calls above inside this pair - same results, logits_save untouched.  bank_scale = NULL: bf16 bank;
- * otherwise the e4m3 bank of spn_bank_quantize_fp8 (ws from spn_bank_workspace_bytes_fp8 then). */
+ * SAME (q, bank, labels, B, M, D, m_begin, inv_tau).
+ *   B >= 128 (B % 8 == 0, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
+ *     backward pass is a transpose-and-scale launch (G^T) plus ONE weight-gradient-shaped GEMM dq = (G^T)^T bank on the
+ *     MFMA kernels, instead of a recomputing stream kernel in 32-query blocks.
+ *   B < 128 with spn_bank_config(1): barrier-free streaming kernels (csrc/bank2.hip), fp32 logits kept (B * M * 4 B).
+ *   otherwise (token-max banks, e4m3 banks at B >= 128, ...): the pair runs the calls above - same results, logits_save
+ *     untouched.
+ * bank_scale = NULL: bf16 bank; else the e4m3 bank of spn_bank_quantize_fp8 (ws from spn_bank_workspace_bytes_fp8). */
 size_t spn_bank_logits_bytes(int B, int M);
+/* 1 = batches below 128 queries use the second-generation streaming kernels (csrc/bank2.hip; also SPN_BANK2=1), 0 = the
+ * first-generation block-cooperative kernels (default: faster at 40 000-row banks).  Process-wide
+ * tuning switch like the SPN_* environment knobs; both give the same results within the documented tolerances. */
+int spn_bank_config(int second_generation);
 int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
                             int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
                             size_t ws_bytes, void* stream);

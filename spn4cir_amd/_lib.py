@@ -82,6 +82,7 @@ _SIGS = {
     "spn_bank_grad_q": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_bank_workspace_bytes": (sz, [i32, i32, i32]),
     "spn_bank_logits_bytes": (sz, [i32, i32]),
+    "spn_bank_config": (i32, [i32]),
     "spn_bank_stats_fwd_save": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
     "spn_bank_grad_q_saved": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_bank_workspace_bytes_fp8": (sz, [i32, i32, i32]),

@@ -978,7 +978,9 @@ size_t bank_workspace_bytes(int B, int M, int D) {
     const size_t b = (size_t)c.nchunks * B * D * sizeof(float);
     if (b > a) a = b;
     const size_t n = bank2_workspace_bytes(B, M, D);                              // second-generation kernels (bank2.hip)
-    return a > n ? a : n;
+    if (n > a) a = n;
+    const size_t t = B >= 128 && B % 8 == 0 ? gemm_tn_workspace_bytes(M, B, D) : 0;  // GEMM backward pass from saved p
+    return a > t ? a : t;
 }
 
 template <int D, bool BWD, bool FP8, bool GRP = false>
@@ -1075,6 +1077,86 @@ static bool bank_expand_fp8(const BankArgs& a, float* ws, size_t ws_bytes, BankA
     return true;
 }
 
+// ---------------------------------------------------------------------- batches of 128 queries and more, saved pass
+// The forward pass is a GEMM (gemm_bank_stats); with a save buffer its epilogue also keeps p = exp(logit - tile max) as
+// bf16 [B, ldp] and the tile maxima.  The backward pass is then two launches instead of a recomputing stream kernel:
+//   G^T[m][b] = p * exp(tile max - lse_b) - [m == label_b] (1 - eps) - eps / M_total     (bank_p_to_gt_kernel, a transpose)
+//   dq [B, D] = (G^T)^T bank = gemm_tn(G^T [M, B], bank [M, D])                          (the weight-gradient GEMM)
+// i.e. 2 M B D flop on the MFMA GEMM kernels and 2 x 2 M B bytes of p / G traffic, against a recomputation of the logits
+// plus a dq GEMM in 32-query blocks that re-read every bank tile B / 32 times from L2 (72 us at B = 256, M = 40 000).
+struct LargeSave {
+    bf16_t* P; int ldp; bf16_t* Gt; int mpad; float* tmax; int nt;
+};
+static size_t large_save_bytes(int B, int M) {
+    const size_t ldp = (size_t)(M + 255) / 256 * 256, mpad = (size_t)(M + 63) / 64 * 64, nt = (size_t)(M + 255) / 256;
+    return (((size_t)B * ldp * 2 + 255) & ~(size_t)255) + ((mpad * B * 2 + 255) & ~(size_t)255) + nt * B * 4;
+}
+static LargeSave large_save_at(void* base, int B, int M) {
+    LargeSave s;
+    s.ldp = (M + 255) / 256 * 256; s.mpad = (M + 63) / 64 * 64; s.nt = (M + 255) / 256;
+    char* p = (char*)base;
+    s.P = (bf16_t*)p; p += ((size_t)B * s.ldp * 2 + 255) & ~(size_t)255;
+    s.Gt = (bf16_t*)p; p += ((size_t)s.mpad * B * 2 + 255) & ~(size_t)255;
+    s.tmax = (float*)p;
+    return s;
+}
+static bool bank_gemm_on() {
+    static const bool use_gemm = [] {
+        const char* e = getenv("SPN_BANK_GEMM");
+        return !(e && e[0] == '0');
+    }();
+    return use_gemm;
+}
+// batches that take the GEMM forward pass and can keep p for a GEMM backward pass
+bool bank_saved_path_large(const BankArgs& a) {
+    return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= 128 && a.B % 8 == 0 && a.D % 64 == 0;
+}
+size_t bank_saved_bytes_any(int B, int M) {
+    const size_t small = bank_saved_bytes(B, M), large = B >= 128 ? large_save_bytes(B, M) : 0;
+    return small > large ? small : large;
+}
+
+__global__ __launch_bounds__(256) void bank_p_to_gt_kernel(const bf16_t* __restrict__ P, int ldp, const float* __restrict__ tmax,
+                                                          const float* __restrict__ lse, const int64_t* __restrict__ labels,
+                                                          int B, int M, int m_begin, float ls, float inv_m,
+                                                          bf16_t* __restrict__ Gt) {
+    __shared__ float T[64][65];
+    const int m0 = blockIdx.x * 64, b0 = blockIdx.y * 64, t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int bl = (t >> 3) + 32 * i, b = b0 + bl, m8 = (t & 7) * 8;
+        float g[8];
+        if (b < B) {
+            const bf16x8 p = *(const bf16x8*)(P + (size_t)b * ldp + m0 + m8);
+            const float tm = tmax[(size_t)((m0 + m8) >> 8) * B + b];          // 8 keys of one 256-key tile
+            const float sc = __expf(tm - lse[b]);
+            const int64_t lab = labels[b] - (int64_t)m_begin;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = m0 + m8 + e;
+                float gv = bf2f(p[e]) * sc - ls * inv_m;
+                gv -= ((int64_t)key == lab) ? 1.0f - ls : 0.f;
+                g[e] = key < M ? gv : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) T[bl][m8 + e] = g[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ml = (t >> 3) + 32 * i, b8 = (t & 7) * 8;
+        if (b0 + b8 >= B) continue;                                           // B % 8 == 0: whole vectors
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(T[b8 + e][ml]);
+        *(bf16x8*)(Gt + (size_t)(m0 + ml) * B + b0 + b8) = o;
+    }
+}
+
 int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, hipStream_t st, float* zsave) {
     int rc = bank_check(a);
     if (rc) return rc;
@@ -1089,17 +1171,20 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     // Large batches: the logits pass as a 256x256-tile GEMM with a statistics epilogue (the bank is read once, the
     // queries come from L2); the streaming kernel below re-reads every bank tile once per 32 queries, which is the
     // right trade only while B is small (8-way data parallel: 32 per GPU).  SPN_BANK_GEMM=0 forces streaming.
-    static const bool use_gemm = [] {
-        const char* e = getenv("SPN_BANK_GEMM");
-        return !(e && e[0] == '0');
-    }();
+    const bool use_gemm = bank_gemm_on();
     if (use_gemm && !a.bank_scale && !a.group && a.B >= 128 && a.D % 64 == 0) {
         const int nt = gemm_bank_stats_tiles(a.M);
         if (ws_bytes < (size_t)nt * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
         {
             const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
             ProfScope prof(PK_BANK_FWD, bytes, st);
-            rc = gemm_bank_stats(a.q, a.bank, a.B, a.M, a.D, a.ldq, a.D, a.labels, a.inv_tau, a.m_begin, ws, st);
+            if (zsave && bank_saved_path_large(a)) {
+                const LargeSave sv = large_save_at(zsave, a.B, a.M);
+                rc = gemm_bank_stats(a.q, a.bank, a.B, a.M, a.D, a.ldq, a.D, a.labels, a.inv_tau, a.m_begin, ws, st, sv.P, sv.ldp,
+                                     sv.tmax);
+            } else {
+                rc = gemm_bank_stats(a.q, a.bank, a.B, a.M, a.D, a.ldq, a.D, a.labels, a.inv_tau, a.m_begin, ws, st);
+            }
         }
         if (rc) return rc;
         hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, ws, nt, a.B, stats);
@@ -1147,6 +1232,16 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     // logits saved by the forward call of this step: stream the bank once, no recomputation (bank2.hip)
     if (zsaved && bank_saved_path(a))
         return bank2_grad_q(a, zsaved, row_lse, label_smoothing, M_total, grad_scale, dq, ws, ws_bytes, st);
+    if (zsaved && bank_saved_path_large(a)) {
+        const LargeSave sv = large_save_at(const_cast<float*>(zsaved), a.B, a.M);
+        if (ws_bytes < gemm_tn_workspace_bytes(a.M, a.B, a.D)) return SPN_ERR_WORKSPACE;
+        const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 6 + (double)a.B * 16;
+        ProfScope prof(PK_BANK_BWD, bytes, st);
+        hipLaunchKernelGGL(bank_p_to_gt_kernel, dim3(sv.mpad / 64, (a.B + 63) / 64), dim3(256), 0, st, sv.P, sv.ldp, sv.tmax, row_lse,
+                           a.labels, a.B, a.M, a.m_begin, label_smoothing, 1.0f / (float)M_total, sv.Gt);
+        SPN_CHECK_LAUNCH();
+        return gemm_tn(sv.Gt, a.bank, a.M, a.B, a.D, a.B, a.D, dq, a.D, grad_scale * a.inv_tau, 0, nullptr, ws, ws_bytes, st);
+    }
     {
         BankArgs b;
         size_t base;

@@ -8,10 +8,10 @@
 // unavoidable traffic is the bank itself.  Here:
 //
 //   forward  (bank_rowtile_fwd_kernel): every WAVE owns whole bank rows (full D) and its own LDS ring, fed by its own
-//     buffer_load ... lds pieces of 8 rows x 128 B; the 32 queries sit in registers (D = 768: 192 VGPRs, one wave per
-//     SIMD).  A 16-row tile is 16 keys x 32 queries of v_mfma_f32_16x16x32_bf16 over the full D: no partial sums to
-//     exchange, no block barrier in the loop - the only waits are the wave's own counted vmcnt, and the count is
-//     uniform because the tail issues zero-fill pieces (out-of-range buffer offsets move no bytes).  The logits
+//     buffer_load ... lds instructions of 1 KB of consecutive bytes; the 32 queries sit in registers (D = 768: 192
+//     VGPRs, one wave per SIMD).  A tile is 8 keys x 32 queries of v_mfma_f32_16x16x32_bf16 over the full D: no partial
+//     sums to exchange, no block barrier in the loop - the only waits are the wave's own counted vmcnt, and the count is
+//     uniform because the tail issues zero-fill tiles (out-of-range buffer offsets move no bytes).  The logits
 //     z = <q, bank_j> / tau are SAVED (fp32 [B, M]: 5 MB at B = 32, 8 % of the bank bytes) for the backward pass.
 //   backward (bank_dslice_bwd_kernel): with z saved nothing has to be recomputed, so a block no longer needs whole rows:
 //     it owns ONE 128-column slice of D and a long row range (grid = D/128 slices x chunks = #CUs), its waves stream
@@ -32,6 +32,35 @@ static constexpr int RQ = 32;          // queries per block
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// The row-tile forward keeps its 32 queries (192 registers at D = 768) in ACCUMULATION registers: as ordinary values
+// they fill the 256 architectural VGPRs, and the compiler then serialises every fragment read behind the previous
+// step's MFMAs through one 4-register temporary (read -> wait -> MFMA, ~150 cycles per k-step).  MFMA operands may
+// live in AGPRs on gfx950 (unified 512-entry file), so the accumulator and the B operand are pinned there by constraint
+// and the queries are parked in AGPRs once at start-up (at D = 1024 they alone are 256 registers: the fragments beyond the
+// budget stay in VGPRs and use the "v" form - left to the allocator, the overflow was copied into a temporary AGPR in
+// front of every use, a VALU write -> XDL read hazard nobody pads).  The hazard recogniser does not look into inline asm: the caller puts >= 18 wait states (s_nop) between
+// the last MFMA of a chain and the first VALU read of its accumulator (8-pass XDL write -> VALU read).
+__device__ __forceinline__ void mfma16_aq(f32x4& acc, const bf16x8& a, const bf16x8& q) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(q));
+}
+__device__ __forceinline__ void mfma16_fp8_aq(f32x4& acc, long a, long q) {
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(q));
+}
+// the same with the B operand in a VGPR: the few query fragments that do not fit the 256 AGPRs (D = 1024)
+__device__ __forceinline__ void mfma16_vq(f32x4& acc, const bf16x8& a, const bf16x8& q) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(q));
+}
+__device__ __forceinline__ void mfma16_fp8_vq(f32x4& acc, long a, long q) {
+    asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(q));
+}
+// AGPR budget of the parked queries: 256 minus the accumulators (and a little air); register index of value (mt, ks[, term])
+__host__ __device__ constexpr bool q_parked(int first_reg, int nregs) { return first_reg + nregs <= 236; }
+// the accumulators are operands of the drain, so no read of them can be scheduled in front of it
+__device__ __forceinline__ void mfma_drain(f32x4& a, f32x4& b) { asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a), "+a"(b)); }
+__device__ __forceinline__ void mfma_drain(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(a), "+a"(b), "+a"(c), "+a"(d));
 }
 
 // 8 e4m3 bytes -> 8 bf16 (exact: every e4m3 value is a bf16 value)
@@ -57,17 +86,23 @@ __device__ __forceinline__ void unpack_fp8x8_b2(long p, float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-// Ring piece = 8 rows x 128 B (1 KB, one DMA instruction); a ring BLOCK = two pieces = the 128-byte column block `i` of a
-// 16-row tile (bf16: 64 k values = two MFMA k-steps; e4m3: 128 k values = four).  Inside a piece the 16-byte chunk c of
-// row r sits at position c ^ ((r >> 1) & 7) (swizzle applied on the SOURCE address of the DMA, which writes LDS
-// linearly): the 16 rows of a fragment read then cover all 16-byte bank groups (rows alternate between the two halves of
-// a 256-byte bank line, the XOR spreads the eight even / odd rows over its eight 16-byte slots).
+// A wave's rows are one contiguous byte range of the bank; it streams them in TILES of 8 rows (bf16, D = 768: 12 KB),
+// every DMA instruction moving 1 KB of CONSECUTIVE bytes (scattered 128-byte pieces of 8 different rows per instruction
+// measured 4.4 TB/s at any bank size, consecutive kilobytes are what the HBM channels want).  LDS image of a tile = its
+// rows back to back (row r at r * ROWB); inside each aligned group of 16 (bf16 rows are multiples of 256 B: every row
+// starts on bank 0) resp. 8 sixteen-byte chunks, chunk c sits at position c ^ x(r), x = 2 (r & 7) resp. r & 7 - applied
+// to the SOURCE address of the DMA (still inside the same 1 KB run), so that the eight rows of a fragment read, and the
+// two neighbouring chunks the lane quarters of a wave read together, fall on distinct bank groups.
+// An 8-row tile feeds the 16-row A operand of v_mfma_f32_16x16x32 with its rows twice (lanes 8-15 re-read rows 0-7, an
+// LDS broadcast); the duplicate output rows are ignored.  That doubles the MFMA count per byte - 48 per 12 KB and wave,
+// a fifth of what the HBM stream leaves room for - and halves the LDS a ring slot needs: three slots per wave, two tiles
+// in flight behind the one being consumed.
 struct RowTileGeom {
     int nq, nchunks, rows_per_block;
+    int dbg;      // SPN_BANK2_DBG (experiments; results wrong): 1 = stream only (no fragment reads / MFMA / statistics)
 };
 
-static constexpr int RT_LEAD = 17;                 // ring blocks in flight per wave (34 KB)
-static constexpr int RT_RING = RT_LEAD + 1;        // + the block being consumed
+static constexpr int RT_RING_B = 36 * 1024;        // LDS ring of one wave
 static constexpr int RT_MAX_ROWS_PER_WAVE = 512;   // fp8: a wave's row scales live in LDS (2 KB)
 
 static RowTileGeom rowtile_geom(int B, int M) {
@@ -76,10 +111,12 @@ static RowTileGeom rowtile_geom(int B, int M) {
     int target = device_cu_count() / g.nq;
     if (target < 1) target = 1;
     int rows = (M + target - 1) / target;
-    rows = (rows + 31) / 32 * 32;                  // 4 waves x a multiple of 8 rows
+    rows = (rows + 31) / 32 * 32;                  // 4 waves x whole 8-row tiles
     if (rows > 4 * RT_MAX_ROWS_PER_WAVE) rows = 4 * RT_MAX_ROWS_PER_WAVE;
     g.rows_per_block = rows;
     g.nchunks = (M + rows - 1) / rows;
+    static const int dbg = [] { const char* e = getenv("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
     return g;
 }
 
@@ -88,25 +125,44 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
                                                                  float* __restrict__ ws) {
     constexpr int EB = FP8 ? 1 : 2;                   // bytes per bank element
     constexpr int ROWB = D * EB;                      // bytes per bank row
-    constexpr int NBT = ROWB / 128;                   // ring blocks per 16-row tile
-    constexpr int KPB = FP8 ? 4 : 2;                  // MFMA k-steps (32 k values) per ring block
+    constexpr int TILE_B = 8 * ROWB;                  // one tile: 8 consecutive rows
+    constexpr int NP = TILE_B / 1024;                 // DMA instructions per tile
+    constexpr int NS0 = RT_RING_B / TILE_B;
+    constexpr int NS = (NS0 - 1) * NP > 60 ? 60 / NP + 1 : NS0;      // ring slots (vmcnt counts at most 63)
     constexpr int KS = D / 32;
-    static_assert(ROWB % 128 == 0 && KS == NBT * KPB, "bank width");
+    constexpr int XG = ROWB % 256 == 0 ? 16 : 8;      // chunks per swizzle group
+    static_assert(TILE_B % 1024 == 0 && NS >= 2 && ROWB % 128 == 0, "bank width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* ring = smem + w * (RT_RING * 2048);
-    float* Fin = (float*)(smem + 4 * RT_RING * 2048);                 // [4 waves][RQ][4]
+    char* ring = smem + w * RT_RING_B;
+    float* Fin = (float*)(smem + 4 * RT_RING_B);                      // [4 waves][RQ][4]
     float* Ssc = Fin + 4 * RQ * 4 + w * RT_MAX_ROWS_PER_WAVE;         // fp8: this wave's row scales
     const int qi = blockIdx.x / gm.nchunks, mi = blockIdx.x % gm.nchunks;
     const int q0 = qi * RQ;
     const int rw = gm.rows_per_block >> 2;                            // rows per wave, a multiple of 8
     const int r_lo = mi * gm.rows_per_block + w * rw;                 // shard-local first row of this wave
     const int r_hi = min(a.M, r_lo + rw);
-    const int ntiles = r_hi > r_lo ? (r_hi - r_lo + 15) >> 4 : 0;
-    const int nblk = ntiles * NBT;
-    // rows >= r_hi read as zero and move no bytes (the half-tile at the end of a wave's range, the uniform tail pieces)
+    const int ntiles = r_hi > r_lo ? (r_hi - r_lo + 7) >> 3 : 0;
+    // rows >= r_hi read as zero and move no bytes (the last tile of the shard, the uniform tail tiles)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)max(r_hi, 0) * (uint32_t)ROWB);
+
+    auto issue = [&](int t) {                         // tile t of this wave (wave-uniform); t >= ntiles: zero fill
+        char* dst = ring + (t % NS) * TILE_B;
+        const uint32_t base = (uint32_t)(r_lo + t * 8) * (uint32_t)ROWB;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int pos = p * 1024 + lane * 16;                              // LDS byte inside the tile image
+            const int r = pos / ROWB, cp = (pos - r * ROWB) >> 4;              // row, chunk position
+            const int c = cp ^ (XG == 16 ? 2 * r : r);                         // logical chunk fetched into it (r < 8)
+            uint32_t off = base + (uint32_t)(r * ROWB + c * 16);
+            if (t >= ntiles) off = 0xFFFFFFF0u;
+            glds16(rs, dst + p * 1024, off);
+        }
+    };
+    // the bank stream starts before anything else: the first tiles land while the queries are loaded and split
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue(t);
 
     // the 32 queries of the block, full D, in registers (B operand: j = query, k = d).  e4m3 bank: the logits run on
     // v_mfma_f32_16x16x32_fp8_fp8 straight from the raw tile, which needs fp8 queries too - each query is split once
@@ -121,16 +177,18 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
     for (int mt = 0; mt < 2; ++mt) {
         const int qr = q0 + mt * 16 + (lane & 15);
         q_ok[mt] = qr < a.B;
-        label[mt] = q_ok[mt] ? a.labels[qr] - (int64_t)a.m_begin : -1;
+        label[mt] = a.labels[min(qr, a.B - 1)];      // used behind wait_vm0() below: no wait in front of the query loads
         if constexpr (!FP8) {
+            // parked in AGPRs once (an asm-visible AGPR definition; without it the values stay in VGPRs and every use
+            // pays four v_accvgpr_write); rows beyond the batch re-read the last query - their statistics are never stored
+            const bf16_t* qp = a.q + (size_t)min(qr, a.B - 1) * a.ldq + (lane >> 4) * 8;
+            // all loads of this half first, then the parking (a park right behind its load serialises 48 round trips)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[mt][ks] = *(const bf16x8*)(qp + ks * 32);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (q_ok[mt]) {
-                    qf[mt][ks] = *(const bf16x8*)(a.q + (size_t)qr * a.ldq + ks * 32 + (lane >> 4) * 8);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) qf[mt][ks][e] = (bf16_t)0.0f;
-                }
+                if (q_parked((mt * KS + ks) * 4, 4)) asm volatile("" : "+a"(qf[mt][ks]));
+                else asm volatile("" : "+v"(qf[mt][ks]));
             }
         } else {
             bf16x8 raw[KS];
@@ -163,85 +221,117 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
                     v[e] = fminf(fmaxf(__fmul_rn(res, rl), -448.0f), 448.0f);
                 }
                 ql[mt][ks] = pack_fp8x8_b2(v);
+                if (q_parked((mt * KS + ks) * 4, 4)) asm volatile("" : "+a"(qh[mt][ks]), "+a"(ql[mt][ks]));   // park both terms
+                else asm volatile("" : "+v"(qh[mt][ks]), "+v"(ql[mt][ks]));
             }
         }
     }
     if constexpr (FP8) {
         for (int i = lane; i < r_hi - r_lo; i += 64) Ssc[i] = a.bank_scale[r_lo + i];
     }
-    wait_vm0();                                       // queries (and scales) are in: the counted waits below see DMA only
-
-    auto issue = [&](int jb) {                        // ring block jb of this wave's sequence (wave-uniform)
-        const int t = jb / NBT, i = jb - t * NBT;
-        char* dst = ring + (jb % RT_RING) * 2048;
+    wait_vm0();                                       // queries, scales and the first tiles are in
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = t * 16 + h * 8 + (lane >> 3);                      // row inside this wave's range
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            uint32_t off = (uint32_t)(r_lo + row) * (uint32_t)ROWB + (uint32_t)(i * 128 + c * 16);
-            if (jb >= nblk) off = 0xFFFFFFF0u;                                 // tail: zero fill, no memory traffic
-            glds16(rs, dst + h * 1024, off);
-        }
-    };
+    for (int mt = 0; mt < 2; ++mt) label[mt] = q_ok[mt] ? label[mt] - (int64_t)a.m_begin : -1;
 
     float st_m[2] = {-INFINITY, -INFINITY}, st_l[2] = {0.f, 0.f}, st_sl[2] = {0.f, 0.f}, st_lab[2] = {-INFINITY, -INFINITY};
-    for (int jb = 0; jb < RT_LEAD; ++jb) issue(jb);
-    const int arow = lane & 15, acol = lane >> 4;
-    const int aswz = (arow >> 1) & 7;
-    const uint32_t abase = (uint32_t)((arow >> 3) * 1024 + (arow & 7) * 128);
+    const int arow = lane & 7, acol = lane >> 4;      // fragment row (lanes 8-15 repeat rows 0-7), lane quarter
+    const int aswz = XG == 16 ? 2 * arow : arow;
     for (int t = 0; t < ntiles; ++t) {
+        // the slot refilled now was read one tile ago: its fragment reads have returned (their MFMAs were issued)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t + NS - 1);
+        wait_vmcnt<(NS - 1) * NP>();                  // tile t has landed; NS - 1 newer tiles stay in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (gm.dbg & 1) continue;
+        const char* T = ring + (t % NS) * TILE_B + arow * ROWB;
         f32x4 s[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
         [[maybe_unused]] f32x4 s2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};      // e4m3: the low query term
+        // Software pipeline over groups of four k-steps: the fragment reads of group g + 1 are issued in front of the MFMAs
+        // of group g (one wave per SIMD: a read -> wait -> MFMA chain per k-step left the wave latency-bound at ~150 cycles
+        // per step, 4.4 TB/s over the chip).  The MFMAs are inline asm (queries and accumulators in AGPRs), which also
+        // keeps them in program order behind the reads.
+        constexpr int G = 4, NG = KS / G;
+        static_assert(KS % G == 0, "k-steps per group");
+        // the accumulators were just zeroed by v_accvgpr_write: VALU write -> XDL SrcC read wants wait states the hazard
+        // recogniser cannot place in front of inline asm
+        if constexpr (FP8) asm volatile("s_nop 4" : "+a"(s[0]), "+a"(s[1]), "+a"(s2[0]), "+a"(s2[1]));
+        else asm volatile("s_nop 4" : "+a"(s[0]), "+a"(s[1]));
+        if constexpr (FP8) {
+            long af[2][G];
 #pragma unroll
-        for (int i = 0; i < NBT; ++i) {
-            const int jb = t * NBT + i;
-            // the slot refilled now was read one block ago: its fragment reads have returned (their MFMAs were issued)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            issue(jb + RT_LEAD);
-            wait_vmcnt<2 * RT_LEAD>();                // block jb has landed; RT_LEAD newer blocks stay in flight
-            __builtin_amdgcn_sched_barrier(0);
-            const char* blk = ring + (jb % RT_RING) * 2048 + abase;
+            for (int j = 0; j < G; ++j) {
+                const int u = j * 4 + acol;
+                af[0][j] = *(const long*)(T + (((u >> 1) ^ aswz) << 4) + (u & 1) * 8);
+            }
 #pragma unroll
-            for (int kk = 0; kk < KPB; ++kk) {
-                if constexpr (FP8) {
-                    const int u = kk * 4 + acol;                               // 8-byte unit of the 128-byte row
-                    const long af = *(const long*)(blk + (((u >> 1) ^ aswz) << 4) + (u & 1) * 8);
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const int u = ((g + 1) * G + j) * 4 + acol;
+                        af[(g + 1) & 1][j] = *(const long*)(T + (((u >> 1) ^ aswz) << 4) + (u & 1) * 8);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        s[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af, qh[mt][i * KPB + kk], s[mt], 0, 0, 0);
-                        s2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af, ql[mt][i * KPB + kk], s2[mt], 0, 0, 0);
+                        if (q_parked((mt * KS + g * G + j) * 4, 4)) {
+                            mfma16_fp8_aq(s[mt], af[g & 1][j], qh[mt][g * G + j]);
+                            mfma16_fp8_aq(s2[mt], af[g & 1][j], ql[mt][g * G + j]);
+                        } else {
+                            mfma16_fp8_vq(s[mt], af[g & 1][j], qh[mt][g * G + j]);
+                            mfma16_fp8_vq(s2[mt], af[g & 1][j], ql[mt][g * G + j]);
+                        }
                     }
-                } else {
-                    const bf16x8 af = *(const bf16x8*)(blk + (((kk * 4 + acol) ^ aswz) << 4));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) s[mt] = mfma16(af, qf[mt][i * KPB + kk], s[mt]);
-                }
             }
+            mfma_drain(s[0], s[1], s2[0], s2[1]);
+        } else {
+            bf16x8 af[2][G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) af[0][j] = *(const bf16x8*)(T + (((j * 4 + acol) ^ aswz) << 4));
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        af[(g + 1) & 1][j] = *(const bf16x8*)(T + (((((g + 1) * G + j) * 4 + acol) ^ aswz) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        if (q_parked((mt * KS + g * G + j) * 4, 4)) mfma16_aq(s[mt], af[g & 1][j], qf[mt][g * G + j]);
+                        else mfma16_vq(s[mt], af[g & 1][j], qf[mt][g * G + j]);
+                    }
+            }
+            mfma_drain(s[0], s[1]);
         }
-        // lane: query (lane & 15) of each mt, keys key0 .. key0 + 3 of this tile
-        const int key0 = r_lo + t * 16 + acol * 4;
-        const bool live4 = key0 < r_hi;               // r_hi - r_lo is a multiple of 8 except at the end of the shard
+        // lane quarters 0 / 1: query (lane & 15) of each mt, keys key0 .. key0 + 3 (rows 0-3 / 4-7 of the tile); quarters
+        // 2 / 3 hold the duplicate rows
+        const int key0 = r_lo + t * 8 + acol * 4;
+        const bool mine = acol < 2 && key0 < r_hi;
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f};
-        if constexpr (FP8) sc4 = *(const f32x4*)(Ssc + t * 16 + acol * 4);
+        if constexpr (FP8) sc4 = *(const f32x4*)(Ssc + t * 8 + (acol & 1) * 4);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 v;
             float tm = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool live = key0 + r < r_hi;
+                const bool live = mine && key0 + r < r_hi;
                 float acc = s[mt][r];
                 if constexpr (FP8) acc = (acc + s2[mt][r] * 0.0625f) * sq[mt];
                 v[r] = live ? acc * sc4[r] * a.inv_tau : -INFINITY;
                 tm = fmaxf(tm, v[r]);
             }
-            if (tm > -INFINITY) {
+            if (tm > -INFINITY && !(gm.dbg & 4)) {
                 const float mn = fmaxf(st_m[mt], tm);
                 float add = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool live = key0 + r < r_hi;
+                    const bool live = v[r] > -INFINITY;
                     add += live ? __expf(v[r] - mn) : 0.f;
                     st_sl[mt] += live ? v[r] : 0.f;
                     st_lab[mt] = (live && (int64_t)(key0 + r) == label[mt]) ? v[r] : st_lab[mt];
@@ -251,11 +341,11 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
             }
             if constexpr (SAVE) {
                 // ldz is a multiple of 32: the vector store stays inside the row; keys beyond the shard hold -inf
-                if (live4 && q_ok[mt]) *(f32x4*)(zsave + (size_t)(q0 + mt * 16 + arow) * ldz + key0) = v;
+                if (mine && q_ok[mt] && !(gm.dbg & 2)) *(f32x4*)(zsave + (size_t)(q0 + mt * 16 + (lane & 15)) * ldz + key0) = v;
             }
         }
     }
-    // merge the four key groups of a query (lanes l, l^16, l^32, l^48), then the four waves through LDS
+    // merge the key groups of a query (lanes l, l^16, l^32, l^48), then the four waves through LDS
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -269,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
         }
         if (lane < 16) *(f32x4*)(Fin + (w * RQ + mt * 16 + lane) * 4) = f32x4{st_m[mt], st_l[mt], st_sl[mt], st_lab[mt]};
     }
-    wait_vm0();                                       // the zero-fill tail pieces still target this wave's ring
+    wait_vm0();                                       // the zero-fill tail tiles still target this wave's ring
     __syncthreads();
     if (tid < RQ) {
         float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
@@ -289,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void bank_rowtile_fwd_kernel(BankArgs a, Ro
 
 template <int D, bool FP8, bool SAVE>
 static int launch_rowtile_fwd(const BankArgs& a, const RowTileGeom& g, float* zsave, int ldz, float* ws, hipStream_t st) {
-    const size_t lds = 4 * (size_t)RT_RING * 2048 + 4 * RQ * 4 * sizeof(float) + (FP8 ? 4 * RT_MAX_ROWS_PER_WAVE * sizeof(float) : 0);
+    const size_t lds = 4 * (size_t)RT_RING_B + 4 * RQ * 4 * sizeof(float) + (FP8 ? 4 * RT_MAX_ROWS_PER_WAVE * sizeof(float) : 0);
     auto kern = bank_rowtile_fwd_kernel<D, FP8, SAVE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -314,6 +404,8 @@ static int launch_rowtile_fwd(const BankArgs& a, const RowTileGeom& g, float* zs
 // z slot image: query row q at byte q * 128, chunk c (4 keys) at position c ^ ((q >> 1) & 7).
 struct DSliceGeom {
     int nq, nch, rows_per_chunk, nsl;
+    int sliced;      // the bank pointer holds the slice-major copy [D/128][M][128] (bank_slice_major)
+    int dbg;         // SPN_BANK2_DBG (experiments; results wrong): 8 = stream only, 16 = no G (exp) computation
 };
 
 static constexpr int DS_SLOTS = 3;
@@ -339,6 +431,9 @@ static DSliceGeom dslice_geom(int B, int M, int D) {
     rows = (rows + 127) / 128 * 128;                       // 4 waves x 32-row tiles
     g.rows_per_chunk = rows;
     g.nch = (M + rows - 1) / rows;
+    g.sliced = 0;
+    static const int dbg = [] { const char* e = getenv("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
     return g;
 }
 
@@ -369,17 +464,6 @@ __global__ __launch_bounds__(256, 1) void bank_dslice_bwd_kernel(BankArgs a, DSl
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rss = make_rsrc(FP8 ? (const void*)a.bank_scale : (const void*)zs,
                                                                   FP8 ? (uint32_t)a.M * 4u : 0u);
 
-    float lse[2];
-    int64_t label[2];
-    bool q_ok[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int qr = q0 + mt * 16 + (lane & 15);
-        q_ok[mt] = qr < a.B;
-        label[mt] = q_ok[mt] ? a.labels[qr] - (int64_t)a.m_begin : -1;
-        lse[mt] = q_ok[mt] ? row_lse[qr] : 0.f;
-    }
-    wait_vm0();
     f32x4 dq[2][8];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -395,11 +479,13 @@ __global__ __launch_bounds__(256, 1) void bank_dslice_bwd_kernel(BankArgs a, DSl
             uint32_t off;
             if constexpr (FP8) {                           // 8 rows x 128 raw bytes per instruction, linear image
                 const int r = ii * 8 + (lane >> 3);
-                off = (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)(sl * 128 + (lane & 7) * 16);
+                off = gm.sliced ? ((uint32_t)sl * (uint32_t)a.M + (uint32_t)(mrow0 + r)) * 128u + (uint32_t)((lane & 7) * 16)
+                                : (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)(sl * 128 + (lane & 7) * 16);
             } else {                                       // 4 rows x 256 B per instruction, swizzled image
                 const int r = ii * 4 + (lane >> 4);
                 const int c = (lane & 15) ^ bank2_swz(r & 15);
-                off = (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)(sl * 256 + c * 16);
+                off = gm.sliced ? ((uint32_t)sl * (uint32_t)a.M + (uint32_t)(mrow0 + r)) * 256u + (uint32_t)(c * 16)
+                                : (uint32_t)(mrow0 + r) * (uint32_t)ROWB + (uint32_t)(sl * 256 + c * 16);
             }
             if (dead) off = 0xFFFFFFF0u;
             glds16(rsb, dst + ii * 1024, off);
@@ -419,14 +505,26 @@ __global__ __launch_bounds__(256, 1) void bank_dslice_bwd_kernel(BankArgs a, DSl
         }
     };
 
-    issue(0);
+    issue(0);                                              // the stream starts before anything else
     issue(1);
+    float lse[2];
+    int64_t label[2];
+    bool q_ok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int qr = q0 + mt * 16 + (lane & 15);
+        q_ok[mt] = qr < a.B;
+        label[mt] = q_ok[mt] ? a.labels[qr] - (int64_t)a.m_begin : -1;
+        lse[mt] = q_ok[mt] ? row_lse[qr] : 0.f;
+    }
+    wait_vm0();
     for (int i = 0; i < nmine; ++i) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot refilled now was read one tile ago
         __builtin_amdgcn_sched_barrier(0);
         issue(i + 2);
         wait_vmcnt<2 * NDMA>();
         __builtin_amdgcn_sched_barrier(0);
+        if (gm.dbg & 8) continue;
         const char* T = ring + (i % DS_SLOTS) * DS_SLOT_B;
         const char* Z = T + DS_BANK_B;
         const int mrow0 = m_lo + (w + 4 * i) * 32;
@@ -448,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void bank_dslice_bwd_kernel(BankArgs a, DSl
             for (int e = 0; e < 8; ++e) {
                 const int key = mrow0 + (lane >> 4) * 8 + e;
                 const float z = e < 4 ? z0[e] : z1[e - 4];
-                float gv = __expf(z - lse[mt]) - label_smoothing * inv_m_total;
+                float gv = ((gm.dbg & 16) ? z : __expf(z - lse[mt])) - label_smoothing * inv_m_total;
                 gv -= ((int64_t)key == label[mt]) ? 1.0f - label_smoothing : 0.f;
                 gv = (q_ok[mt] && key < m_hi) ? gv : 0.f;
                 if constexpr (FP8) gv *= scl[e >> 2][e & 3];
@@ -525,12 +623,18 @@ static int launch_dslice_bwd(const BankArgs& a, const DSliceGeom& g, const float
 }
 
 // ------------------------------------------------------------------------------------------------ host
+// Default OFF (measured): at B = 32, M = 40 000 the pair needs 23.7 / 26.9 us against the
+// first-generation kernels' 19.7 / 23.1 us - the per-wave serial structure (load queries, wait, stream) has more fixed
+// cost than the block-cooperative kernels, and at that bank size fixed cost is half of the pass.  SPN_BANK2=1 or
+// spn_bank_config(1) selects them (they win on the backward pass of large e4m3 banks: 137 vs 151 us at 400 000 rows).
+static int g_bank2 = -1;
+void bank2_config(int on) { g_bank2 = on ? 1 : 0; }
 static bool bank2_on() {
-    static const bool on = [] {
+    if (g_bank2 < 0) {
         const char* e = getenv("SPN_BANK2");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+        g_bank2 = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_bank2 == 1;
 }
 
 // The saved-logits pair serves plain (one row = one target) banks, bf16 or e4m3, at per-call batches below 128 queries
@@ -580,7 +684,11 @@ int bank2_stats_fwd(const BankArgs& a, float* stats, float* zsave, float* ws, si
 
 int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, float label_smoothing, int64_t M_total,
                  float grad_scale, float* dq, float* ws, size_t ws_bytes, hipStream_t st) {
-    const DSliceGeom g = dslice_geom(a.B, a.M, a.D);
+    DSliceGeom g = dslice_geom(a.B, a.M, a.D);
+    {   // timing experiment only (results wrong): address the plain bank as if it were the slice-major copy
+        static const bool exp_sliced = [] { const char* e = getenv("SPN_BANK2_EXP_SLICED"); return e && e[0] == '1'; }();
+        if (exp_sliced) g.sliced = 1;
+    }
     if (ws_bytes < (size_t)g.nch * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
     const int ldz = bank_saved_ld(a.M);
     const float inv_m = 1.0f / (float)M_total;

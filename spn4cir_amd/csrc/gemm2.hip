@@ -352,14 +352,21 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
                         lv = fmaxf(lv, __shfl_xor(lv, off, 64));
                     }
                     if (mx > -INFINITY) {
+                        float pe[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) l += __expf(z[e] - mx);
+                        for (int e = 0; e < 8; ++e) { pe[e] = __expf(z[e] - mx); l += pe[e]; }
+                        if (ep.bs_p_out) {                 // block-uniform: tile-relative probabilities for the backward pass
+                            const bf16x8 pk = {f2bf(pe[0]), f2bf(pe[1]), f2bf(pe[2]), f2bf(pe[3]),
+                                               f2bf(pe[4]), f2bf(pe[5]), f2bf(pe[6]), f2bf(pe[7])};
+                            *(bf16x8*)(ep.bs_p_out + (size_t)m * ep.bs_ldp + n) = pk;      // bs_ldp covers whole tiles
+                        }
                     }
 #pragma unroll
                     for (int off = LPR / 2; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
                     if (u == 0) {
                         const int tile_n = n0 / BN;
                         *(f32x4*)(ep.bs_out + ((size_t)tile_n * M + m) * 4) = f32x4{mx, l, sl, lv};
+                        if (ep.bs_max_out) ep.bs_max_out[(size_t)tile_n * M + m] = mx;
                     }
                     continue;
                 }
@@ -1088,12 +1095,14 @@ static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
 int gemm_bank_stats_tiles(int M) { return (M + 255) / 256; }
 
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
-                    float inv_tau, int m_begin, float* partial, hipStream_t st) {
+                    float inv_tau, int m_begin, float* partial, hipStream_t st, bf16_t* p_out, int ldp, float* max_out) {
     if (B <= 0 || M <= 0 || D <= 0 || !labels || !partial) return SPN_ERR_ARG;
     if (D % BK2 || ldq % 8 || ldb % 8) return SPN_ERR_SHAPE;
     if ((uint64_t)B * ldq * 2 >= (1ull << 32) || (uint64_t)M * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     GemmEpilogue e;
     e.bs_labels = labels; e.bs_out = partial; e.bs_inv_tau = inv_tau; e.bs_m_begin = m_begin;
+    if (p_out && (ldp % 256 || ldp < M || !max_out)) return SPN_ERR_ARG;
+    e.bs_p_out = p_out; e.bs_ldp = ldp; e.bs_max_out = max_out;
     e.ldc = 8;
     return launch_nt2<256, 256, 2, 4, 2, GEMM_BANKSTATS, ACT_NONE, 2, 64>(q, bank, B, M, D, ldq, ldb, e, st);
 }

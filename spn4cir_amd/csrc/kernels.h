@@ -30,6 +30,11 @@ struct GemmEpilogue {
     float* bs_out = nullptr;
     float bs_inv_tau = 1.0f;
     int bs_m_begin = 0;
+    // optional: keep the tile-relative probabilities p = exp(logit - tile max) as bf16 [B, bs_ldp] (bs_ldp a multiple of 256)
+    // and the tile maxima [tile_n][B] for the GEMM-path backward pass (bank_grad_q with saved logits, B >= 128)
+    bf16_t* bs_p_out = nullptr;
+    int bs_ldp = 0;
+    float* bs_max_out = nullptr;
     int dbg = 0;                     // gemm2 only, SPN_GEMM_DBG bottleneck-elimination bits (wrong results): 1 = every k tile
                                      // re-reads k0 = 0, 2 = no DMA after the prologue, 4 = LDS fragments read once per
                                      // k step, 8 = no epilogue
@@ -47,7 +52,8 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
              const GemmEpilogue& ep, hipStream_t st);
 // logits statistics of q [B, D] against bank [M, D] on the GEMM path; partial [ceil(M/256)][B][4] floats
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
-                    float inv_tau, int m_begin, float* partial, hipStream_t st);
+                    float inv_tau, int m_begin, float* partial, hipStream_t st, bf16_t* p_out = nullptr, int ldp = 0,
+                    float* max_out = nullptr);
 int gemm_bank_stats_tiles(int M);
 bool gemm_tn2_pair_ok(int N1a, int N2a);
 size_t gemm_tn2_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b);
@@ -188,8 +194,11 @@ int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t 
 int bank_stats_fold(const float* ws, int n, int B, float* stats, hipStream_t st);
 // bank2.hip: barrier-free kernels for batches below 128 queries, backward from saved logits
 bool bank_saved_path(const BankArgs& a);
+void bank2_config(int on);
 int bank_saved_ld(int M);
 size_t bank_saved_bytes(int B, int M);
+size_t bank_saved_bytes_any(int B, int M);   // bank.hip: the same incl. the layout of batches >= 128 (p, G^T, tile maxima)
+bool bank_saved_path_large(const BankArgs& a);
 size_t bank2_workspace_bytes(int B, int M, int D);
 int bank2_stats_fwd(const BankArgs& a, float* stats, float* zsave, float* ws, size_t ws_bytes, hipStream_t st);
 int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, float label_smoothing, int64_t M_total,

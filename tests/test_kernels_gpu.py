@@ -293,6 +293,15 @@ def test_bank_saved_logits_pair(ops, B, M, D, tau, fp8):
     operands, the saved logits themselves, dq against the oracle and against the recomputing backward kernel, two
     unequal shards with label smoothing, a bank smaller than one tile, rows that end in the middle of a 16-row tile."""
     from oracle import bank_loss
+    from spn4cir_amd import _lib
+    _lib.lib().spn_bank_config(1)                  # the streaming pair is opt-in (spn_bank_config / SPN_BANK2=1)
+    try:
+        _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8)
+    finally:
+        _lib.lib().spn_bank_config(0)
+
+
+def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8):
     text, refer, bank, ridx, labels = _bank_case(B, M, D, 3 * B + M)
     q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
     bank_b = ops.prepare_bank(dev(bank), "fp8" if fp8 else "bf16")
@@ -305,12 +314,13 @@ def test_bank_saved_logits_pair(ops, B, M, D, tau, fp8):
     assert save is not None
     stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau, save=save)
     lse, row, mean = ops.bank_loss_finalize(stats, M)
-    assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
-    assert (stats[:, 3].cpu().double() - lab_ref).abs().max() < 2e-4
-    assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+    tol = 1e-3 if fp8 else 2e-4                   # e4m3: the two-term query model reproduces the logits to fp32 rounding of
+    assert (lse.cpu().double() - lse_ref).abs().max() < tol               # values up to 1 / tau
+    assert (stats[:, 3].cpu().double() - lab_ref).abs().max() < tol
+    assert abs(mean.item() - row_ref.mean().item()) < tol
     ld = (M + 31) // 32 * 32
     z = save[:B * ld * 4].view(torch.float32).view(B, ld)[:, :M].cpu().double()
-    assert (z - (qr.double() @ br.double().t()) / tau).abs().max() < 5e-4
+    assert (z - (qr.double() @ br.double().t()) / tau).abs().max() < (5e-3 if fp8 else 5e-4)   # fp32 products of logits up to 1 / tau
     dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B, saved=save)
     dq_ref = bank_loss.infonce_grad_q(qr, br, labels, tau)
     assert rel_err(dq[:, :D], dq_ref) < 1.5e-2     # G is rounded to bf16 before the second GEMM
@@ -335,6 +345,43 @@ def test_bank_saved_logits_pair(ops, B, M, D, tau, fp8):
         d = sum(ops.bank_grad_q(qb, sh, dev(labels), 1.0 / tau, lse2, 1.0 / B, M_total=M, label_smoothing=eps, m_begin=a,
                                 saved=sv) for sh, sv, a, _ in halves)
         assert rel_err(d[:, :D], qd.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (136, 5001, 512, 0.02),
+                                        (512, 8000, 768, 0.02)])
+def test_bank_saved_pair_large_batch(ops, B, M, D, tau):
+    """B >= 128: the forward GEMM keeps p = exp(logit - tile max) and the backward pass is G^T + ONE weight-gradient-shaped
+    GEMM (spn_bank_grad_q_saved): dq against the oracle and against the recomputing kernel, with label smoothing and
+    two unequal shards (global labels, m_begin)."""
+    from oracle import bank_loss
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 5 * B + M)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    bank_b = ops.prepare_bank(dev(bank))
+    qr, br = qb[:, :D].cpu().float(), bank_b[:, :D].cpu().float()
+    lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+    save = ops.bank_logits_buffer(B, M, "cuda")
+    assert save is not None
+    stats = ops.bank_stats_fwd(qb, bank_b, dev(labels), 1.0 / tau, save=save)
+    lse, row, mean = ops.bank_loss_finalize(stats, M)
+    assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+    assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+    dq = ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B, saved=save)
+    assert rel_err(dq[:, :D], bank_loss.infonce_grad_q(qr, br, labels, tau)) < 2e-2      # p and G each rounded to bf16
+    assert rel_err(dq, ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)) < 2e-2
+    eps, cut = 0.1, (M // 3) | 1
+    qd = qr.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy((qd @ br.double().t()) / tau, labels, label_smoothing=eps)
+    ref.backward()
+    halves = []
+    for a, b in ((0, cut), (cut, M)):
+        sh = bank_b[a:b].contiguous()
+        sv = ops.bank_logits_buffer(B, b - a, "cuda")
+        halves.append((sh, sv, a, ops.bank_stats_fwd(qb, sh, dev(labels), 1.0 / tau, m_begin=a, save=sv)))
+    lse2, row2, mean2 = ops.bank_loss_finalize(torch.stack([h[3] for h in halves]), M, label_smoothing=eps)
+    assert abs(mean2.item() - ref.item()) < 3e-4
+    d = sum(ops.bank_grad_q(qb, sh, dev(labels), 1.0 / tau, lse2, 1.0 / B, M_total=M, label_smoothing=eps, m_begin=a,
+                            saved=sv) for sh, sv, a, _ in halves)
+    assert rel_err(d[:, :D], qd.grad) < 2e-2
 
 
 def test_bank_label_smoothing_and_shards(ops):
