@@ -57,7 +57,12 @@ def parse():
     p.add_argument("--bank", type=int, default=40000)
     p.add_argument("--model", default="ViT-L/14")
     p.add_argument("--tau", type=float, default=0.02)
-    p.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
+    p.add_argument("--bank-mode", default="auto", choices=["auto", "sharded", "replicated"],
+                   help="N > 1: how the bank loss is parallelised (DESIGN.md section 6).  auto = replicated below 10^6 bank rows "
+                        "(no data-path collective: at M = 40 000 the sharded variant puts three latency-bound collectives on the "
+                        "critical path to save ~40 us of bank kernel), sharded above (north_star's all-gather of queries)")
+    p.add_argument("--no-alt-bank-mode", action="store_true",
+                   help="N > 1: skip the short extra measurement of the OTHER bank mode reported as bank_mode_alt")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
     p.add_argument("--prof-every", type=int, default=5,
@@ -238,6 +243,8 @@ def main():
     sd = synthetic.text_state_dict(W, layers, D, seed=0)
     model = CIRPlus(sd, tau=args.tau, device=dev, plus=True)
     target, refer = synthetic.banks(args.bank, D, seed=2)
+    if args.bank_mode == "auto":
+        args.bank_mode = "replicated" if args.bank < 1000000 else "sharded"
     trainer = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode)
     trainer.set_banks(refer, target)
 
@@ -311,6 +318,27 @@ def main():
                   "ms_per_step": round(dtp.item() / args.steps * 1e3, 3), "live_rows_rank0": total,
                   "dense_rows_per_rank": B * ids.shape[1], "loss_last": round(float(lp.item()), 5),
                   "note": "optional TextTower packed mode (pack_eot); not the headline value"}
+
+    # N > 1: the other bank mode, measured briefly with the same barrier / max-over-ranks protocol (not the headline)
+    alt = None
+    if (world > 1 or force_dp) and not args.no_alt_bank_mode:
+        other = "sharded" if args.bank_mode == "replicated" else "replicated"
+        tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other)
+        tr2.set_banks(refer, target)
+        for _ in range(max(2, args.warmup)):
+            tr2.step(ids, ridx, labels)
+        barrier()
+        t0 = time.perf_counter()
+        n_alt = max(5, args.steps // 2)
+        for _ in range(n_alt):
+            tr2.step(ids, ridx, labels)
+        barrier()
+        dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+        alt = {"bank_mode": other, "value": round(B_global * n_alt / dta.item(), 1), "unit": "triplets/sec",
+               "ms_per_step": round(dta.item() / n_alt * 1e3, 3), "steps": n_alt}
+        del tr2
 
     if rank == 0:
         per_kernel = {}
@@ -387,6 +415,8 @@ def main():
         out.update(extra)
         if packed:
             out["packed_eot"] = packed
+        if alt:
+            out["bank_mode_alt"] = alt
         if not args.no_recall:
             rec = recall_block(args, sd, model, dev)
             if rec:

@@ -42,13 +42,24 @@ def shard_range(total, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+_gather_bufs = {}
+
+
 def all_gather_cat(x, group=None):
+    """Concatenation of every rank's x along dim 0 (equal shapes on all ranks), gathered by ONE collective straight into a
+    preallocated [world * n, ...] buffer (all_gather_into_tensor: no per-rank temporaries, no torch.cat pass).  The buffer
+    is cached per (shape, dtype, device, group) and reused by the next step's call with the same key: callers consume the
+    result inside the step (the bank kernels read it before the next forward overwrites it)."""
     world, _ = _world(group)
     if _skip(world):
         return x
-    out = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(out, x.contiguous(), group=group)
-    return torch.cat(out, dim=0)
+    x = x.contiguous()
+    key = (tuple(x.shape), x.dtype, str(x.device), id(group))
+    out = _gather_bufs.get(key)
+    if out is None:
+        out = _gather_bufs[key] = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
 
 
 def reduce_scatter_rows(x, group=None):
