@@ -213,6 +213,28 @@ def recall_block(args, sd, model, dev):
                       f"exact tower {exact_s * 1e3:.0f} ms on the GPU"}
 
 
+def collect_kernels(lib, n_steps, rows, W):
+    """kernels[] entries from the library's HIP-event records (spn_prof_*), after n_steps steps with every class timed."""
+    ks = []
+    for kid, (name, bound) in KERNELS.items():
+        ms, work, n = C.c_double(), C.c_double(), C.c_int()
+        lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(n))
+        if not n.value:
+            continue
+        w = work.value
+        if kid in (2, 3):     # the profiler counts flops for attention; price it on bytes (see KERNELS)
+            w = n.value * float(rows) * W * 2.0 * (4 if kid == 2 else 8)
+        rate = w / (ms.value * 1e-3)
+        ent = {"kernel": name, "bound": bound, "launches_per_step": n.value // max(1, n_steps),
+               "avg_us": round(ms.value / n.value * 1e3, 1), "ms_per_step": round(ms.value / max(1, n_steps), 3)}
+        if bound == "mfma":
+            ent.update(achieved=round(rate / 1e12, 1), unit="TFLOP/s", frac=round(rate / 1e12 / PEAK_BF16_TFLOPS, 4))
+        else:
+            ent.update(achieved=round(rate / 1e9, 1), unit="GB/s", frac=round(rate / 1e9 / PEAK_HBM_GBS, 4))
+        ks.append(ent)
+    return ks
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -291,6 +313,12 @@ def main():
             trainer.step(ids, ridx, labels)
         torch.cuda.synchronize()
         lib.spn_prof_disable()
+        dense_raw = {}
+        for kid in KERNELS:                   # collected now: the packed pass below reuses the recorder
+            ms, work, n = C.c_double(), C.c_double(), C.c_int()
+            lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(n))
+            dense_raw[kid] = (ms.value, work.value, n.value)
+        lib.spn_prof_reset()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -318,6 +346,16 @@ def main():
                   "ms_per_step": round(dtp.item() / args.steps * 1e3, 3), "live_rows_rank0": total,
                   "dense_rows_per_rank": B * ids.shape[1], "loss_last": round(float(lp.item()), 5),
                   "note": "optional TextTower packed mode (pack_eot); not the headline value"}
+        if prof and rank == 0:
+            # the same per-class breakdown for the packed step (rocprofv3 table: profiles/r03_packed_kernel_stats.txt)
+            lib.spn_prof_enable(max(64, 200 * args.kernel_pass_steps))
+            lib.spn_prof_select(0xFFFFFFFF, 1)
+            for _ in range(args.kernel_pass_steps):
+                trainer.step(ids, ridx, labels, cu, total)
+            torch.cuda.synchronize()
+            lib.spn_prof_disable()
+            packed["kernels"] = collect_kernels(lib, args.kernel_pass_steps, total, W)
+            lib.spn_prof_reset()
 
     # N > 1: the other bank mode, measured briefly with the same barrier / max-over-ranks protocol (not the headline)
     alt = None
@@ -344,14 +382,13 @@ def main():
         per_kernel = {}
         if prof:
             for kid, (name, bound) in KERNELS.items():
-                ms, work, n = C.c_double(), C.c_double(), C.c_int()
-                lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(n))
-                if n.value:
-                    w = work.value
+                msv, workv, nv = dense_raw[kid]
+                if nv:
+                    w = workv
                     if kid in (2, 3):     # the profiler counts flops for attention; price it on bytes (see KERNELS)
-                        w = n.value * float(B * ids.shape[1]) * W * 2.0 * (4 if kid == 2 else 8)
-                    per_kernel[kid] = dict(kernel=name, bound=bound, launches=n.value, total_ms=ms.value,
-                                           avg_us=ms.value / n.value * 1e3, work=w)
+                        w = nv * float(B * ids.shape[1]) * W * 2.0 * (4 if kid == 2 else 8)
+                    per_kernel[kid] = dict(kernel=name, bound=bound, launches=nv, total_ms=msv,
+                                           avg_us=msv / nv * 1e3, work=w)
         roof = None
         extra = {}
         pass_ms = None

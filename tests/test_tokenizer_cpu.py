@@ -32,6 +32,21 @@ def test_tokenizer_matches_reference(golden_dir):
     assert tok.encode("is red and has long sleeves") == e[:-1]
 
 
+def test_tokenizer_more_captions_match_reference(golden_dir):
+    """40 more captions + one truncated one, ids captured from the reference's clip.tokenize
+    (tests/golden/make_golden_tokenizer.py): punctuation runs, digits, apostrophes, html entities, non-ASCII, whitespace."""
+    import json
+    from spn4cir_amd.tokenizer import ClipTokenizer
+    z = np.load(os.path.join(golden_dir, "tokenizer_more.npz"))
+    captions = json.loads(str(z["captions"]))
+    assert len(captions) >= 40
+    tok = ClipTokenizer()
+    got = tok(captions).numpy()
+    bad = [c for c, a, b in zip(captions, got, z["ids"]) if not np.array_equal(a, b)]
+    assert not bad, bad
+    assert np.array_equal(tok(json.loads(str(z["long_caption"])), truncate=True).numpy(), z["long_ids"])
+
+
 @pytest.mark.skipif(not os.path.exists("/root/reference/clip4cir/clip/simple_tokenizer.py"), reason="reference absent")
 def test_tokenizer_fuzz_against_reference():
     """In the build container only: random caption-like strings through both tokenizers."""
