@@ -1199,7 +1199,8 @@ struct TnSecond {
 template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
 __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int Kr, int N1, int N2,
                                          int lda, int ldb, float* __restrict__ Cz, int ldc, float* __restrict__ colsum_out,
-                                         int m0, int n0, int kb, int ke) {
+                                         int m0, int n0, int kb, int ke, uint32_t* pace = nullptr,
+                                         uint32_t pace_members = 0) {
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
@@ -1258,7 +1259,34 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
         wait_chunks(nk > 1);
         __builtin_amdgcn_s_barrier();
         if (wr == 1) __builtin_amdgcn_s_barrier();
+        // k pacing (grouped launch): the workgroups of one XCD round share A / B panels through that XCD's 4 MB L2, which
+        // only works while they read the same k range at about the same time - over 308 k tiles they drift apart and
+        // every tile ends up streaming its own panels from HBM (2.4x the algorithmic bytes, PMC FETCH_SIZE).  Every
+        // PACE_R k tiles wave 0 adds one to the group's counter (fire and forget) and loads it; ONE k tile later it looks
+        // at the loaded value (long since back: the check costs no stall) and holds the workgroup - the other waves
+        // stop at the next slot barrier - until every member has reached the previous phase: the spread stays below
+        // 2 PACE_R k tiles.  Correctness never depends on it (bounded spin; dispatch order makes every member resident
+        // before any later block needs a CU).
+        constexpr int PACE_R = 2;
+        uint32_t pace_val = 0;
         for (int kt = 0; kt < nk; ++kt) {
+            if (pace != nullptr && wid == 0) {
+                if ((kt & (PACE_R - 1)) == 0) {
+                    if (lane == 0) {
+                        __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pace_val = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if ((kt & (PACE_R - 1)) == 1 && kt > PACE_R) {
+                    const uint32_t target = pace_members * (uint32_t)(kt / PACE_R);
+                    uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace_val);
+                    for (int tries = 0; v < target && tries < 20000; ++tries) {
+                        __builtin_amdgcn_s_sleep(8);
+                        uint32_t x = 0;
+                        if (lane == 0) x = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+                    }
+                }
+            }
             const char* sA = smem + (kt & 1) * STAGE;
             const char* sB = sA + A_BYTES;
             const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
@@ -1435,6 +1463,7 @@ struct TnGroup {
     int n;
     int full, tail, tail_splits, k_chunk;   // tiles [0, full) unsplit; [full, full + tail) split over the reduction
     float* slabs;                            // [tail_splits][tail][256*256] partial tiles, then [tail_splits][tail][256] column sums
+    uint32_t* pace;                          // k pacing counters, one 128-byte line per (XCD, round) of whole tiles; NULL = off
 };
 
 __device__ __forceinline__ int tn_group_find(const TnGroup& g, int tile) {
@@ -1463,7 +1492,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_group_ker
     const int bid = tile - g.tile_begin[pi];
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
     if (whole) {
-        tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, P.C, P.ldc, P.colsum, m0, n0, 0, Kr);
+        // pace group = the 32 whole tiles one XCD runs in one round (block b sits on XCD b % 8, in dispatch order)
+        uint32_t* pace = g.pace ? g.pace + (size_t)((((int)blockIdx.x >> 3) / 32) * 8 + ((int)blockIdx.x & 7)) * 32 : nullptr;
+        tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, P.C, P.ldc, P.colsum, m0, n0, 0, Kr, pace,
+                                                32u);
     } else {
         // slab of (z, tail tile): a dense [BM][BN] tile; the pointers are biased so that the tile's own (m0, n0) indexing of
         // a [*, BN] matrix lands in it (never dereferenced outside the slab: rows / columns beyond N1 / N2 are masked)
@@ -1629,9 +1661,23 @@ int device_cu_count() {
     return n;
 }
 
+static constexpr size_t TN_PACE_BYTES = 64 * 1024;          // pacing counters: 128 B per (XCD, round), <= 512 groups
+
+// SPN_TN_PACE=1 turns the k pacing of the grouped launch on.  Default OFF, measured (round 3, same box, bench step):
+// without 13.32 ms / step, grouped launch 1 243 TFLOP/s; with 14.29 ms, 882 TFLOP/s.  The tiles of a group are not equally
+// fast - the n0 == 0 tiles carry the bias-gradient MFMAs (+25 % matrix work) - and pacing holds all 32 to the slowest; what
+// the shared panels save in L2 misses is less than what the fast tiles lose waiting.
+static bool tn_pace_on() {
+    static const bool on = [] {
+        const char* e = getenv("SPN_TN_PACE");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 size_t gemm_tn_grouped_workspace_bytes(int Kr) {
     (void)Kr;
-    return (size_t)device_cu_count() * (256 * 256 + 256) * sizeof(float);      // at most one slab per CU
+    return (size_t)device_cu_count() * (256 * 256 + 256) * sizeof(float) + TN_PACE_BYTES;   // at most one slab per CU
 }
 
 int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st) {
@@ -1666,9 +1712,16 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
     g.k_chunk = ((ktiles + splits - 1) / splits) * BK2;
     g.tail_splits = tail ? (Kr + g.k_chunk - 1) / g.k_chunk : 1;
     g.slabs = ws;
-    if (tail) {
-        const size_t need = (size_t)g.tail_splits * tail * (256 * 256 + 256) * sizeof(float);
-        if (!ws || ws_bytes < need) return SPN_ERR_WORKSPACE;
+    const size_t slab_bytes = tail ? (size_t)g.tail_splits * tail * (256 * 256 + 256) * sizeof(float) : 0;
+    if (tail && (!ws || ws_bytes < slab_bytes)) return SPN_ERR_WORKSPACE;
+    // k pacing of the whole tiles: needs every round of an XCD to be 32 tiles (full is a multiple of the CU count), at least
+    // two of them sharing panels to be worth it, and room for the counters behind the slabs
+    g.pace = nullptr;
+    const int groups = (g.full / cus) * 8;
+    if (tn_pace_on() && cus == 256 && g.full >= cus && ws && ws_bytes >= slab_bytes + TN_PACE_BYTES &&
+        (size_t)groups * 128 <= TN_PACE_BYTES) {
+        g.pace = (uint32_t*)((char*)ws + ((slab_bytes + 255) & ~(size_t)255));
+        if (hipMemsetAsync(g.pace, 0, (size_t)groups * 128, st) != hipSuccess) g.pace = nullptr;
     }
     constexpr int LDS = 2 * (256 + 256) * 128;
     auto kern = gemm_tn2_group_kernel<256, 256, 2, 4, 2, 2>;
