@@ -276,6 +276,9 @@ def main():
     ridx_all, lab_all = synthetic.triplet_indices(B_global, args.bank, seed=4)
     sl = slice(rank * B, (rank + 1) * B)
     ids, ridx, labels = ids_all[sl].to(dev), ridx_all[sl].to(dev), lab_all[sl].to(dev)
+    # N > 1: the host copy of this rank's ids lets the trainer exchange the token-embedding gradient as touched rows
+    # (SparseRowReducer) instead of a dense 152 MB all-reduce; a training loop has them on the host anyway (tokenizer output)
+    ids_host = ids_all[sl].contiguous() if (world > 1 or force_dp) and os.environ.get("SPN_DENSE_EMBED_ALLREDUCE") != "1" else None
 
     def barrier():
         if world > 1 or force_dp:
@@ -284,7 +287,7 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = trainer.step(ids, ridx, labels)
+        loss = trainer.step(ids, ridx, labels, ids_host=ids_host)
     lib = _lib.lib()
     prof = not args.no_prof
     # Live roofline measurement: HIP-event pairs around the launches of the DOMINANT kernel (gemm_nt, checked
@@ -299,7 +302,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(ids, ridx, labels)
+        loss = trainer.step(ids, ridx, labels, ids_host=ids_host)
     barrier()
     dt = time.perf_counter() - t0
     dom_rec = None
@@ -310,7 +313,7 @@ def main():
         lib.spn_prof_reset()
         lib.spn_prof_select(0xFFFFFFFF, 1)
         for _ in range(args.kernel_pass_steps):
-            trainer.step(ids, ridx, labels)
+            trainer.step(ids, ridx, labels, ids_host=ids_host)
         torch.cuda.synchronize()
         lib.spn_prof_disable()
         dense_raw = {}
@@ -333,11 +336,11 @@ def main():
         cu, total = trainer.tower.cu_seqlens(ids_all[sl])
         cu = cu.to(dev)
         for _ in range(max(2, args.warmup)):
-            lp = trainer.step(ids, ridx, labels, cu, total)
+            lp = trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            lp = trainer.step(ids, ridx, labels, cu, total)
+            lp = trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
         barrier()
         dtp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
@@ -346,12 +349,13 @@ def main():
                   "ms_per_step": round(dtp.item() / args.steps * 1e3, 3), "live_rows_rank0": total,
                   "dense_rows_per_rank": B * ids.shape[1], "loss_last": round(float(lp.item()), 5),
                   "note": "optional TextTower packed mode (pack_eot); not the headline value"}
-        if prof and rank == 0:
-            # the same per-class breakdown for the packed step (rocprofv3 table: profiles/r03_packed_kernel_stats.txt)
+        if prof:
+            # the same per-class breakdown for the packed step (rocprofv3 table: profiles/r03_packed_kernel_stats.txt);
+            # every rank runs the steps (they contain collectives), rank 0 reports its records
             lib.spn_prof_enable(max(64, 200 * args.kernel_pass_steps))
             lib.spn_prof_select(0xFFFFFFFF, 1)
             for _ in range(args.kernel_pass_steps):
-                trainer.step(ids, ridx, labels, cu, total)
+                trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
             torch.cuda.synchronize()
             lib.spn_prof_disable()
             packed["kernels"] = collect_kernels(lib, args.kernel_pass_steps, total, W)
@@ -364,12 +368,12 @@ def main():
         tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other)
         tr2.set_banks(refer, target)
         for _ in range(max(2, args.warmup)):
-            tr2.step(ids, ridx, labels)
+            tr2.step(ids, ridx, labels, ids_host=ids_host)
         barrier()
         t0 = time.perf_counter()
         n_alt = max(5, args.steps // 2)
         for _ in range(n_alt):
-            tr2.step(ids, ridx, labels)
+            tr2.step(ids, ridx, labels, ids_host=ids_host)
         barrier()
         dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:

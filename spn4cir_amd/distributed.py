@@ -126,6 +126,84 @@ class BankLossDP:
         return dq
 
 
+class SparseRowReducer:
+    """Sum over ranks of a [V, W] gradient whose non-zero rows every rank can name on the HOST before the step runs: the
+    token-embedding gradient (38 M of ViT-L/14's 124 M text parameters, 152 MB in fp32) is zero outside the rows of the
+    token ids of the rank's own captions - a few thousand of 49 408.  A dense all-reduce of it is a third of all gradient
+    bytes and, being final only when backward ends, the one bucket that cannot hide behind it.  Here instead:
+
+      plan(ids_host)   host only, before any device work of the step is enqueued: unique ids of this rank, exchanged with
+                       the other ranks over a CPU (gloo) group - two tiny collectives, no device synchronisation, the
+                       device is still busy with the previous step;
+      start(grad)      behind the kernels that finish the gradient: this rank's U rows are gathered into a [cap, W] send
+                       buffer (cap = the largest U of any rank) and ONE all-gather moves them (async);
+      finish(grad)     wait; the other ranks' rows are added into this rank's gradient (index_add_).
+
+    Per rank (G - 1) * cap * W * 4 bytes arrive (G = 8, cap = 5.3 k, W = 768: 114 MB) against the 2 (G - 1) / G * 152 MB
+    = 266 MB a ring all-reduce of the dense matrix moves; with real captions (a vocabulary of a few thousand words) the
+    gap is far larger.  Summation order differs from an all-reduce only in the order of G addends per element."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.host_group = None
+        if not _skip(self.world) and dist.get_backend(group) != "gloo":
+            self.host_group = dist.new_group(backend="gloo")     # collective: every rank constructs its reducer
+        elif not _skip(self.world):
+            self.host_group = group
+        self._plan = None
+        self._work = None
+
+    def plan(self, ids_host):
+        if _skip(self.world):
+            self._plan = None
+            return
+        uniq = torch.unique(ids_host.reshape(-1).to(torch.int64))
+        n = torch.tensor([uniq.numel()], dtype=torch.int64)
+        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(counts, n, group=self.host_group)
+        counts = [int(c) for c in counts]
+        cap = max(1, max(counts))
+        mine = torch.zeros(cap, dtype=torch.int64)
+        mine[:uniq.numel()] = uniq
+        rows_all = [torch.zeros(cap, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(rows_all, mine, group=self.host_group)
+        self._plan = dict(counts=counts, cap=cap, rows=rows_all, uniq=uniq)
+
+    def start(self, grad2d):
+        """grad2d [V, W]: this rank's (final) gradient.  Enqueues the gather of its rows and the all-gather."""
+        pl = self._plan
+        if pl is None:
+            return
+        dev = grad2d.device
+        if "rows_dev" not in pl:
+            pl["rows_dev"] = [r[:c].to(dev, non_blocking=True) for r, c in zip(pl["rows"], pl["counts"])]
+        send = torch.zeros(pl["cap"], grad2d.shape[1], dtype=grad2d.dtype, device=dev)
+        u = pl["counts"][self.rank]
+        if u:
+            send[:u] = grad2d.index_select(0, pl["rows_dev"][self.rank])
+        recv = torch.empty(self.world * pl["cap"], grad2d.shape[1], dtype=grad2d.dtype, device=dev)
+        if dist.get_backend(self.group) == "gloo":
+            parts = list(recv.view(self.world, pl["cap"], grad2d.shape[1]).unbind(0))
+            self._work = dist.all_gather(parts, send, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        pl["recv"] = recv
+
+    def finish(self, grad2d):
+        pl = self._plan
+        if pl is None or self._work is None:
+            return
+        self._work.wait()
+        self._work = None
+        cap = pl["cap"]
+        for r in range(self.world):
+            c = pl["counts"][r]
+            if r != self.rank and c:
+                grad2d.index_add_(0, pl["rows_dev"][r], pl["recv"][r * cap:r * cap + c])
+        self._plan = None
+
+
 class GradBucketReducer:
     """Sum the flat gradient over ranks in buckets, overlapped with the rest of backward.
 

@@ -11,7 +11,7 @@ import torch
 
 from . import ops
 from . import distributed as _dp
-from .distributed import BankLossDP, GradBucketReducer, _world, shard_range
+from .distributed import BankLossDP, GradBucketReducer, SparseRowReducer, _world, shard_range
 
 
 def wgrad_groups(layers, world):
@@ -55,6 +55,8 @@ class Stage2Trainer:
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.tower.device)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.tower.device)   # applied steps (check_finite mode)
         self.reducer = GradBucketReducer(self.tower.grads, group)
+        # token-embedding gradients: exchanged as touched rows when the caller also hands the ids on the host (step(ids_host=))
+        self.sparse_embed = SparseRowReducer(group) if (self.world > 1 or _dp._FORCE) else None
         self._bank = None
         self._m_begin, self._M_total = 0, 0
         self._refer = None
@@ -75,11 +77,16 @@ class Stage2Trainer:
             self._m_begin = 0
             self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32), bank_dtype)
 
-    def step(self, ids, refer_idx, labels, cu_seqlens=None, total_rows=0):
+    def step(self, ids, refer_idx, labels, cu_seqlens=None, total_rows=0, ids_host=None):
         """ids int32 [B_local, L], refer_idx / labels int64 [B_local] (device). Returns the global mean
         loss as a 1-element device tensor.  cu_seqlens / total_rows (TextTower.cu_seqlens of the host ids,
-        uploaded) switch the text tower to its packed mode: same result, only live rows computed."""
+        uploaded) switch the text tower to its packed mode: same result, only live rows computed.
+        ids_host (data parallel only): the same ids as a CPU tensor - the token-embedding gradient is then summed over the
+        ranks as touched rows (SparseRowReducer) instead of as a dense 152 MB all-reduce."""
         t = self.tower
+        sparse = self.sparse_embed is not None and ids_host is not None and not self.check_finite
+        if sparse:
+            self.sparse_embed.plan(ids_host)              # host-side collectives only; before any device work of the step
         feats = t.forward(ids, cu_seqlens, total_rows)
         q, qb, inv = ops.combine_l2norm_fwd(self._refer, refer_idx, feats)
         ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / self.model.tau,
@@ -97,15 +104,24 @@ class Stage2Trainer:
         # flat range of the last group's blocks (blocks 0 .. groups[-1]-1): contiguous behind the embeddings
         keep = (spans[-1][1], spans[-1 - groups[-1]][1]) if split else None
 
+        tok_elems = t.vocab * t.width                     # flat range of token_embedding.weight: [0, V * W)
+        tok_grad = t.grads[:tok_elems].view(t.vocab, t.width)
+
         def on_span(start, end):
             if start == 0 and split:
                 self.reducer.flush()                      # everything before the embeddings goes out as its own bucket(s)
-            self.reducer.on_span_ready(start, end)
+            if start == 0 and sparse:
+                self.sparse_embed.start(tok_grad)         # touched rows of the token embedding, one all-gather
+                self.reducer.on_span_ready(tok_elems, end)    # positional embedding: dense, tiny
+            else:
+                self.reducer.on_span_ready(start, end)
             if start == 0 and split:
                 self.reducer.flush()                      # ... and so do the embeddings, now
 
         t.backward_phased(dtext, on_span, groups, embed_early=split)
         pending = self.reducer.finish(keep_span=keep)
+        if sparse:
+            self.sparse_embed.finish(tok_grad)
         self.step_count += 1
         found = None
         if self.check_finite:

@@ -131,3 +131,44 @@ def test_bank_loss_data_parallel_world2(mode):
         assert ok_loss, (mode, rank, loss, ref)
         assert ok_grad, (mode, rank)
         assert ok_red, (mode, rank)
+
+
+def _sparse_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd.distributed import SparseRowReducer
+        V, W, B, L = 500, 24, 6, 11
+        ok = True
+        red = SparseRowReducer(None)
+        for step in range(3):                                 # different ids every step, unequal unique counts per rank
+            g = torch.Generator().manual_seed(100 * step + rank)
+            ids = torch.randint(0, V if rank else 40, (B, L), generator=g, dtype=torch.int32)   # rank 0: few distinct rows
+            ids[:, 0] = 7                                      # a row every rank touches
+            grad = torch.zeros(V, W)
+            grad.index_add_(0, ids.reshape(-1).long(), torch.randn(B * L, W, generator=g))      # non-zero only on own ids
+            dense = grad.clone()
+            dist.all_reduce(dense)                             # what the dense bucket would give
+            red.plan(ids)
+            red.start(grad)
+            red.finish(grad)
+            ok = ok and torch.allclose(grad, dense, atol=1e-5, rtol=1e-5)
+        out.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_embedding_row_exchange_world2():
+    """SparseRowReducer (the token-embedding gradient as touched rows: host-side plan over gloo, one all-gather, index_add)
+    equals the dense all-reduce, for unequal per-rank row counts, shared rows and changing ids."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -46,18 +46,22 @@ def _worker(rank, world, port, mode, out):
         bl = B // world
         sl = slice(rank * bl, (rank + 1) * bl)
         losses = []
+        # SPN_TEST_DDP_SPARSE=1: the token-embedding gradient goes out as touched rows (Stage2Trainer.step(ids_host=))
+        host = ids[sl].contiguous() if os.environ.get("SPN_TEST_DDP_SPARSE") == "1" else None
         for _ in range(2):
-            losses.append(tr.step(ids[sl].to(dev), ridx[sl].to(dev), labels[sl].to(dev)).item())
+            losses.append(tr.step(ids[sl].to(dev), ridx[sl].to(dev), labels[sl].to(dev), ids_host=host).item())
         out.put((rank, losses, model.tower.params.cpu().numpy()))   # by value: the worker exits right after
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,layers", [("sharded", 2), ("replicated", 2),
-                                         ("sharded", 6)])    # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
-def test_two_ranks_match_single_process(mode, layers, monkeypatch):
+@pytest.mark.parametrize("mode,layers,sparse", [("sharded", 2, 0), ("replicated", 2, 0),
+                                                ("sharded", 6, 0),   # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
+                                                ("replicated", 6, 1), ("sharded", 2, 1)])   # embedding rows exchanged sparsely
+def test_two_ranks_match_single_process(mode, layers, sparse, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("SPN_TEST_DDP_SPARSE", str(sparse))
     monkeypatch.setenv("SPN_TEST_DDP_LAYERS", str(layers))
     from spn4cir_amd.models import CIRPlus
     from spn4cir_amd.trainer import Stage2Trainer
