@@ -151,7 +151,7 @@ size_t spn_bank_workspace_bytes(int B, int M, int D);
  * `(q @ bank.T) / tau`, models_negplus.py:150-153) instead of recomputing them in the backward pass: logits_save is
  * spn_bank_logits_bytes(B, M) bytes of device scratch written by the forward call and read by the backward call of the
  * SAME (q, bank, labels, B, M, D, m_begin, inv_tau).
- *   B >= 128 (B % 8 == 0, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
+ *   B >= 256 (B % 8 == 0, D >= 512, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
  *     backward pass is a transpose-and-scale launch (G^T) plus ONE weight-gradient-shaped GEMM dq = (G^T)^T bank on the
  *     MFMA kernels, instead of a recomputing stream kernel in 32-query blocks.
  *   B < 128 with spn_bank_config(1): barrier-free streaming kernels (csrc/bank2.hip), fp32 logits kept (B * M * 4 B).

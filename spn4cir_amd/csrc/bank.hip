@@ -1107,9 +1107,12 @@ static bool bank_gemm_on() {
     }();
     return use_gemm;
 }
-// batches that take the GEMM forward pass and can keep p for a GEMM backward pass
+// batches that take the GEMM forward pass and keep p for a GEMM backward pass.  Measured (profiles/r03_bank_bench.txt):
+// B = 256, D = 768, M = 40 000: backward 72 -> 60 us; B = 128, D = 256, M = 30 000 (the BLIP head): 22 -> 50 us - a
+// 128 x 256 output is two tiles, the split-K GEMM cannot fill the chip with it - so the path is taken from 256 queries and
+// 512 columns; below that the recomputing stream kernel stays.
 bool bank_saved_path_large(const BankArgs& a) {
-    return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= 128 && a.B % 8 == 0 && a.D % 64 == 0;
+    return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= 256 && a.B % 8 == 0 && a.D >= 512 && a.D % 64 == 0;
 }
 size_t bank_saved_bytes_any(int B, int M) {
     const size_t small = bank_saved_bytes(B, M), large = B >= 128 ? large_save_bytes(B, M) : 0;

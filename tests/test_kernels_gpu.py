@@ -347,8 +347,8 @@ def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8):
         assert rel_err(d[:, :D], qd.grad) < 1.5e-2
 
 
-@pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (136, 5001, 512, 0.02),
-                                        (512, 8000, 768, 0.02)])
+@pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (264, 5001, 512, 0.02),
+                                        (512, 8000, 768, 0.02), (256, 3000, 1024, 0.05)])
 def test_bank_saved_pair_large_batch(ops, B, M, D, tau):
     """B >= 128: the forward GEMM keeps p = exp(logit - tile max) and the backward pass is G^T + ONE weight-gradient-shaped
     GEMM (spn_bank_grad_q_saved): dq against the oracle and against the recomputing kernel, with label smoothing and
