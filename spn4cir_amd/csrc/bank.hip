@@ -149,10 +149,18 @@ static BankChunking bank_chunking(int B, int M) {
 // target, a bank tile is exactly one target, and the logit of (query, target) is the MAX over the tile's 32 rows;
 // labels, m_begin and the statistics count targets.  The gradient flows to the arg-max row only (first index on
 // ties, as torch.max), so G has one non-zero per (query, tile) and the dq GEMM is unchanged.
-template <int D, bool BWD, bool FP8, bool GRP>
+// FUSED (with BWD): ONE pass over the bank yields both the softmax statistics and the query gradient - the gradient of the
+// InfoNCE loss w.r.t. q is attention with K = V = bank, dq_b = (sum_j p_bj bank_j - bank_label) / tau, so the flash-attention
+// recurrence applies: every tile's G = exp(z - m) against a running row maximum m, accumulators rescaled by exp(m_old -
+// m_new) when it moves.  The block writes O = sum_j exp(z_j - m_c) bank_j (fp32, relative to its chunk's final maximum m_c)
+// and {m_c, l_c, sum z, label logit}; bank_fused_combine_kernel folds the chunks with the GLOBAL lse (so shards of a
+// data-parallel bank combine exactly as before) and subtracts the label row.  The bank is read once per STEP instead of once
+// per pass: 61 MB instead of 122.9 MB at 40 000 x 768.
+template <int D, bool BWD, bool FP8, bool GRP, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChunking ck, const float* __restrict__ row_lse,
                                                             float label_smoothing, float inv_m_total,
-                                                            float* __restrict__ ws) {
+                                                            float* __restrict__ ws, float* __restrict__ ws2 = nullptr) {
+    static_assert(!FUSED || (BWD && !GRP), "the fused pass is the backward structure of a plain bank");
     constexpr int DW = D / 4;            // columns per wave
     constexpr int KSW = DW / 32;         // 32-deep k-steps per wave in the logit GEMM
     constexpr int NDT = DW / 16;         // 16-wide d tiles per wave in the gradient GEMM
@@ -165,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     float* Sp = (float*)(smem + 2 * TILE_B);             // [4 waves][2 mt][2 nt][64 lanes][4]
     bf16_t* Gs = (bf16_t*)(smem + 2 * TILE_B + 4 * 4096);   // [BQ][LDG]
     float* Fin = (float*)(smem + 2 * TILE_B);            // reuse of Sp at the end (forward stats)
+    [[maybe_unused]] float* As = (float*)(smem + 2 * TILE_B + 4 * 4096 + BQ * LDG * 2);   // FUSED: rescale factor per query
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     const bool q_ok = q_o < a.B;
     const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;   // GRP: shard-local TARGET id
     float lse = 0.f;
-    if constexpr (BWD) lse = q_ok ? row_lse[q_o] : 0.f;
+    if constexpr (BWD && !FUSED) lse = q_ok ? row_lse[q_o] : 0.f;
     float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
 
     f32x4 dq[2][NDT];
@@ -362,6 +371,45 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                 st_l = st_l * __expf(st_m - mn) + add;
                 st_m = mn;
             }
+        } else if constexpr (FUSED) {
+            // tile maximum of this lane's query over all 32 keys: both key-half waves read both halves' partial sums
+            f32x4 so = {0, 0, 0, 0};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) so += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + (nt_o ^ 1)) * 64 + lane) * 4);
+            const int key0o = m_lo + t * TR + (nt_o ^ 1) * 16 + (lane >> 4) * 4;
+            float z[4], tmx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z[r] = (key0 + r < a.M) ? sv[r] * a.inv_tau : -INFINITY;
+                const float zo = (key0o + r < a.M) ? so[r] * a.inv_tau : -INFINITY;
+                tmx = fmaxf(tmx, fmaxf(z[r], zo));
+            }
+            tmx = fmaxf(tmx, __shfl_xor(tmx, 16, 64));
+            tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+            // lazy reference: st_m follows the row maximum only when a tile exceeds it by more than FUSED_SLACK, so p <=
+            // e^SLACK (harmless in bf16 / fp32) and the accumulators are rescaled a few times per chunk, not per tile -
+            // with 32 queries per block SOME row sets a new record in almost every tile of a short chunk
+            constexpr float FUSED_SLACK = 8.0f;
+            const float mn = (tmx > st_m + FUSED_SLACK) ? tmx : st_m;           // st_m = -inf: the first live tile sets it
+            const float alpha = (mn > st_m && st_m > -INFINITY) ? __expf(st_m - mn) : 1.0f;   // nothing accumulated before the first live tile
+            float add = 0.f;
+            bf16x4 gb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = z[r] > -INFINITY;
+                const float pv = live ? __expf(z[r] - mn) : 0.f;
+                add += pv;
+                st_sl += live ? z[r] : 0.f;
+                const bool is_lab = live && (int64_t)(key0 + r) == label;
+                st_lab = is_lab ? z[r] : st_lab;
+                // the label key stays out of O: the fold subtracts (1 - p_label) bank_label with p_label in fp32, so a
+                // confident row (p_label -> 1) does not turn into the difference of two bf16-rounded near-equal sums
+                gb[r] = f2bf((q_ok && !is_lab) ? pv : 0.f);
+            }
+            st_l = st_l * alpha + add;
+            st_m = mn;
+            *(bf16x4*)(Gs + (mt_o * 16 + (lane & 15)) * LDG + nt_o * 16 + (lane >> 4) * 4) = gb;
+            if (nt_o == 0 && lane < 16) As[mt_o * 16 + lane] = alpha;
         } else {
             bf16x4 gb;
 #pragma unroll
@@ -377,6 +425,13 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         }
         if constexpr (BWD) {
             __syncthreads();
+            if constexpr (FUSED) {                       // the accumulators follow the row maximum (lane: query lane & 15 of each mt)
+                const float a0 = As[lane & 15], a1 = As[16 + (lane & 15)];
+                if (__any(a0 != 1.0f || a1 != 1.0f)) {   // the maximum moves in the first tiles of a chunk, then rarely
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) { dq[0][dt] *= a0; dq[1][dt] *= a1; }
+                }
+            }
             // ---- dq[q][d] += sum_key G[q][key] bank[key][d]:  D[i = d][j = query], k = key (one 32-step)
             bf16x8 gf[2];
 #pragma unroll
@@ -428,8 +483,112 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             const int q = q0 + mt * 16 + (lane & 15);
             if (q >= a.B) continue;
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-                *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
+            for (int dt = 0; dt < NDT; ++dt) {
+                if constexpr (FUSED) {
+                    // chunk partials in bf16: every term of the fold is a positively weighted partial (the label key is
+                    // excluded), so their rounding averages out over the chunks - below the bf16 rounding G already has
+                    const f32x4 v = dq[mt][dt];
+                    *(bf16x4*)((bf16_t*)ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) =
+                        bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                } else {
+                    *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
+                }
+            }
+        }
+        if constexpr (FUSED) {
+            // statistics of the chunk: every lane group / key-half wave of a query shares the running maximum, so l, sum z
+            // add up and the label logit is the maximum of the (at most one) finite entry
+            __syncthreads();
+            float* f = Fin + ((w * 64 + lane) * 4);
+            f[0] = st_m; f[1] = st_l; f[2] = st_sl; f[3] = st_lab;
+            __syncthreads();
+            if (tid < BQ) {
+                const int mt = tid >> 4, ql = tid & 15;
+                float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+                for (int nt = 0; nt < 2; ++nt)
+                    for (int g = 0; g < 4; ++g) {
+                        const float* p = Fin + (((mt * 2 + nt) * 64 + g * 16 + ql) * 4);
+                        m = fmaxf(m, p[0]);
+                        l += p[1];
+                        sl += p[2];
+                        lab = fmaxf(lab, p[3]);
+                    }
+                const int q = q0 + tid;
+                if (q < a.B) {
+                    float* o = ws2 + ((size_t)mi * a.B + q) * 4;
+                    o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+                }
+            }
+        }
+    }
+}
+
+// dq[b, :] = alpha * ( sum_c exp(m_c[b] - lse[b]) O_c[b, :]  -  (1 - p_label) bank[label_b, :] if the label lies in this shard )
+// (O excludes the label key; p_label = exp(z_label - lse) from the chunk statistics, the same fp32 arithmetic as
+// softmax - onehot): the "backward" half of the fused pass - no bank traffic but the B label rows.
+// Block = (64 columns, one query): 8 column octets x 32 chunk groups.
+template <bool FP8>
+__global__ __launch_bounds__(256) void bank_fused_combine_kernel(const bf16_t* __restrict__ Op, const float* __restrict__ sp, int nch,
+                                                                int B, int D, const float* __restrict__ lse,
+                                                                const void* __restrict__ bank, const float* __restrict__ scale,
+                                                                const int64_t* __restrict__ labels, int m_begin, int M,
+                                                                float alpha, float* __restrict__ dq, int lddq) {
+    __shared__ float red[32][8][9];
+    __shared__ float zl[32];
+    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int b = blockIdx.y, c = (blockIdx.x * 8 + cq) * 8;
+    const float ls = lse[b];
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float zlab = -INFINITY;
+    const bool in = c < D;
+    const bf16_t* o = Op + (size_t)b * D + (in ? c : 0);
+    const float* st = sp + (size_t)b * 4;
+    const size_t so = (size_t)B * D, ss = (size_t)B * 4;
+    auto acc = [&](const bf16x8& v, float wgt) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]) * wgt;
+    };
+    int r = rl;
+    for (; r + 96 < nch; r += 128) {                                 // four independent (weight, partial) loads in flight
+        const bf16x8 v0 = *(const bf16x8*)(o + (size_t)r * so), v1 = *(const bf16x8*)(o + (size_t)(r + 32) * so);
+        const bf16x8 v2 = *(const bf16x8*)(o + (size_t)(r + 64) * so), v3 = *(const bf16x8*)(o + (size_t)(r + 96) * so);
+        const float* s0 = st + (size_t)r * ss;
+        const float m0 = s0[0], m1 = s0[32 * ss], m2 = s0[64 * ss], m3 = s0[96 * ss];
+        zlab = fmaxf(fmaxf(zlab, s0[3]), fmaxf(fmaxf(s0[32 * ss + 3], s0[64 * ss + 3]), s0[96 * ss + 3]));
+        acc(v0, __expf(m0 - ls));                                    // chunk maximum against the global lse
+        acc(v1, __expf(m1 - ls));
+        acc(v2, __expf(m2 - ls));
+        acc(v3, __expf(m3 - ls));
+    }
+    for (; r < nch; r += 32) {
+        const float* s0 = st + (size_t)r * ss;
+        zlab = fmaxf(zlab, s0[3]);
+        acc(*(const bf16x8*)(o + (size_t)r * so), __expf(s0[0] - ls));
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cq][e] = s[e];
+    if (cq == 0) zl[rl] = zlab;
+    __syncthreads();
+    if (threadIdx.x < 64) {                                          // thread = one column of the block
+        const int col = blockIdx.x * 64 + threadIdx.x;
+        float t = 0.f, z = -INFINITY;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) { t += red[k][threadIdx.x >> 3][threadIdx.x & 7]; z = fmaxf(z, zl[k]); }
+        if (col < D) {
+            const int64_t lab = labels[b] - (int64_t)m_begin;
+            if (lab >= 0 && lab < (int64_t)M) {
+                const float cl = 1.0f - __expf(z - ls);
+                float v;
+                if constexpr (FP8) {
+                    const uint32_t w4 = *(const uint32_t*)((const uint8_t*)bank + (size_t)lab * D + (col & ~3));
+                    const f32x2 p2 = (col & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w4, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w4, false);
+                    v = bf2f(f2bf(p2[col & 1] * scale[lab]));        // the kernels see the dequantised row rounded to bf16
+                } else {
+                    v = bf2f(((const bf16_t*)bank)[(size_t)lab * D + col]);
+                }
+                t -= v * cl;
+            }
+            dq[(size_t)b * lddq + col] = t * alpha;
         }
     }
 }
@@ -999,8 +1158,78 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
         const double bytes = (double)a.M * D * (FP8 ? 1 : 2) + (FP8 ? 4.0 * a.M : 0.0) + (double)a.B * D * (BWD ? 6 : 2) +
                              (double)a.B * 16;
         ProfScope prof(BWD ? PK_BANK_BWD : PK_BANK_FWD, bytes, st);
-        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, row_lse, ls, inv_m, ws, (float*)nullptr);
     }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// ---- fused forward + backward pass (one bank read per step); save buffer = [nchunks][B][D] O partials, [nchunks][B][4] stats
+static bool bank_fused_on() { return bank_mode() != 3; }
+// mode 2: the fused stream pass also at B >= 256, D >= 512, where the default is the GEMM forward pass that keeps p + the
+// G^T / TN-GEMM backward pass
+static bool bank_fused_large() { return bank_mode() == 2; }
+bool bank_fused_ok(const BankArgs& a) {
+    if (!bank_fused_on() || a.group || a.B <= 0) return false;
+    if (a.bank_scale && a.B >= 128) return false;          // large e4m3 batches expand the shard once per pass instead
+    switch (a.D) {
+        case 128: case 256: case 512: case 640: case 768: case 1024: return true;
+        default: return false;
+    }
+}
+static size_t fused_save_bytes(int B, int M, int D) {
+    const BankChunking c = bank_chunking(B, M);
+    return (size_t)c.nchunks * B * ((size_t)D * 2 + 4 * sizeof(float));     // bf16 partials + {m, l, sum z, label z}
+}
+
+template <int D, bool FP8>
+static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
+    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2 + BQ * sizeof(float);
+    auto kern = bank_stream_kernel<D, true, FP8, false, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        // ONE read of the shard (the step needs no second pass) + the chunk partials written for the fold
+        const double bytes = (double)a.M * D * (FP8 ? 1 : 2) + (FP8 ? 4.0 * a.M : 0.0) + (double)a.B * D * 2 +
+                             (double)c.nchunks * a.B * (D * 2 + 16);
+        ProfScope prof(PK_BANK_FWD, bytes, st);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, (const float*)nullptr, 0.f, 0.f, Op, sp);
+    }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStream_t st) {
+    const BankChunking c = bank_chunking(a.B, a.M);
+    float* Op = save;                                                    // bf16 [nchunks][B][D]
+    float* sp = save + (size_t)c.nchunks * a.B * a.D / 2;
+    int rc = SPN_ERR_SHAPE;
+#define SPN_FUSED(D_) case D_: rc = a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
+    switch (a.D) {
+        SPN_FUSED(128) SPN_FUSED(256) SPN_FUSED(512) SPN_FUSED(640) SPN_FUSED(768) SPN_FUSED(1024)
+        default: return SPN_ERR_SHAPE;
+    }
+#undef SPN_FUSED
+    if (rc) return rc;
+    return bank_stats_fold(sp, c.nchunks, a.B, stats, st);
+}
+
+static int bank_fused_bwd(const BankArgs& a, const float* save, const float* row_lse, float grad_scale, float* dq, hipStream_t st) {
+    const BankChunking c = bank_chunking(a.B, a.M);
+    const bf16_t* Op = (const bf16_t*)save;
+    const float* sp = save + (size_t)c.nchunks * a.B * a.D / 2;
+    ProfScope prof(PK_BANK_BWD, (double)c.nchunks * a.B * (a.D * 2 + 16) + (double)a.B * a.D * 6, st);
+    const dim3 grid((a.D + 63) / 64, a.B);
+    if (a.bank_scale)
+        hipLaunchKernelGGL(bank_fused_combine_kernel<true>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, row_lse, (const void*)a.bank,
+                           a.bank_scale, a.labels, a.m_begin, a.M, grad_scale * a.inv_tau, dq, a.D);
+    else
+        hipLaunchKernelGGL(bank_fused_combine_kernel<false>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, row_lse,
+                           (const void*)a.bank, (const float*)nullptr, a.labels, a.m_begin, a.M, grad_scale * a.inv_tau, dq, a.D);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
@@ -1114,9 +1343,12 @@ static bool bank_gemm_on() {
 bool bank_saved_path_large(const BankArgs& a) {
     return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= 256 && a.B % 8 == 0 && a.D >= 512 && a.D % 64 == 0;
 }
+static size_t fused_save_bytes(int B, int M, int D);
 size_t bank_saved_bytes_any(int B, int M) {
     const size_t small = bank_saved_bytes(B, M), large = B >= 128 ? large_save_bytes(B, M) : 0;
-    return small > large ? small : large;
+    const size_t fused = fused_save_bytes(B, M, 1024);      // the widest bank: the C-ABI sizes the scratch from (B, M) alone
+    const size_t a = small > large ? small : large;
+    return a > fused ? a : fused;
 }
 
 __global__ __launch_bounds__(256) void bank_p_to_gt_kernel(const bf16_t* __restrict__ P, int ldp, const float* __restrict__ tmax,
@@ -1166,6 +1398,8 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     // per-GPU batches below 128 queries: the barrier-free row-tile kernel (bank2.hip); zsave (optional) keeps the logits
     // for bank_grad_q's saved path.  SPN_BANK2=0 keeps everything on the first-generation kernels below.
     if (bank_saved_path(a)) return bank2_stats_fwd(a, stats, zsave, ws, ws_bytes, st);
+    // with a save buffer: ONE pass computes the statistics and the unnormalised query gradient (bank_fused_*)
+    if (zsave && bank_fused_ok(a) && !(bank_saved_path_large(a) && !bank_fused_large())) return bank_fused_fwd(a, stats, zsave, st);
     {
         BankArgs b;
         size_t base;
@@ -1235,7 +1469,10 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
     // logits saved by the forward call of this step: stream the bank once, no recomputation (bank2.hip)
     if (zsaved && bank_saved_path(a))
         return bank2_grad_q(a, zsaved, row_lse, label_smoothing, M_total, grad_scale, dq, ws, ws_bytes, st);
-    if (zsaved && bank_saved_path_large(a)) {
+    if (zsaved && bank_fused_ok(a) && !(bank_saved_path_large(a) && !bank_fused_large())) {
+        if (label_smoothing == 0.f) return bank_fused_bwd(a, zsaved, row_lse, grad_scale, dq, st);
+        // label smoothing needs the column sums of the bank: this step's backward recomputes the logits (below)
+    } else if (zsaved && bank_saved_path_large(a)) {
         const LargeSave sv = large_save_at(const_cast<float*>(zsaved), a.B, a.M);
         if (ws_bytes < gemm_tn_workspace_bytes(a.M, a.B, a.D)) return SPN_ERR_WORKSPACE;
         const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 6 + (double)a.B * 16;

@@ -627,15 +627,19 @@ static int launch_dslice_bwd(const BankArgs& a, const DSliceGeom& g, const float
 // first-generation kernels' 19.7 / 23.1 us - the per-wave serial structure (load queries, wait, stream) has more fixed
 // cost than the block-cooperative kernels, and at that bank size fixed cost is half of the pass.  SPN_BANK2=1 or
 // spn_bank_config(1) selects them (they win on the backward pass of large e4m3 banks: 137 vs 151 us at 400 000 rows).
-static int g_bank2 = -1;
-void bank2_config(int on) { g_bank2 = on ? 1 : 0; }
-static bool bank2_on() {
-    if (g_bank2 < 0) {
-        const char* e = getenv("SPN_BANK2");
-        g_bank2 = (e && e[0] == '1') ? 1 : 0;
+// spn_bank_config mode: 0 = default routing, 1 = these kernels below 128 queries, 2 = the fused single pass also at
+// B >= 256, 3 = two passes everywhere (no fused pass).  Environment defaults: SPN_BANK2=1 -> 1, SPN_BANK_FUSED_LARGE=1 -> 2,
+// SPN_BANK_FUSED=0 -> 3.
+static int g_bank_mode = -1;
+void bank2_config(int mode) { g_bank_mode = (mode >= 0 && mode <= 3) ? mode : 0; }
+int bank_mode() {
+    if (g_bank_mode < 0) {
+        auto is = [](const char* n, char c) { const char* e = getenv(n); return e && e[0] == c; };
+        g_bank_mode = is("SPN_BANK2", '1') ? 1 : is("SPN_BANK_FUSED_LARGE", '1') ? 2 : is("SPN_BANK_FUSED", '0') ? 3 : 0;
     }
-    return g_bank2 == 1;
+    return g_bank_mode;
 }
+static bool bank2_on() { return bank_mode() == 1; }
 
 // The saved-logits pair serves plain (one row = one target) banks, bf16 or e4m3, at per-call batches below 128 queries
 bool bank_saved_path(const BankArgs& a) {

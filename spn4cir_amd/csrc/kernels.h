@@ -194,7 +194,8 @@ int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t 
 int bank_stats_fold(const float* ws, int n, int B, float* stats, hipStream_t st);
 // bank2.hip: barrier-free kernels for batches below 128 queries, backward from saved logits
 bool bank_saved_path(const BankArgs& a);
-void bank2_config(int on);
+void bank2_config(int mode);
+int bank_mode();
 int bank_saved_ld(int M);
 size_t bank_saved_bytes(int B, int M);
 size_t bank_saved_bytes_any(int B, int M);   // bank.hip: the same incl. the layout of batches >= 128 (p, G^T, tile maxima)

@@ -309,11 +309,11 @@ BANK_LOGITS_MAX_BYTES = 1 << 30
 
 
 def bank_logits_buffer(B, M, device):
-    """Scratch for the saved-logits pair (bank_stats_fwd(..., save=buf) / bank_grad_q(..., saved=buf)), or None when the
-    pair would not use it or it would exceed BANK_LOGITS_MAX_BYTES (the backward pass then recomputes the logits).  One buffer per forward call (torch's caching allocator): it belongs to that call's autograd /
-    step context until its backward has run, so two forwards in flight never share logits."""
-    if B >= 128 and B % 8:
-        return None
+    """Scratch of the forward/backward pair (bank_stats_fwd(..., save=buf) / bank_grad_q(..., saved=buf)): the chunk
+    partials of the fused single pass, or the saved probabilities / logits of the two-pass pairs - the library routes by
+    shape.  None when it would exceed BANK_LOGITS_MAX_BYTES (the backward pass then recomputes the logits).  One buffer
+    per forward call (torch's caching allocator): it belongs to that call's autograd / step context until its backward
+    has run, so two forwards in flight never share it."""
     n = lib().spn_bank_logits_bytes(B, M)
     if n > BANK_LOGITS_MAX_BYTES:
         return None

@@ -1,6 +1,6 @@
 """Bank InfoNCE kernels alone (dev tool): forward / backward time and the achieved fraction of the HBM roofline for the
-shapes of BASELINE configs 2, 3 and 5, recomputing first-generation kernels (child 1) next to the saved-logits pair (child 2: the second-generation
-streaming kernels below 128 queries unless BANK_BENCH_GEN2=0, the GEMM backward pass from saved probabilities above).
+shapes of BASELINE configs 2, 3 and 5: the recomputing two-pass kernels, the saved pair, and the fused single pass (one
+child process each).
 
     python tools/bank_bench.py [--rotate 8]
 
@@ -85,20 +85,30 @@ def main():
     if a.child:
         return child(a.rotate)
     res = {}
-    for name, env in (("gen1 (SPN_BANK2=0)", {"SPN_BANK2": "0", "SPN_BANK_SAVE": "0"}),
-                      ("gen2", {"SPN_BANK2": os.environ.get("BANK_BENCH_GEN2", "1"), "SPN_BANK_SAVE": "1"})):
+    configs = (("recompute", {"SPN_BANK2": "0", "SPN_BANK_SAVE": "0"}),
+               ("saved", {"SPN_BANK2": os.environ.get("BANK_BENCH_GEN2", "0"), "SPN_BANK_FUSED": "0", "SPN_BANK_SAVE": "1"}),
+               ("fused", {"SPN_BANK2": "0", "SPN_BANK_FUSED_LARGE": "1", "SPN_BANK_SAVE": "1"}))
+    for name, env in configs:
         p = subprocess.run([sys.executable, __file__, "--child", "--rotate", str(a.rotate)], env=dict(os.environ, **env),
                            capture_output=True, text=True)
         if p.returncode:
             print(p.stdout[-2000:], p.stderr[-4000:])
             raise SystemExit(1)
         res[name] = json.loads(p.stdout.strip().splitlines()[-1])
-    print(f"bank InfoNCE passes: the main kernel alone (HIP events recorded by the library around its launch, 16 launches "
-          f"rotating over {a.rotate} bank copies); 'call' = whole op from the host incl. fold launch and wrapper overhead")
-    print(f"{'B':>4} {'M':>7} {'D':>5} {'bank':>5} | {'gen1 fwd':>9} {'bwd':>7} | {'gen2 fwd':>9} {'bwd':>7} | {'gen2 TB/s fwd':>13} {'bwd':>6} {'pair/8TB/s':>10}")
-    for o, n in zip(res["gen1 (SPN_BANK2=0)"], res["gen2"]):
-        print(f"{o['B']:>4} {o['M']:>7} {o['D']:>5} {o['bank']:>5} | {o['fwd_us']:>9} {o['bwd_us']:>7} | {n['fwd_us']:>9} {n['bwd_us']:>7} |"
-              f" {n['fwd_TBps']:>13} {n['bwd_TBps']:>6} {n['pair_frac_of_8TBps']:>10}   call {o['fwd_call_us']}/{o['bwd_call_us']} -> {n['fwd_call_us']}/{n['bwd_call_us']}")
+    print(f"bank InfoNCE passes: the main kernels alone (HIP events recorded by the library around each launch, 16 launches "
+          f"rotating over {a.rotate} bank copies); call = whole op from the host incl. fold launches and wrapper overhead.\n"
+          f"recompute = two passes, logits recomputed in the backward pass; saved = two passes, the backward pass reads what the "
+          f"forward pass kept (B >= 256: p + G^T + TN GEMM; below: BANK_BENCH_GEN2=1 for the streaming pair, else = recompute);\n"
+          f"fused = ONE pass over the bank (statistics + unnormalised dq), the backward call folds the chunk partials.")
+    print(f"{'B':>4} {'M':>7} {'D':>5} {'bank':>5} | {'recompute f':>11} {'b':>6} {'sum':>6} | {'saved f':>8} {'b':>6} {'sum':>6} | "
+          f"{'fused pass':>10} {'fold':>6} {'sum':>6} | {'fused step bytes/8TB/s':>22}")
+    for o, n, f in zip(res["recompute"], res["saved"], res["fused"]):
+        eb = 1 if o["bank"] == "fp8" else 2
+        frac = 2 * o["M"] * o["D"] * eb / ((f["fwd_us"] + f["bwd_us"]) * 1e-6) / 8e12
+        print(f"{o['B']:>4} {o['M']:>7} {o['D']:>5} {o['bank']:>5} | {o['fwd_us']:>11} {o['bwd_us']:>6} {o['fwd_us'] + o['bwd_us']:>6.1f} | "
+              f"{n['fwd_us']:>8} {n['bwd_us']:>6} {n['fwd_us'] + n['bwd_us']:>6.1f} | {f['fwd_us']:>10} {f['bwd_us']:>6} "
+              f"{f['fwd_us'] + f['bwd_us']:>6.1f} | {frac:>22.3f}   call {o['fwd_call_us']}/{o['bwd_call_us']} -> "
+              f"{f['fwd_call_us']}/{f['bwd_call_us']}")
 
 
 if __name__ == "__main__":
