@@ -386,18 +386,24 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             }
             tmx = fmaxf(tmx, __shfl_xor(tmx, 16, 64));
             tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
-            // lazy reference: st_m follows the row maximum only when a tile exceeds it by more than FUSED_SLACK, so p <=
-            // e^SLACK (harmless in bf16 / fp32) and the accumulators are rescaled a few times per chunk, not per tile -
-            // with 32 queries per block SOME row sets a new record in almost every tile of a short chunk
-            constexpr float FUSED_SLACK = 8.0f;
-            const float mn = (tmx > st_m + FUSED_SLACK) ? tmx : st_m;           // st_m = -inf: the first live tile sets it
-            const float alpha = (mn > st_m && st_m > -INFINITY) ? __expf(st_m - mn) : 1.0f;   // nothing accumulated before the first live tile
+            // The reference exponent st_m is an INTEGER power of two (log2 domain) and p = 2^(z log2e - st_m) is built as
+            // exp2(fraction) scaled by an exact ldexp: bf16(p) = 2^-st_m bf16(2^(z log2e)) whatever st_m is, and a change of
+            // reference rescales the accumulators by an exact power of two.  So the rounding of every p - and with it dq up
+            // to fp32 summation order - does not depend on how the bank is cut into chunks, shards or query blocks: a
+            // data-parallel step reproduces the single-process one as closely as the two-pass kernels do.
+            // Lazy: st_m moves only when a tile exceeds it by more than 2^FUSED_SLACK (p <= 2^12, harmless in bf16 / fp32);
+            // with 32 queries per block SOME row sets a new record in almost every tile of a short chunk.
+            constexpr float FUSED_SLACK = 12.0f, LOG2E = 1.4426950408889634f;
+            const float tm2 = tmx * LOG2E;
+            const float mn = (tm2 > st_m + FUSED_SLACK) ? ceilf(tm2) : st_m;    // st_m = -inf: the first live tile sets it
+            const float alpha = (mn > st_m && st_m > -INFINITY) ? ldexpf(1.0f, (int)(st_m - mn)) : 1.0f;   // nothing accumulated before the first live tile
             float add = 0.f;
             bf16x4 gb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool live = z[r] > -INFINITY;
-                const float pv = live ? __expf(z[r] - mn) : 0.f;
+                const float z2 = z[r] * LOG2E, zf = floorf(z2);
+                const float pv = live ? ldexpf(__builtin_amdgcn_exp2f(z2 - zf), (int)fmaxf(zf - mn, -200.0f)) : 0.f;
                 add += pv;
                 st_sl += live ? z[r] : 0.f;
                 const bool is_lab = live && (int64_t)(key0 + r) == label;
@@ -484,15 +490,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             if (q >= a.B) continue;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                if constexpr (FUSED) {
-                    // chunk partials in bf16: every term of the fold is a positively weighted partial (the label key is
-                    // excluded), so their rounding averages out over the chunks - below the bf16 rounding G already has
-                    const f32x4 v = dq[mt][dt];
-                    *(bf16x4*)((bf16_t*)ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) =
-                        bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                } else {
-                    *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
-                }
+                *(f32x4*)(ws + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt];
             }
         }
         if constexpr (FUSED) {
@@ -516,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                 const int q = q0 + tid;
                 if (q < a.B) {
                     float* o = ws2 + ((size_t)mi * a.B + q) * 4;
-                    o[0] = m; o[1] = l; o[2] = sl; o[3] = lab;
+                    o[0] = m * 0.6931471805599453f; o[1] = l; o[2] = sl; o[3] = lab;    // the reference exponent in natural-log units
                 }
             }
         }
@@ -526,54 +524,51 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
 // dq[b, :] = alpha * ( sum_c exp(m_c[b] - lse[b]) O_c[b, :]  -  (1 - p_label) bank[label_b, :] if the label lies in this shard )
 // (O excludes the label key; p_label = exp(z_label - lse) from the chunk statistics, the same fp32 arithmetic as
 // softmax - onehot): the "backward" half of the fused pass - no bank traffic but the B label rows.
-// Block = (64 columns, one query): 8 column octets x 32 chunk groups.
+// The partials stay fp32: rounding them would make dq depend on where the chunk boundaries fall (see the kernel).
+// Block = (64 columns, one query): 16 column quads x 16 chunk groups.
 template <bool FP8>
-__global__ __launch_bounds__(256) void bank_fused_combine_kernel(const bf16_t* __restrict__ Op, const float* __restrict__ sp, int nch,
+__global__ __launch_bounds__(256) void bank_fused_combine_kernel(const float* __restrict__ Op, const float* __restrict__ sp, int nch,
                                                                 int B, int D, const float* __restrict__ lse,
                                                                 const void* __restrict__ bank, const float* __restrict__ scale,
                                                                 const int64_t* __restrict__ labels, int m_begin, int M,
                                                                 float alpha, float* __restrict__ dq, int lddq) {
-    __shared__ float red[32][8][9];
-    __shared__ float zl[32];
-    const int cq = threadIdx.x & 7, rl = threadIdx.x >> 3;
-    const int b = blockIdx.y, c = (blockIdx.x * 8 + cq) * 8;
+    __shared__ float red[16][16][5];
+    __shared__ float zl[16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int b = blockIdx.y, c = (blockIdx.x * 16 + cq) * 4;
     const float ls = lse[b];
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 s = {0, 0, 0, 0};
     float zlab = -INFINITY;
     const bool in = c < D;
-    const bf16_t* o = Op + (size_t)b * D + (in ? c : 0);
+    const float* o = Op + (size_t)b * D + (in ? c : 0);
     const float* st = sp + (size_t)b * 4;
     const size_t so = (size_t)B * D, ss = (size_t)B * 4;
-    auto acc = [&](const bf16x8& v, float wgt) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]) * wgt;
-    };
     int r = rl;
-    for (; r + 96 < nch; r += 128) {                                 // four independent (weight, partial) loads in flight
-        const bf16x8 v0 = *(const bf16x8*)(o + (size_t)r * so), v1 = *(const bf16x8*)(o + (size_t)(r + 32) * so);
-        const bf16x8 v2 = *(const bf16x8*)(o + (size_t)(r + 64) * so), v3 = *(const bf16x8*)(o + (size_t)(r + 96) * so);
+    for (; r + 48 < nch; r += 64) {                                  // four independent (weight, partial) loads in flight
+        const f32x4 v0 = *(const f32x4*)(o + (size_t)r * so), v1 = *(const f32x4*)(o + (size_t)(r + 16) * so);
+        const f32x4 v2 = *(const f32x4*)(o + (size_t)(r + 32) * so), v3 = *(const f32x4*)(o + (size_t)(r + 48) * so);
         const float* s0 = st + (size_t)r * ss;
-        const float m0 = s0[0], m1 = s0[32 * ss], m2 = s0[64 * ss], m3 = s0[96 * ss];
-        zlab = fmaxf(fmaxf(zlab, s0[3]), fmaxf(fmaxf(s0[32 * ss + 3], s0[64 * ss + 3]), s0[96 * ss + 3]));
-        acc(v0, __expf(m0 - ls));                                    // chunk maximum against the global lse
-        acc(v1, __expf(m1 - ls));
-        acc(v2, __expf(m2 - ls));
-        acc(v3, __expf(m3 - ls));
+        const float m0 = s0[0], m1 = s0[16 * ss], m2 = s0[32 * ss], m3 = s0[48 * ss];
+        zlab = fmaxf(fmaxf(zlab, s0[3]), fmaxf(fmaxf(s0[16 * ss + 3], s0[32 * ss + 3]), s0[48 * ss + 3]));
+        s += v0 * __expf(m0 - ls);                                   // chunk reference against the global lse
+        s += v1 * __expf(m1 - ls);
+        s += v2 * __expf(m2 - ls);
+        s += v3 * __expf(m3 - ls);
     }
-    for (; r < nch; r += 32) {
+    for (; r < nch; r += 16) {
         const float* s0 = st + (size_t)r * ss;
         zlab = fmaxf(zlab, s0[3]);
-        acc(*(const bf16x8*)(o + (size_t)r * so), __expf(s0[0] - ls));
+        s += *(const f32x4*)(o + (size_t)r * so) * __expf(s0[0] - ls);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[rl][cq][e] = s[e];
+    for (int e = 0; e < 4; ++e) red[rl][cq][e] = s[e];
     if (cq == 0) zl[rl] = zlab;
     __syncthreads();
     if (threadIdx.x < 64) {                                          // thread = one column of the block
         const int col = blockIdx.x * 64 + threadIdx.x;
         float t = 0.f, z = -INFINITY;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) { t += red[k][threadIdx.x >> 3][threadIdx.x & 7]; z = fmaxf(z, zl[k]); }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t += red[k][threadIdx.x >> 2][threadIdx.x & 3]; z = fmaxf(z, zl[k]); }
         if (col < D) {
             const int64_t lab = labels[b] - (int64_t)m_begin;
             if (lab >= 0 && lab < (int64_t)M) {
@@ -1179,7 +1174,7 @@ bool bank_fused_ok(const BankArgs& a) {
 }
 static size_t fused_save_bytes(int B, int M, int D) {
     const BankChunking c = bank_chunking(B, M);
-    return (size_t)c.nchunks * B * ((size_t)D * 2 + 4 * sizeof(float));     // bf16 partials + {m, l, sum z, label z}
+    return (size_t)c.nchunks * B * (D + 4) * sizeof(float);     // fp32 partials + {m, l, sum z, label z}
 }
 
 template <int D, bool FP8>
@@ -1195,7 +1190,7 @@ static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op
     {
         // ONE read of the shard (the step needs no second pass) + the chunk partials written for the fold
         const double bytes = (double)a.M * D * (FP8 ? 1 : 2) + (FP8 ? 4.0 * a.M : 0.0) + (double)a.B * D * 2 +
-                             (double)c.nchunks * a.B * (D * 2 + 16);
+                             (double)c.nchunks * a.B * (D * 4 + 16);
         ProfScope prof(PK_BANK_FWD, bytes, st);
         hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, (const float*)nullptr, 0.f, 0.f, Op, sp);
     }
@@ -1205,8 +1200,8 @@ static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op
 
 static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStream_t st) {
     const BankChunking c = bank_chunking(a.B, a.M);
-    float* Op = save;                                                    // bf16 [nchunks][B][D]
-    float* sp = save + (size_t)c.nchunks * a.B * a.D / 2;
+    float* Op = save;                                                    // [nchunks][B][D]
+    float* sp = save + (size_t)c.nchunks * a.B * a.D;
     int rc = SPN_ERR_SHAPE;
 #define SPN_FUSED(D_) case D_: rc = a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
     switch (a.D) {
@@ -1220,9 +1215,9 @@ static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStrea
 
 static int bank_fused_bwd(const BankArgs& a, const float* save, const float* row_lse, float grad_scale, float* dq, hipStream_t st) {
     const BankChunking c = bank_chunking(a.B, a.M);
-    const bf16_t* Op = (const bf16_t*)save;
-    const float* sp = save + (size_t)c.nchunks * a.B * a.D / 2;
-    ProfScope prof(PK_BANK_BWD, (double)c.nchunks * a.B * (a.D * 2 + 16) + (double)a.B * a.D * 6, st);
+    const float* Op = save;
+    const float* sp = save + (size_t)c.nchunks * a.B * a.D;
+    ProfScope prof(PK_BANK_BWD, (double)c.nchunks * a.B * (a.D * 4 + 16) + (double)a.B * a.D * 6, st);
     const dim3 grid((a.D + 63) / 64, a.B);
     if (a.bank_scale)
         hipLaunchKernelGGL(bank_fused_combine_kernel<true>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, row_lse, (const void*)a.bank,

@@ -167,18 +167,21 @@ class _TgcirStep(torch.autograd.Function):
         pooled, _ = model.head.forward(feats, tokens, tokens_b, ref_tokens)
         q, qb, inv = ops.combine_l2norm_fwd(None, None, pooled)
         bank = model._target_bank_dev
-        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / model.tau)
+        saved = ops.bank_logits_buffer(qb.shape[0], bank.shape[0], qb.device)
+        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / model.tau, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
-        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, B=ids.shape[0])
+        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, B=ids.shape[0], saved=saved)
         return mean.reshape(()).clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         m, st = ctx.model, ctx.st
         bank = m._target_bank_dev
-        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / m.tau, st["lse"], float(grad_out) / st["B"],
-                             M_total=bank.shape[0])[:, :m.head.C].contiguous()
-        dpooled = ops.combine_l2norm_bwd(st["q"], st["inv"], dq)
+        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / m.tau, st["lse"], 1.0 / st["B"],
+                             M_total=bank.shape[0], saved=st["saved"])[:, :m.head.C].contiguous()
+        # autograd's d(loss) scales the (linear) backward on the device: no host synchronisation before the first launch
+        scale = grad_out.detach().to(device=dq.device, dtype=torch.float32).reshape(1)
+        dpooled = ops.combine_l2norm_bwd(st["q"], st["inv"], dq, scale=scale)
         snap_h = gradsink.snapshot(m._params, m.head.grads, m.head.named_views)
         snap_t = gradsink.snapshot(m._params, m.text.grads, m.text.named_views, "clip.")
         dfeats, dtokens = m.head.backward(dpooled)
