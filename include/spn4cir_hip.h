@@ -147,22 +147,25 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
                     int m_begin, float inv_tau, const float* row_lse, float label_smoothing, int64_t M_total,
                     float grad_scale, float* dq, void* ws, size_t ws_bytes, void* stream);
 size_t spn_bank_workspace_bytes(int B, int M, int D);
-/* The same two passes as ONE forward/backward pair that keeps the logits of the step (what autograd keeps for
- * `(q @ bank.T) / tau`, models_negplus.py:150-153) instead of recomputing them in the backward pass: logits_save is
- * spn_bank_logits_bytes(B, M) bytes of device scratch written by the forward call and read by the backward call of the
- * SAME (q, bank, labels, B, M, D, m_begin, inv_tau).
+/* The forward/backward PAIR of one step: logits_save is spn_bank_logits_bytes(B, M) bytes of device scratch written by the
+ * forward call and read by the backward call of the SAME (q, bank, labels, B, M, D, m_begin, inv_tau) - what autograd keeps
+ * for `(q @ bank.T) / tau` (models_negplus.py:150-153), in whichever form the shape's kernels want:
+ *   default below 256 queries (any B the GEMM pair does not take; e4m3 banks below 128 queries): ONE pass over the bank.  The
+ *     forward call computes the statistics AND the unnormalised query gradient sum_j 2^(z_j log2e - r) bank_j per bank chunk
+ *     (flash-attention recurrence; scratch = the chunk partials); the backward call folds them with row_lse and subtracts
+ *     the label row - it does not read the bank again.  With label_smoothing != 0 the backward call recomputes instead.
  *   B >= 256 (B % 8 == 0, D >= 512, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
- *     backward pass is a transpose-and-scale launch (G^T) plus ONE weight-gradient-shaped GEMM dq = (G^T)^T bank on the
- *     MFMA kernels, instead of a recomputing stream kernel in 32-query blocks.
- *   B < 128 with spn_bank_config(1): barrier-free streaming kernels (csrc/bank2.hip), fp32 logits kept (B * M * 4 B).
- *   otherwise (token-max banks, e4m3 banks at B >= 128, ...): the pair runs the calls above - same results, logits_save
+ *     backward pass is a transpose-and-scale launch (G^T) plus ONE weight-gradient-shaped GEMM dq = (G^T)^T bank.
+ *   spn_bank_config(1), B < 128: barrier-free streaming kernels (csrc/bank2.hip), fp32 logits kept (B * M * 4 B).
+ *   otherwise (token-max banks, e4m3 banks at B >= 128): the pair runs the two calls above - same results, logits_save
  *     untouched.
  * bank_scale = NULL: bf16 bank; else the e4m3 bank of spn_bank_quantize_fp8 (ws from spn_bank_workspace_bytes_fp8). */
 size_t spn_bank_logits_bytes(int B, int M);
-/* 1 = batches below 128 queries use the second-generation streaming kernels (csrc/bank2.hip; also SPN_BANK2=1), 0 = the
- * first-generation block-cooperative kernels (default: faster at 40 000-row banks).  Process-wide
- * tuning switch like the SPN_* environment knobs; both give the same results within the documented tolerances. */
-int spn_bank_config(int second_generation);
+/* Routing of the pair, process-wide like the SPN_* environment knobs; every mode gives the same results within the
+ * documented tolerances: 0 = default (above); 1 = second-generation streaming kernels below 128 queries (also SPN_BANK2=1;
+ * slower at 40 000-row banks); 2 = the fused single pass at every batch size (SPN_BANK_FUSED_LARGE=1);
+ * 3 = two passes everywhere (SPN_BANK_FUSED=0). */
+int spn_bank_config(int mode);
 int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
                             int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
                             size_t ws_bytes, void* stream);
