@@ -244,14 +244,24 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             }
         }
     };
-    auto dequant = [&](int t, int buf) {
-        const char* raw = tiles + TILE_B + buf * RAW_B;
+    // row scales of the thread's D / 128 raw pieces, loaded ONE TILE AHEAD (behind the tile's DMA): a global load where
+    // the scale is needed puts an L2 / HBM round trip on every tile's critical path
+    [[maybe_unused]] float sc_next[FP8 ? D / 128 : 1];
+    auto load_scales = [&](int t) {
         const int mrow0 = m_lo + t * TR;
+#pragma unroll
+        for (int i = 0; i < D / 128; ++i) {
+            const int r = ((i * 256 + tid) * 16) / D;
+            sc_next[i] = (mrow0 + r < a.M) ? a.bank_scale[mrow0 + r] : 0.f;
+        }
+    };
+    auto dequant = [&](int t, int buf, const float (&scv)[FP8 ? D / 128 : 1]) {
+        const char* raw = tiles + TILE_B + buf * RAW_B;
 #pragma unroll
         for (int i = 0; i < D / 128; ++i) {
             const int p = (i * 256 + tid) * 16;          // byte offset of this thread's 16 e4m3 values
             const int r = p / D, cb = (p % D) >> 4;
-            const float sc = (mrow0 + r < a.M) ? a.bank_scale[mrow0 + r] : 0.f;
+            const float sc = scv[i];
             const u32x4 v = *(const u32x4*)(raw + p);
             bf16x8 o[2];
 #pragma unroll
@@ -269,14 +279,21 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         }
     };
 
-    if (ntiles > 0) stage(0, 0);
+    if (ntiles > 0) {
+        stage(0, 0);
+        if constexpr (FP8) load_scales(0);
+    }
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         wait_vm0();
         __syncthreads();
         if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
         if constexpr (FP8) {
-            dequant(t, buf);
+            float sc_cur[D / 128];
+#pragma unroll
+            for (int i = 0; i < D / 128; ++i) sc_cur[i] = sc_next[i];
+            if (t + 1 < ntiles) load_scales(t + 1);
+            dequant(t, buf, sc_cur);
             __syncthreads();
         }
         const char* T = tiles + (FP8 ? 0 : buf * TILE_B);
