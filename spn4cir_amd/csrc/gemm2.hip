@@ -1200,7 +1200,7 @@ template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
 __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int Kr, int N1, int N2,
                                          int lda, int ldb, float* __restrict__ Cz, int ldc, float* __restrict__ colsum_out,
                                          int m0, int n0, int kb, int ke, uint32_t* pace = nullptr,
-                                         uint32_t pace_members = 0) {
+                                         uint32_t pace_members = 0, int cs_mod = 0, int cs_rem = 0, int pace_lag = 0) {
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
@@ -1210,7 +1210,14 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
     const int wr = wid / WN, wc = wid % WN;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)Kr * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)Kr * (uint32_t)ldb * 2u);
-    const bool do_colsum = colsum_out != nullptr && n0 == 0 && wc == 0;
+    // column sums of A (the bias gradient).  cs_mod == 0: the n0 == 0 tile of a tile row computes them over all of k (its
+    // wc == 0 waves: four extra MFMA per slot, +25 % matrix work for that tile).  cs_mod > 0 (grouped launch, tile rows whose
+    // tiles are all whole): the cs_mod tiles of the row share the work - tile cs_rem takes the k tiles with kt % cs_mod ==
+    // cs_rem, wave (wr, wc) the 32 columns i == wc - and add their partial sums to colsum_out (zeroed before the launch)
+    // atomically: every tile of the launch then carries nearly the same matrix work, which k pacing needs.
+    const bool cs_spread = colsum_out != nullptr && cs_mod > 0;
+    const bool do_colsum = colsum_out != nullptr && cs_mod == 0 && n0 == 0 && wc == 0;
+    static_assert(SCHED != 2 || (MI == 4 && WN == 4), "spread column sums: one 32-column block per wave column");
 
     f32x16 acc[MI][NJ], accs[MI];
 #pragma unroll
@@ -1269,15 +1276,16 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
         // before any later block needs a CU).
         constexpr int PACE_R = 2;
         uint32_t pace_val = 0;
-        for (int kt = 0; kt < nk; ++kt) {
+        int cs_left = cs_rem;                           // k tiles until this tile's next column-sum turn
+        for (int kt = 0; kt < nk; ++kt, cs_left = cs_left == 0 ? cs_mod - 1 : cs_left - 1) {
             if (pace != nullptr && wid == 0) {
                 if ((kt & (PACE_R - 1)) == 0) {
                     if (lane == 0) {
                         __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         pace_val = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                } else if ((kt & (PACE_R - 1)) == 1 && kt > PACE_R) {
-                    const uint32_t target = pace_members * (uint32_t)(kt / PACE_R);
+                } else if ((kt & (PACE_R - 1)) == 1 && kt > PACE_R * (1 + pace_lag)) {
+                    const uint32_t target = pace_members * (uint32_t)(kt / PACE_R - pace_lag);
                     uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)pace_val);
                     for (int tries = 0; v < target && tries < 20000; ++tries) {
                         __builtin_amdgcn_s_sleep(8);
@@ -1313,6 +1321,11 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
                 if (do_colsum) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) accs[i] = mfma32(ones, a[i], accs[i]);
+                } else if (cs_spread && cs_left == 0) {
+                    if (wc == 0) accs[0] = mfma32(ones, a[0], accs[0]);
+                    else if (wc == 1) accs[0] = mfma32(ones, a[1], accs[0]);
+                    else if (wc == 2) accs[0] = mfma32(ones, a[2], accs[0]);
+                    else accs[0] = mfma32(ones, a[3], accs[0]);
                 }
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[0][1]),
                              "+v"(acc[1][1]), "+v"(acc[2][1]), "+v"(acc[3][1]));
@@ -1374,6 +1387,10 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
             const int m = m0 + wr * TM + i * 32 + lane;
             if (m < N1) colsum_out[m] = accs[i][0];
         }
+    }
+    if (cs_spread && lane < 32) {
+        const int m = m0 + wr * TM + wc * 32 + lane;
+        if (m < N1) unsafeAtomicAdd(colsum_out + m, accs[0][0]);
     }
     // split-K partials leave through LDS (same staging as gemm_nt2's epilogue): the MFMA layout would store 16 B
     // per row per instruction; row-major, one wave instruction writes two whole 512-B rows.
@@ -1464,7 +1481,16 @@ struct TnGroup {
     int full, tail, tail_splits, k_chunk;   // tiles [0, full) unsplit; [full, full + tail) split over the reduction
     float* slabs;                            // [tail_splits][tail][256*256] partial tiles, then [tail_splits][tail][256] column sums
     uint32_t* pace;                          // k pacing counters, one 128-byte line per (XCD, round) of whole tiles; NULL = off
+    int pace_lag;                            // phases (of 2 k tiles) a member may run ahead of the slowest one
+    int cs_spread;                           // 1 = column sums shared by the tiles of a row (tn_zero_colsum_kernel ran before)
 };
+
+// zeroes the column-sum outputs of a grouped launch whose tiles add their shares atomically (one workgroup per problem)
+__global__ void tn_zero_colsum_kernel(const TnGroup g) {
+    const TnProblem& P = g.p[blockIdx.x];
+    if (P.colsum)
+        for (int i = threadIdx.x; i < P.N1; i += blockDim.x) P.colsum[i] = 0.f;
+}
 
 __device__ __forceinline__ int tn_group_find(const TnGroup& g, int tile) {
     int p = 0;
@@ -1494,8 +1520,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_group_ker
     if (whole) {
         // pace group = the 32 whole tiles one XCD runs in one round (block b sits on XCD b % 8, in dispatch order)
         uint32_t* pace = g.pace ? g.pace + (size_t)((((int)blockIdx.x >> 3) / 32) * 8 + ((int)blockIdx.x & 7)) * 32 : nullptr;
+        // the tile row's column sums are shared by its tiles when all of them are whole tiles (g.cs_spread: colsum zeroed)
+        const int row_last = g.tile_begin[pi] + (bid / tiles_n) * tiles_n + tiles_n - 1;
+        const bool spread = g.cs_spread && row_last < g.full;
         tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, P.C, P.ldc, P.colsum, m0, n0, 0, Kr, pace,
-                                                32u);
+                                                32u, spread ? tiles_n : 0, spread ? bid % tiles_n : 0, g.pace_lag);
     } else {
         // slab of (z, tail tile): a dense [BM][BN] tile; the pointers are biased so that the tile's own (m0, n0) indexing of
         // a [*, BN] matrix lands in it (never dereferenced outside the slab: rows / columns beyond N1 / N2 are masked)
@@ -1717,11 +1746,28 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
     // k pacing of the whole tiles: needs every round of an XCD to be 32 tiles (full is a multiple of the CU count), at least
     // two of them sharing panels to be worth it, and room for the counters behind the slabs
     g.pace = nullptr;
+    static const int pace_lag = env_int_min1("SPN_TN_PACE_LAG", 1) - 1;      // SPN_TN_PACE_LAG = lag + 1
+    g.pace_lag = pace_lag;
     const int groups = (g.full / cus) * 8;
     if (tn_pace_on() && cus == 256 && g.full >= cus && ws && ws_bytes >= slab_bytes + TN_PACE_BYTES &&
         (size_t)groups * 128 <= TN_PACE_BYTES) {
         g.pace = (uint32_t*)((char*)ws + ((slab_bytes + 255) & ~(size_t)255));
         if (hipMemsetAsync(g.pace, 0, (size_t)groups * 128, st) != hipSuccess) g.pace = nullptr;
+    }
+    // shared column sums (SPN_TN_CS_SPREAD=0: the n0 == 0 tile of every row computes them alone, as in round 2)
+    static const bool cs_spread = [] {
+        const char* e = getenv("SPN_TN_CS_SPREAD");
+        return !(e && e[0] == '0');
+    }();
+    g.cs_spread = 0;
+    if (cs_spread) {
+        bool any = false;
+        for (int i = 0; i < n; ++i) any = any || probs[i].colsum != nullptr;
+        if (any) {
+            hipLaunchKernelGGL(tn_zero_colsum_kernel, dim3(n), dim3(256), 0, st, g);
+            SPN_CHECK_LAUNCH();
+            g.cs_spread = 1;
+        }
     }
     constexpr int LDS = 2 * (256 + 256) * 128;
     auto kern = gemm_tn2_group_kernel<256, 256, 2, 4, 2, 2>;
