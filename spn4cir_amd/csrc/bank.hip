@@ -145,6 +145,28 @@ static BankChunking bank_chunking(int B, int M) {
     return c;
 }
 
+// e4m3 helpers shared by the stream kernels (layout notes: "fp8 bank, forward pass on the fp8 MFMA" below)
+template <int D>
+__device__ __forceinline__ int fp8_swz(int r) {
+    if constexpr (D % 256 == 0) return r & 15;
+    else return (r >> 1) & 7;
+}
+
+__device__ __forceinline__ long pack_fp8x8(const float (&v)[8]) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+
+__device__ __forceinline__ void unpack_fp8x8(long p, float (&v)[8]) {
+    const int lo = (int)(unsigned)((unsigned long)p & 0xffffffffu), hi = (int)(unsigned)((unsigned long)p >> 32);
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = d[0]; v[7] = d[1];
+}
+
 // GRP (token-max banks, blip24cir .../blip2_qformer_cir_align_prompt.py:253-265): the bank holds TR = 32 token rows per
 // target, a bank tile is exactly one target, and the logit of (query, target) is the MAX over the tile's 32 rows;
 // labels, m_begin and the statistics count targets.  The gradient flows to the arg-max row only (first index on
@@ -174,6 +196,12 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     bf16_t* Gs = (bf16_t*)(smem + 2 * TILE_B + 4 * 4096);   // [BQ][LDG]
     float* Fin = (float*)(smem + 2 * TILE_B);            // reuse of Sp at the end (forward stats)
     [[maybe_unused]] float* As = (float*)(smem + 2 * TILE_B + 4 * 4096 + BQ * LDG * 2);   // FUSED: rescale factor per query
+    // F8L (fused pass over an e4m3 bank): the logits run on the fp8 MFMA straight from the raw tile - queries as two e4m3
+    // terms, as bank_fp8_fwd_kernel - while the SAME raw tile is dequantised into the bf16 image the dq GEMM reads
+    // (its G operand needs more than e4m3's 3 mantissa bits); no barrier between the two, one fewer per tile
+    constexpr bool F8L = FP8 && FUSED;
+    [[maybe_unused]] float* Qm = As + BQ;                 // [4 waves][32 queries] partial max |q|
+    [[maybe_unused]] float* Sst = Qm + 4 * BQ;            // [2][TR] row scales of the tile in flight / in use
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
@@ -200,12 +228,52 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         }
     }
 
+    [[maybe_unused]] long qh[2][F8L ? KSW : 1], ql[2][F8L ? KSW : 1];
+    [[maybe_unused]] float sq[2] = {1.f, 1.f};
+    if constexpr (F8L) {        // q ~= sq hi + (sq / 16) lo, one scale per query (bank_fp8_fwd_kernel; oracle: split_query_e4m3)
+        float am[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am[mt] = fmaxf(am[mt], fabsf(bf2f(qf[mt][ks][e])));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 16, 64));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 32, 64));
+            if ((lane >> 4) == 0) Qm[w * 32 + mt * 16 + lane] = am[mt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float m = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) m = fmaxf(m, Qm[ww * 32 + mt * 16 + (lane & 15)]);
+            sq[mt] = m > 0.f ? m / 448.0f : 1.0f;
+            const float rh = 1.0f / sq[mt], rl = rh * 16.0f;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                float v[8], hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(__fmul_rn(bf2f(qf[mt][ks][e]), rh), -448.0f), 448.0f);
+                qh[mt][ks] = pack_fp8x8(v);
+                unpack_fp8x8(qh[mt][ks], hv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float res = __fsub_rn(bf2f(qf[mt][ks][e]), __fmul_rn(hv[e], sq[mt]));
+                    v[e] = fminf(fmaxf(__fmul_rn(res, rl), -448.0f), 448.0f);
+                }
+                ql[mt][ks] = pack_fp8x8(v);
+            }
+        }
+    }
+
     // softmax-phase ownership: wave w owns query sub-tile mt_o and key sub-tile nt_o of each tile;
     // lane owns query q_o and keys nt_o*16 + (lane>>4)*4 + 0..3
     const int mt_o = w >> 1, nt_o = w & 1;
     const int q_o = q0 + mt_o * 16 + (lane & 15);
     const bool q_ok = q_o < a.B;
     const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;   // GRP: shard-local TARGET id
+    [[maybe_unused]] const float zs = sq[mt_o] * a.inv_tau;               // F8L: query scale x 1 / tau
     float lse = 0.f;
     if constexpr (BWD && !FUSED) lse = q_ok ? row_lse[q_o] : 0.f;
     float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
@@ -228,9 +296,12 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         if constexpr (FP8) {
             char* dst = tiles + TILE_B + buf * RAW_B;
 #pragma unroll
-            for (int i = 0; i < D / 128; ++i) {
+            for (int i = 0; i < D / 128; ++i) {            // raw image swizzled as in bank_fp8_fwd_kernel (fp8_swz)
                 const int ii = w * (D / 128) + i;
-                glds16(rs, dst + ii * 1024, (uint32_t)mrow0 * (uint32_t)D + (uint32_t)(ii * 1024 + lane * 16));
+                const int p = ii * 1024 + lane * 16;
+                const int r = p / D, cp = (p % D) >> 4;
+                const int c = cp ^ fp8_swz<D>(r);
+                glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)D + (uint32_t)c * 16u);
             }
         } else {
             char* dst = tiles + buf * TILE_B;
@@ -247,6 +318,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     // row scales of the thread's D / 128 raw pieces, loaded ONE TILE AHEAD (behind the tile's DMA): a global load where
     // the scale is needed puts an L2 / HBM round trip on every tile's critical path
     [[maybe_unused]] float sc_next[FP8 ? D / 128 : 1];
+    [[maybe_unused]] float sc_row = 0.f;                 // F8L: scale of tile row tid (tid < TR), for the statistics
     auto load_scales = [&](int t) {
         const int mrow0 = m_lo + t * TR;
 #pragma unroll
@@ -254,13 +326,16 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             const int r = ((i * 256 + tid) * 16) / D;
             sc_next[i] = (mrow0 + r < a.M) ? a.bank_scale[mrow0 + r] : 0.f;
         }
+        if constexpr (F8L) {
+            if (tid < TR) sc_row = (mrow0 + tid < a.M) ? a.bank_scale[mrow0 + tid] : 0.f;
+        }
     };
     auto dequant = [&](int t, int buf, const float (&scv)[FP8 ? D / 128 : 1]) {
         const char* raw = tiles + TILE_B + buf * RAW_B;
 #pragma unroll
         for (int i = 0; i < D / 128; ++i) {
-            const int p = (i * 256 + tid) * 16;          // byte offset of this thread's 16 e4m3 values
-            const int r = p / D, cb = (p % D) >> 4;
+            const int p = (i * 256 + tid) * 16;          // byte offset of this thread's 16 e4m3 values in the raw image
+            const int r = p / D, cb = ((p % D) >> 4) ^ fp8_swz<D>(r);        // logical 16-value chunk at that position
             const float sc = scv[i];
             const u32x4 v = *(const u32x4*)(raw + p);
             bf16x8 o[2];
@@ -288,13 +363,18 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         wait_vm0();
         __syncthreads();
         if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        [[maybe_unused]] float sc_cur[FP8 ? D / 128 : 1];
         if constexpr (FP8) {
-            float sc_cur[D / 128];
 #pragma unroll
             for (int i = 0; i < D / 128; ++i) sc_cur[i] = sc_next[i];
+            if constexpr (F8L) {
+                if (tid < TR) Sst[buf * TR + tid] = sc_row;          // read after the Sp barrier below
+            }
             if (t + 1 < ntiles) load_scales(t + 1);
-            dequant(t, buf, sc_cur);
-            __syncthreads();
+            if constexpr (!F8L) {
+                dequant(t, buf, sc_cur);
+                __syncthreads();
+            }
         }
         const char* T = tiles + (FP8 ? 0 : buf * TILE_B);
 
@@ -304,6 +384,33 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0, 0, 0, 0};
+        if constexpr (F8L) {
+            const char* R = tiles + TILE_B + buf * RAW_B;
+            f32x4 sl4[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) sl4[mt][nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int r = nt * 16 + (lane & 15);
+                    const int kb = w * DW + ks * 32 + (lane >> 4) * 8;               // byte offset of this lane's 8 values
+                    const long bfr = *(const long*)(R + r * D + (((kb >> 4) ^ fp8_swz<D>(r)) << 4) + (kb & 8));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        s[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, qh[mt][ks], s[mt][nt], 0, 0, 0);
+                        sl4[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, ql[mt][ks], sl4[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+            dequant(t, buf, sc_cur);                     // VALU + LDS beside the MFMAs; the image is read after two barriers
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) s[mt][nt] += sl4[mt][nt] * 0.0625f;
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks) {
 #pragma unroll
@@ -314,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) s[mt][nt] = mfma16b(bfrag, qf[mt][ks], s[mt][nt]);
             }
+        }
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -395,10 +503,15 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             for (int ww = 0; ww < 4; ++ww) so += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + (nt_o ^ 1)) * 64 + lane) * 4);
             const int key0o = m_lo + t * TR + (nt_o ^ 1) * 16 + (lane >> 4) * 4;
             float z[4], tmx = -INFINITY;
+            [[maybe_unused]] f32x4 sb4 = {1.f, 1.f, 1.f, 1.f}, sbo = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (F8L) {                         // logit = row scale x query scale x (hi + lo / 16) / tau
+                sb4 = *(const f32x4*)(Sst + buf * TR + nt_o * 16 + (lane >> 4) * 4) * zs;
+                sbo = *(const f32x4*)(Sst + buf * TR + (nt_o ^ 1) * 16 + (lane >> 4) * 4) * zs;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                z[r] = (key0 + r < a.M) ? sv[r] * a.inv_tau : -INFINITY;
-                const float zo = (key0o + r < a.M) ? so[r] * a.inv_tau : -INFINITY;
+                z[r] = (key0 + r < a.M) ? (F8L ? sv[r] * sb4[r] : sv[r] * a.inv_tau) : -INFINITY;
+                const float zo = (key0o + r < a.M) ? (F8L ? so[r] * sbo[r] : so[r] * a.inv_tau) : -INFINITY;
                 tmx = fmaxf(tmx, fmaxf(z[r], zo));
             }
             tmx = fmaxf(tmx, __shfl_xor(tmx, 16, 64));
@@ -616,27 +729,6 @@ __global__ __launch_bounds__(256) void bank_fused_combine_kernel(const float* __
 // group - x = r & 15 when a row is a multiple of 256 B (every row starts on bank 0), (r >> 1) & 7 when it is an odd
 // multiple of 128 B (rows alternate between two bank halves): the 16 rows of a fragment read fall in 16 distinct
 // 16-byte bank groups.
-template <int D>
-__device__ __forceinline__ int fp8_swz(int r) {
-    if constexpr (D % 256 == 0) return r & 15;
-    else return (r >> 1) & 7;
-}
-
-__device__ __forceinline__ long pack_fp8x8(const float (&v)[8]) {
-    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
-    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
-}
-
-__device__ __forceinline__ void unpack_fp8x8(long p, float (&v)[8]) {
-    const int lo = (int)(unsigned)((unsigned long)p & 0xffffffffu), hi = (int)(unsigned)((unsigned long)p >> 32);
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1]; v[6] = d[0]; v[7] = d[1];
-}
-
 static constexpr int FP8_MAX_CHUNK_ROWS = 2048;   // rows of a block's chunk whose scales are kept in LDS (8 KB)
 static constexpr int FP8_STAGES = 4;     // raw tiles in flight per block: a chunk is ~5 tiles, so nearly all of it is
                                          // requested at once (two stages: one DMA latency per tile, 22.9 us at B = 32)
@@ -1196,7 +1288,8 @@ static size_t fused_save_bytes(int B, int M, int D) {
 
 template <int D, bool FP8>
 static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
-    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2 + BQ * sizeof(float);
+    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2 + BQ * sizeof(float) +
+                       (FP8 ? (4 * BQ + 2 * TR) * sizeof(float) : 0);       // + Qm, Sst
     auto kern = bank_stream_kernel<D, true, FP8, false, true>;
     static bool attr_set = false;
     if (!attr_set) {

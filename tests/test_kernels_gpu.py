@@ -313,7 +313,7 @@ def test_bank_fused_single_pass(ops, B, M, D, tau, fp8):
     from oracle import bank_loss
     if fp8 and B >= 128:
         pytest.skip("e4m3 banks at B >= 128 run the two-pass path (bank expanded once per pass)")
-    _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=False, split_q=False)
+    _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=False)
 
 
 @pytest.mark.parametrize("noise", [3.0, 3.5, 5.0])        # smallest 1 - p_label of the batch ~ 1e-4, 1e-3, 4e-2
@@ -352,9 +352,9 @@ def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=True, split_q=Tr
     qr = qb[:, :D].cpu().float()
     br = (bank_b.dequantize() if fp8 else bank_b)[:, :D].cpu().float()
     if fp8 and not split_q:
-        br = br.bfloat16().float()               # the fused pass multiplies the bf16 image of the dequantised tile
+        br = br.bfloat16().float()               # kernels that multiply the bf16 image of the dequantised tile
     if fp8 and split_q:          # the logits of an e4m3 bank run on the fp8 MFMA: queries as two e4m3 terms (oracle: split_query_e4m3)
-        qr = bank_loss.split_query_e4m3(qr)   # (the fused pass dequantises the tile to bf16 in LDS instead: bf16 queries)
+        qr = bank_loss.split_query_e4m3(qr)   # (so does the fused pass; its dq GEMM reads a dequantised bf16 image)
     lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
     save = ops.bank_logits_buffer(B, M, "cuda")
     assert save is not None
