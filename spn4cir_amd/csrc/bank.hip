@@ -126,6 +126,12 @@ __device__ __forceinline__ int bank_swz(int r) {
     return (((r & 3) | (((r >> 3) & 1) << 2)) << 1) | ((r >> 2) & 1);
 }
 
+// LDS bytes of bank_stream_kernel's tile area (its RS / TILES_B)
+template <int D, bool FP8>
+static constexpr size_t bank_stream_tiles_bytes() {
+    return FP8 ? (size_t)TR * D * 2 + (size_t)((D <= 768) ? 3 : 2) * TR * D : 2 * (size_t)TR * D * 2;
+}
+
 struct BankChunking {
     int nq;         // query tiles
     int nchunks;    // bank chunks
@@ -191,11 +197,16 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
     constexpr int GLDS_PER_WAVE = D / 64;
     constexpr int LDG = TR + 8;          // G row stride (elements): 80 B rows, 16-B aligned
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* tiles = smem;                                  // 2 x TILE_B
-    float* Sp = (float*)(smem + 2 * TILE_B);             // [4 waves][2 mt][2 nt][64 lanes][4]
-    bf16_t* Gs = (bf16_t*)(smem + 2 * TILE_B + 4 * 4096);   // [BQ][LDG]
-    float* Fin = (float*)(smem + 2 * TILE_B);            // reuse of Sp at the end (forward stats)
-    [[maybe_unused]] float* As = (float*)(smem + 2 * TILE_B + 4 * 4096 + BQ * LDG * 2);   // FUSED: rescale factor per query
+    // e4m3 bank: RS raw tiles (1 byte per element) behind ONE bf16 image; three where they fit, so that two tiles are in
+    // flight per CU while a third is consumed (with one in flight the statistics and dq phases of a tile delay the request
+    // for the tile after next: ablation at 400 000 rows, 144 us = 113 streaming + 19 statistics + 13 dq, nothing hidden)
+    constexpr int RS = (FP8 && D <= 768) ? 3 : 2;
+    constexpr int TILES_B = FP8 ? TILE_B + RS * (TR * D) : 2 * TILE_B;
+    char* tiles = smem;                                  // 2 x TILE_B (bf16) / TILE_B + RS x raw (e4m3)
+    float* Sp = (float*)(smem + TILES_B);                // [4 waves][2 mt][2 nt][64 lanes][4]
+    bf16_t* Gs = (bf16_t*)(smem + TILES_B + 4 * 4096);   // [BQ][LDG]
+    float* Fin = (float*)(smem + TILES_B);               // reuse of Sp at the end (forward stats)
+    [[maybe_unused]] float* As = (float*)(smem + TILES_B + 4 * 4096 + BQ * LDG * 2);   // FUSED: rescale factor per query
     // F8L (fused pass over an e4m3 bank): the logits run on the fp8 MFMA straight from the raw tile - queries as two e4m3
     // terms, as bank_fp8_fwd_kernel - while the SAME raw tile is dequantised into the bf16 image the dq GEMM reads
     // (its G operand needs more than e4m3's 3 mantissa bits); no barrier between the two, one fewer per tile
@@ -354,15 +365,27 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         }
     };
 
+    constexpr int NDMA = D / 128;                        // e4m3: DMA instructions per wave and raw tile
     if (ntiles > 0) {
+        if constexpr (FP8) {                             // scales before the DMA they travel with: the counted wait below
+            load_scales(0);                              // leaves exactly the LAST tile's DMA in flight
+            asm volatile("" ::: "memory");
+        }
         stage(0, 0);
-        if constexpr (FP8) load_scales(0);
+        if constexpr (RS == 3) {
+            if (ntiles > 1) stage(1, 1);
+        }
     }
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        wait_vm0();
+        [[maybe_unused]] const int rbuf = RS == 3 ? t % 3 : buf;       // raw tile of an e4m3 bank
+        if constexpr (RS == 3) {
+            if (t + 1 < ntiles) wait_vmcnt<NDMA>();      // tile t and its scales are in, tile t + 1 may still be in flight
+            else wait_vmcnt<0>();
+        } else {
+            wait_vm0();
+        }
         __syncthreads();
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
         [[maybe_unused]] float sc_cur[FP8 ? D / 128 : 1];
         if constexpr (FP8) {
 #pragma unroll
@@ -370,11 +393,20 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             if constexpr (F8L) {
                 if (tid < TR) Sst[buf * TR + tid] = sc_row;          // read after the Sp barrier below
             }
+            asm volatile("" : "+v"(sc_cur[0]));          // the copies are taken before the next tile's loads are issued
             if (t + 1 < ntiles) load_scales(t + 1);
+            asm volatile("" ::: "memory");
+            if constexpr (RS == 3) {
+                if (t + 2 < ntiles) stage(t + 2, (t + 2) % 3);       // raw[(t + 2) % 3] = raw[(t - 1) % 3]: consumed before this barrier
+            } else {
+                if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+            }
             if constexpr (!F8L) {
-                dequant(t, buf, sc_cur);
+                dequant(t, rbuf, sc_cur);
                 __syncthreads();
             }
+        } else {
+            if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
         }
         const char* T = tiles + (FP8 ? 0 : buf * TILE_B);
 
@@ -385,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) s[mt][nt] = f32x4{0, 0, 0, 0};
         if constexpr (F8L) {
-            const char* R = tiles + TILE_B + buf * RAW_B;
+            const char* R = tiles + TILE_B + rbuf * RAW_B;
             f32x4 sl4[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -405,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                     }
                 }
             }
-            dequant(t, buf, sc_cur);                     // VALU + LDS beside the MFMAs; the image is read after two barriers
+            dequant(t, rbuf, sc_cur);                    // VALU + LDS beside the MFMAs; the image is read after two barriers
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -945,6 +977,330 @@ static int launch_bank_fp8_fwd(const BankArgs& a, const BankChunking& c, float* 
     return SPN_OK;
 }
 
+// ------------------------------------------------------------------ fp8 bank, fused pass entirely on the fp8 MFMA
+// The fused single pass (bank_stream_kernel<.., FUSED>) over an e4m3 bank WITHOUT a dequantised bf16 image: logits as in
+// bank_fp8_fwd_kernel (raw tile x two-term e4m3 queries), and the dq GEMM  dq[q][d] += sum_key G[q][key] raw[key][d]  on
+// v_mfma_f32_16x16x32_fp8_bf8:
+//   A = the raw tile, transposed on the way out of LDS by ds_read_b64_tr_b8 (lane s of a 16-lane group hands in the address
+//       of row s >> 1, byte half s & 1 of a 16-column block; lane o receives column o of those 8 rows - probed on gfx950);
+//   B = G = p x (row scale / c2) x 8 as THREE bf8 (e5m2) terms t0 + t1 + t2 (each the bf8 rounding of what the previous
+//       ones left: 3 significant bits per term, ~2^-9 together - the accuracy of a bf16 G).  e5m2's 32 binades take the
+//       whole range of p against the lazy power-of-two reference (p <= 2^12 -> G <= 2^15; entries 19 binades below the
+//       reference flush to zero, < 2e-6 of the row's largest term each), so the three products accumulate straight into
+//       the dq registers - no per-tile scale, no second accumulator set.  c2 = the chunk's largest row scale rounded up to
+//       a power of two (exact to divide by, exact to multiply back in the epilogue).
+// No bf16 image means no dequantisation pass (a quarter of the F8L kernel's time) and LDS for a five-deep raw ring: four
+// 24 KB tiles in flight per CU, the bytes a streaming bf16 kernel keeps in flight with one.
+static constexpr int FP8F_SLACK = 12;
+template <int D>
+static constexpr int fp8f_stages() {
+    constexpr int rest = 4 * 4096 + 4 * BQ * 4 + FP8_MAX_CHUNK_ROWS * 4 + 3 * BQ * TR + BQ * 4 + 64;
+    constexpr int s = (160 * 1024 - rest) / (TR * D);
+    return s > 5 ? 5 : s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, BankChunking ck, float* __restrict__ Op,
+                                                               float* __restrict__ sp) {
+    constexpr int DW = D / 4, KSW = DW / 32, NDT = DW / 16, RAW_B = TR * D;
+    constexpr int S = fp8f_stages<D>(), NDMA = D / 128;
+    static_assert(S >= 3 && (S - 1) * NDMA <= 63 && D % 128 == 0, "bank width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* tiles = smem;                                   // S x RAW_B
+    float* Sp = (float*)(smem + S * RAW_B);               // [4 waves][2 mt][2 nt][64 lanes][4]; reused as Fin at the end
+    float* Qm = Sp + 4096;                                // [4 waves][32 queries] partial max |q|; then the block maximum of the scales
+    float* Ssc = Qm + 4 * BQ;                             // row scales of the chunk (<= FP8_MAX_CHUNK_ROWS)
+    uint8_t* G8 = (uint8_t*)(Ssc + FP8_MAX_CHUNK_ROWS);   // [3 terms][BQ queries][TR keys] bf8
+    float* As = (float*)(G8 + 3 * BQ * TR);               // rescale factor per query
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int mi = blockIdx.x % ck.nchunks, qi = blockIdx.x / ck.nchunks;
+    const int q0 = qi * BQ;
+    const int m_lo = mi * ck.rows;
+    const int m_hi = min(a.M, m_lo + ck.rows);
+    const int ntiles = m_hi > m_lo ? (m_hi - m_lo + TR - 1) / TR : 0;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.bank, (uint32_t)a.M * (uint32_t)D);
+
+    auto stage = [&](int t) {
+        const int mrow0 = m_lo + t * TR;
+        char* dst = tiles + (t % S) * RAW_B;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int ii = w * NDMA + i;
+            const int p = ii * 1024 + lane * 16;
+            const int r = p / D, cp = (p % D) >> 4;
+            const int c = cp ^ fp8_swz<D>(r);
+            glds16(rs, dst + ii * 1024, (uint32_t)(mrow0 + r) * (uint32_t)D + (uint32_t)c * 16u);
+        }
+    };
+    float smax = 0.f;
+    for (int i = tid; i < ntiles * TR; i += 256) {
+        const float v = (m_lo + i < a.M) ? a.bank_scale[m_lo + i] : 0.f;
+        Ssc[i] = v;
+        smax = fmaxf(smax, v);
+    }
+    // ---- this wave's d-slice of the 32 queries -> two e4m3 terms (as bank_fp8_fwd_kernel)
+    long qh[2][KSW], ql[2][KSW];
+    float sq[2];
+    {
+        bf16x8 qf[2][KSW];
+        float am[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int qr = q0 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                if (qr < a.B) {
+                    qf[mt][ks] = *(const bf16x8*)(a.q + (size_t)qr * a.ldq + w * DW + ks * 32 + (lane >> 4) * 8);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[mt][ks][e] = (bf16_t)0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t)
+            if (t < ntiles) stage(t);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) smax = fmaxf(smax, __shfl_xor(smax, off, 64));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am[mt] = fmaxf(am[mt], fabsf(bf2f(qf[mt][ks][e])));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 16, 64));
+            am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 32, 64));
+            if ((lane >> 4) == 0) Qm[w * 32 + mt * 16 + lane] = am[mt];
+        }
+        if (lane == 0) As[w] = smax;
+        __syncthreads();
+        smax = fmaxf(fmaxf(As[0], As[1]), fmaxf(As[2], As[3]));
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float m = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) m = fmaxf(m, Qm[ww * 32 + mt * 16 + (lane & 15)]);
+            sq[mt] = m > 0.f ? m / 448.0f : 1.0f;
+            const float rh = 1.0f / sq[mt], rl = rh * 16.0f;
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) {
+                float v[8], hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(__fmul_rn(bf2f(qf[mt][ks][e]), rh), -448.0f), 448.0f);
+                qh[mt][ks] = pack_fp8x8(v);
+                unpack_fp8x8(qh[mt][ks], hv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float res = __fsub_rn(bf2f(qf[mt][ks][e]), __fmul_rn(hv[e], sq[mt]));
+                    v[e] = fminf(fmaxf(__fmul_rn(res, rl), -448.0f), 448.0f);
+                }
+                ql[mt][ks] = pack_fp8x8(v);
+            }
+        }
+    }
+    // c2 = 2^ceil(log2(largest row scale of the chunk)): G = p x (scale / c2) x 8 <= 2^15
+    int c2e;
+    (void)frexpf(smax > 0.f ? smax : 1.0f, &c2e);         // smax = f x 2^c2e, f in [0.5, 1)  ->  smax <= 2^c2e
+    const float g_mul = ldexpf(8.0f, -c2e);
+
+    const int mt_o = w >> 1, nt_o = w & 1;
+    const int q_o = q0 + mt_o * 16 + (lane & 15);
+    const bool q_ok = q_o < a.B;
+    const int64_t label = q_ok ? a.labels[q_o] - (int64_t)a.m_begin : -1;
+    const float zs = sq[mt_o] * a.inv_tau;                // query scale x 1 / tau
+    float st_m = -INFINITY, st_l = 0.f, st_sl = 0.f, st_lab = -INFINITY;
+    f32x4 dq[2][NDT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[mt][dt] = f32x4{0, 0, 0, 0};
+    __syncthreads();                                      // As (scale maxima) is reused below
+
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t is in when at most the tiles requested after it are outstanding (its own successor in the ring is
+        // requested only below: the dq phase of tile t - 1 read that buffer until the barrier)
+        const int behind = min(S - 2, ntiles - 1 - t);
+        if (behind >= 3) wait_vmcnt<3 * NDMA>();
+        else if (behind == 2) wait_vmcnt<2 * NDMA>();
+        else if (behind == 1) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __syncthreads();
+        if (t + S - 1 < ntiles) stage(t + S - 1);
+        const char* T = tiles + (t % S) * RAW_B;
+        f32x4 sh[2][2], sl4[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                sh[mt][nt] = f32x4{0, 0, 0, 0};
+                sl4[mt][nt] = f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int r = nt * 16 + (lane & 15);
+                const int kb = w * DW + ks * 32 + (lane >> 4) * 8;               // byte offset of this lane's 8 values
+                const long bfr = *(const long*)(T + r * D + (((kb >> 4) ^ fp8_swz<D>(r)) << 4) + (kb & 8));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    sh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, qh[mt][ks], sh[mt][nt], 0, 0, 0);
+                    sl4[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bfr, ql[mt][ks], sl4[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = sh[mt][nt] + sl4[mt][nt] * 0.0625f;
+        __syncthreads();
+        // ---- statistics + G (bank_stream_kernel's FUSED branch: integer lazy reference exponent, label key kept out of G)
+        f32x4 sv = {0, 0, 0, 0}, so = {0, 0, 0, 0};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
+            so += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + (nt_o ^ 1)) * 64 + lane) * 4);
+        }
+        const int kl = t * TR + nt_o * 16 + (lane >> 4) * 4, klo = t * TR + (nt_o ^ 1) * 16 + (lane >> 4) * 4;   // chunk-local rows
+        const int key0 = m_lo + kl, key0o = m_lo + klo;
+        const f32x4 sb4 = *(const f32x4*)(Ssc + kl), sbo = *(const f32x4*)(Ssc + klo);
+        float z[4], tmx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z[r] = (key0 + r < a.M) ? sv[r] * sb4[r] * zs : -INFINITY;
+            const float zo = (key0o + r < a.M) ? so[r] * sbo[r] * zs : -INFINITY;
+            tmx = fmaxf(tmx, fmaxf(z[r], zo));
+        }
+        tmx = fmaxf(tmx, __shfl_xor(tmx, 16, 64));
+        tmx = fmaxf(tmx, __shfl_xor(tmx, 32, 64));
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float tm2 = tmx * LOG2E;
+        const float mn = (tm2 > st_m + (float)FP8F_SLACK) ? ceilf(tm2) : st_m;
+        const float alpha = (mn > st_m && st_m > -INFINITY) ? ldexpf(1.0f, (int)(st_m - mn)) : 1.0f;
+        float add = 0.f;
+        uint32_t g0 = 0, g1 = 0, g2 = 0;                  // this lane's 4 keys, one bf8 term each
+        float x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = z[r] > -INFINITY;
+            const float z2 = z[r] * LOG2E, zf = floorf(z2);
+            const float pv = live ? ldexpf(__builtin_amdgcn_exp2f(z2 - zf), (int)fmaxf(zf - mn, -200.0f)) : 0.f;
+            add += pv;
+            st_sl += live ? z[r] : 0.f;
+            const bool is_lab = live && (int64_t)(key0 + r) == label;
+            st_lab = is_lab ? z[r] : st_lab;
+            x[r] = (q_ok && !is_lab) ? pv * (sb4[r] * g_mul) : 0.f;
+        }
+        st_l = st_l * alpha + add;
+        st_m = mn;
+        {
+            // x = t0 + t1 + t2, every term the bf8 rounding of the remainder
+            int p01 = __builtin_amdgcn_cvt_pk_bf8_f32(x[0], x[1], 0, false);
+            p01 = __builtin_amdgcn_cvt_pk_bf8_f32(x[2], x[3], p01, true);
+            g0 = (uint32_t)p01;
+            f32x2 lo = __builtin_amdgcn_cvt_pk_f32_bf8(p01, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8(p01, true);
+            float r0 = x[0] - lo[0], r1 = x[1] - lo[1], r2 = x[2] - hi[0], r3 = x[3] - hi[1];
+            int p1 = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, 0, false);
+            p1 = __builtin_amdgcn_cvt_pk_bf8_f32(r2, r3, p1, true);
+            g1 = (uint32_t)p1;
+            lo = __builtin_amdgcn_cvt_pk_f32_bf8(p1, false); hi = __builtin_amdgcn_cvt_pk_f32_bf8(p1, true);
+            r0 -= lo[0]; r1 -= lo[1]; r2 -= hi[0]; r3 -= hi[1];
+            int p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, 0, false);
+            p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r2, r3, p2, true);
+            g2 = (uint32_t)p2;
+        }
+        {
+            const int go = (mt_o * 16 + (lane & 15)) * TR + nt_o * 16 + (lane >> 4) * 4;
+            *(uint32_t*)(G8 + go) = g0;
+            *(uint32_t*)(G8 + BQ * TR + go) = g1;
+            *(uint32_t*)(G8 + 2 * BQ * TR + go) = g2;
+        }
+        if (nt_o == 0 && lane < 16) As[mt_o * 16 + lane] = alpha;
+        __syncthreads();
+        {
+            const float a0 = As[lane & 15], a1 = As[16 + (lane & 15)];
+            if (__any(a0 != 1.0f || a1 != 1.0f)) {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) { dq[0][dt] *= a0; dq[1][dt] *= a1; }
+            }
+        }
+        // ---- dq[q][d] += sum_key G[q][key] raw[key][d]:  D[i = d][j = query], k = key (one 32-step, three bf8 terms)
+        long gf[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                gf[pl][mt] = *(const long*)(G8 + pl * BQ * TR + (mt * 16 + (lane & 15)) * TR + (lane >> 4) * 8);
+        const int trow = (lane >> 4) * 8 + ((lane & 15) >> 1);                   // the row this lane hands to the transpose read
+        const char* tbase = T + trow * D + (lane & 1) * 8;
+        const int tsw = fp8_swz<D>(trow);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int c = (w * DW + dt * 16) >> 4;
+            const v2i av = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(tbase + ((c ^ tsw) << 4)));
+            const long af = (long)(((unsigned long)(unsigned)av[1] << 32) | (unsigned long)(unsigned)av[0]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dq[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(af, gf[pl][mt], dq[mt][dt], 0, 0, 0);
+        }
+    }
+
+    // ---- chunk partial of dq (fp32, x c2 / 8) and the chunk statistics, as the FUSED epilogue of bank_stream_kernel
+    const float o_mul = ldexpf(0.125f, c2e);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = q0 + mt * 16 + (lane & 15);
+        if (q >= a.B) continue;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+            *(f32x4*)(Op + ((size_t)mi * a.B + q) * D + w * DW + dt * 16 + (lane >> 4) * 4) = dq[mt][dt] * o_mul;
+    }
+    __syncthreads();
+    float* Fin = Sp;
+    float* f = Fin + ((w * 64 + lane) * 4);
+    f[0] = st_m; f[1] = st_l; f[2] = st_sl; f[3] = st_lab;
+    __syncthreads();
+    if (tid < BQ) {
+        const int mt = tid >> 4, ql_ = tid & 15;
+        float m = -INFINITY, l = 0.f, sl = 0.f, lab = -INFINITY;
+        for (int nt = 0; nt < 2; ++nt)
+            for (int g = 0; g < 4; ++g) {
+                const float* p = Fin + (((mt * 2 + nt) * 64 + g * 16 + ql_) * 4);
+                m = fmaxf(m, p[0]);
+                l += p[1];
+                sl += p[2];
+                lab = fmaxf(lab, p[3]);
+            }
+        const int q = q0 + tid;
+        if (q < a.B) {
+            float* o = sp + ((size_t)mi * a.B + q) * 4;
+            o[0] = m * 0.6931471805599453f; o[1] = l; o[2] = sl; o[3] = lab;
+        }
+    }
+}
+
+template <int D>
+static int launch_bank_fp8_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
+    const size_t lds = (size_t)fp8f_stages<D>() * TR * D + 4 * 4096 + 4 * BQ * 4 + FP8_MAX_CHUNK_ROWS * 4 + 3 * BQ * TR + BQ * 4;
+    auto kern = bank_fp8_fused_kernel<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    {
+        const double bytes = (double)a.M * D + 4.0 * a.M + (double)a.B * D * 2 + (double)c.nchunks * a.B * (D * 4 + 16);
+        ProfScope prof(PK_BANK_FWD, bytes, st);
+        hipLaunchKernelGGL(kern, dim3(c.nq * c.nchunks), dim3(256), lds, st, a, c, Op, sp);
+    }
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 // SPN_BANK_FP8_MFMA=0 keeps the forward pass of an fp8 bank on the dequantise-to-bf16 path (A/B switch)
 static bool bank_fp8_mfma_on() {
     static const bool on = [] {
@@ -1249,7 +1605,7 @@ size_t bank_workspace_bytes(int B, int M, int D) {
 template <int D, bool BWD, bool FP8, bool GRP = false>
 static int launch_bank(const BankArgs& a, const BankChunking& c, const float* row_lse, float ls, float inv_m,
                        float* ws, hipStream_t st) {
-    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2;
+    const size_t lds = bank_stream_tiles_bytes<D, FP8>() + 4 * 4096 + (size_t)BQ * (TR + 8) * 2;
     auto kern = bank_stream_kernel<D, BWD, FP8, GRP>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1288,7 +1644,7 @@ static size_t fused_save_bytes(int B, int M, int D) {
 
 template <int D, bool FP8>
 static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
-    const size_t lds = 2 * (size_t)TR * D * 2 + 4 * 4096 + (size_t)BQ * (TR + 8) * 2 + BQ * sizeof(float) +
+    const size_t lds = bank_stream_tiles_bytes<D, FP8>() + 4 * 4096 + (size_t)BQ * (TR + 8) * 2 + BQ * sizeof(float) +
                        (FP8 ? (4 * BQ + 2 * TR) * sizeof(float) : 0);       // + Qm, Sst
     auto kern = bank_stream_kernel<D, true, FP8, false, true>;
     static bool attr_set = false;
@@ -1313,7 +1669,14 @@ static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStrea
     float* Op = save;                                                    // [nchunks][B][D]
     float* sp = save + (size_t)c.nchunks * a.B * a.D;
     int rc = SPN_ERR_SHAPE;
-#define SPN_FUSED(D_) case D_: rc = a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
+    // e4m3 bank: the all-fp8-MFMA kernel when the chunk's row scales fit its LDS table (SPN_BANK_FP8_FUSED=0: the kernel that
+    // dequantises each tile into a bf16 image for the dq GEMM)
+    static const bool f8 = [] {
+        const char* e = getenv("SPN_BANK_FP8_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    const bool f8k = f8 && a.bank_scale && c.rows <= FP8_MAX_CHUNK_ROWS;
+#define SPN_FUSED(D_) case D_: rc = f8k ? launch_bank_fp8_fused<D_>(a, c, Op, sp, st) : a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
     switch (a.D) {
         SPN_FUSED(128) SPN_FUSED(256) SPN_FUSED(512) SPN_FUSED(640) SPN_FUSED(768) SPN_FUSED(1024)
         default: return SPN_ERR_SHAPE;

@@ -83,6 +83,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+typedef int v2i __attribute__((ext_vector_type(2)));
+
 // LDS transpose read: within each 16-lane group the 16 lanes address a 4x16 block of 16-bit
 // elements (lane i -> row i>>2, columns (i&3)*4..+3, 8 bytes each); lane i receives column i
 // (rows 0..3).  See cdna_hip_programming.md T10.
