@@ -1235,17 +1235,21 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, Bank
         const int trow = (lane >> 4) * 8 + ((lane & 15) >> 1);                   // the row this lane hands to the transpose read
         const char* tbase = T + trow * D + (lane & 1) * 8;
         const int tsw = fp8_swz<D>(trow);
+        long af[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             const int c = (w * DW + dt * 16) >> 4;
             const v2i av = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(tbase + ((c ^ tsw) << 4)));
-            const long af = (long)(((unsigned long)(unsigned)av[1] << 32) | (unsigned long)(unsigned)av[0]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dq[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(af, gf[pl][mt], dq[mt][dt], 0, 0, 0);
+            af[dt] = (long)(((unsigned long)(unsigned)av[1] << 32) | (unsigned long)(unsigned)av[0]);
         }
+        // term-major: the three products into one accumulator are 2 NDT MFMAs apart, never back to back
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    dq[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(af[dt], gf[pl][mt], dq[mt][dt], 0, 0, 0);
     }
 
     // ---- chunk partial of dq (fp32, x c2 / 8) and the chunk statistics, as the FUSED epilogue of bank_stream_kernel
