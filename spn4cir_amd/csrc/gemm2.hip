@@ -511,6 +511,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
     uint64_t ph2 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WN, wc = wid % WN;
+    if (ep.stag_ticks > 0 && (int)blockIdx.x >= ep.stag_from && (int)blockIdx.x < ep.stag_to) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)ep.stag_ticks) __builtin_amdgcn_s_sleep(32);
+    }
     const int tiles_n = (N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
@@ -762,7 +766,24 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
         attr_set = true;
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, st, A, B, M, N, K, lda, ldb, ep);
+    // De-phasing the epilogue bursts (one workgroup per CU, equal tiles: all CUs store their 128-256 KB of output at the same
+    // time, ~8 us per round at the HBM write rate, while the matrix pipes idle).  In a launch of several rounds whose last
+    // round is partial, the CUs that will run one tile fewer have a whole tile of slack: their FIRST tile starts
+    // stag_ticks later, they stay that far behind for the rest of the launch (the dispatcher hands the last round's tiles
+    // to the CUs that free up first - the others) and their bursts fall into the main loops of the rest.
+    GemmEpilogue e = ep;
+    e.stag_from = 0;
+    e.stag_ticks = 0;
+    if constexpr (SCHED == 2) {
+        static const int stag_us = [] { const char* v = getenv("SPN_GEMM_STAGGER_US"); return v ? atoi(v) : 6; }();   // measured: 0 / 6 / 10 / 14 / 18 us -> 13.38 / 13.31 / 13.32 / 13.33 / 13.36 ms per step
+        const int cus = device_cu_count(), rem = tiles % cus;
+        if (stag_us > 0 && tiles > cus && rem > 0 && MODE != GEMM_BANKSTATS) {
+            e.stag_from = rem;                                  // first-round workgroups [rem, cus) are delayed
+            e.stag_to = cus;
+            e.stag_ticks = stag_us * 100 * (K / 768 > 0 ? K / 768 : 1);   // s_memrealtime ticks (100 MHz), scaled with the k loop
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, st, A, B, M, N, K, lda, ldb, e);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -23,6 +23,7 @@ struct GemmEpilogue {
     int act = ACT_NONE;
     float alpha = 1.0f;
     int direct_store = 0;            // gemm2 only: 1 = store from the MFMA layout (no LDS staging)
+    int stag_from = 0, stag_to = 0, stag_ticks = 0;   // gemm2: first-round workgroups [stag_from, stag_to) start stag_ticks (100 MHz) late
     // GEMM_BANKSTATS (gemm2, 256x256 tile only): A = queries [B, D], B = bank rows [M, D]; nothing is stored but the
     // per-row softmax statistics of each 256-column tile: bs_out[(tile_n * B + row) * 4] = {max, sum exp, sum, label logit}
     // of logits * bs_inv_tau (the layout bank_stats_fold_kernel reduces)
