@@ -102,6 +102,16 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
     constexpr int ITERS = CHUNK / (NW * RPI);
     static_assert(BM % CHUNK == 0 && CHUNK % (NW * RPI) == 0 && CHUNK % 32 == 0, "full-tile epilogue geometry");
     float* sC = (float*)smem;
+#ifdef SPN_GEMM_PROBES
+    // SPN_GEMM_DBG bit 128: cycle stamps of the epilogue's sub-phases (mid-grid block, wave 0), over output bytes 16..
+    uint32_t stamp[12];
+    int ns = 0;
+    const bool probe = (SPN_DBG(ep) & 128) && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    const uint64_t pt0 = __builtin_readcyclecounter();
+#define SPN_EPI_STAMP() do { if (ns < 12) stamp[ns++] = (uint32_t)(__builtin_readcyclecounter() - pt0); } while (0)
+#else
+#define SPN_EPI_STAMP() do { } while (0)
+#endif
     const int u = lane % LPR, n = n0 + u * 8;
     f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
     if (ep.bias) {
@@ -127,6 +137,7 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
             }
         }
         __syncthreads();   // operand tiles (or the previous chunk) are no longer read
+        SPN_EPI_STAMP();
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if ((wr * TM + i * 32) / CHUNK != ch) continue;       // wave-uniform; compile-time when TM <= CHUNK
@@ -140,7 +151,9 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
                     *(f32x4*)(sC + r * BN + (stage_slot<BN>(unit, r) << 2)) = v;
                 }
         }
+        SPN_EPI_STAMP();
         __syncthreads();
+        SPN_EPI_STAMP();
         // read-back in batches of RB rows: all LDS reads of a batch in flight, then its math and stores
         constexpr int RB = ITERS >= 4 ? 4 : ITERS;
         static_assert(ITERS % RB == 0, "read-back batches");
@@ -211,7 +224,17 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
             if constexpr (OUT_BF16) *(bf16x8*)(ep.out_bf16 + o) = pack8(v0, v1);
         }
         }
+        SPN_EPI_STAMP();
     }
+#ifdef SPN_GEMM_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SPN_EPI_STAMP();
+    if (probe) {
+        uint32_t* o = ep.out_f32 ? (uint32_t*)ep.out_f32 : (uint32_t*)ep.out_bf16;
+        for (int q = 0; q < 12; ++q) o[4 + q] = q < ns ? stamp[q] : 0u;
+    }
+#endif
+#undef SPN_EPI_STAMP
 }
 
 // Epilogue shared by the NT kernels.  (B-frag, A-frag) operand order: lane owns row m = lane&31 and, for g = 0..3,
