@@ -304,7 +304,8 @@ def test_bank_saved_logits_pair(ops, B, M, D, tau, fp8):
 @pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
 @pytest.mark.parametrize("B,M,D,tau", [(32, 40000, 768, 0.02), (4, 500, 128, 0.01), (32, 4099, 512, 0.02), (70, 3000, 768, 0.02),
                                         (33, 1500, 640, 0.02), (1, 7, 128, 0.02), (3, 33, 256, 0.01), (127, 9001, 1024, 0.05),
-                                        (16, 100000, 768, 0.02), (129, 2000, 256, 0.02), (200, 6000, 768, 0.01)])
+                                        (16, 100000, 768, 0.02), (129, 2000, 256, 0.02), (200, 6000, 768, 0.01),
+                                        (4, 540000, 128, 0.02)])      # > 2 048 rows per chunk: the e4m3 kernel with a bf16 tile image
 def test_bank_fused_single_pass(ops, B, M, D, tau, fp8):
     """Default routing of the pair: ONE pass over the bank computes the softmax statistics and the unnormalised query
     gradient (flash-attention recurrence: running row maximum + rescale), the backward call only folds the chunk
