@@ -1244,7 +1244,8 @@ template <int BM, int BN, int WM, int WN, int STAGES, int SCHED>
 __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int Kr, int N1, int N2,
                                          int lda, int ldb, float* __restrict__ Cz, int ldc, float* __restrict__ colsum_out,
                                          int m0, int n0, int kb, int ke, uint32_t* pace = nullptr,
-                                         uint32_t pace_members = 0, int cs_mod = 0, int cs_rem = 0, int pace_lag = 0) {
+                                         uint32_t pace_members = 0, int cs_mod = 0, int cs_rem = 0, int pace_lag = 0,
+                                         float* __restrict__ cs_part = nullptr) {
     constexpr int NW = WM * WN;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 k rows x cols x 2 B
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
@@ -1434,7 +1435,7 @@ __device__ __forceinline__ void tn2_tile(const bf16_t* __restrict__ A, const bf1
     }
     if (cs_spread && lane < 32) {
         const int m = m0 + wr * TM + wc * 32 + lane;
-        if (m < N1) unsafeAtomicAdd(colsum_out + m, accs[0][0]);
+        if (m < N1) cs_part[(size_t)cs_rem * N1 + m] = accs[0][0];      // this tile's share; tn_colsum_fold_kernel adds the row's shares in order
     }
     // split-K partials leave through LDS (same staging as gemm_nt2's epilogue): the MFMA layout would store 16 B
     // per row per instruction; row-major, one wave instruction writes two whole 512-B rows.
@@ -1526,14 +1527,25 @@ struct TnGroup {
     float* slabs;                            // [tail_splits][tail][256*256] partial tiles, then [tail_splits][tail][256] column sums
     uint32_t* pace;                          // k pacing counters, one 128-byte line per (XCD, round) of whole tiles; NULL = off
     int pace_lag;                            // phases (of 2 k tiles) a member may run ahead of the slowest one
-    int cs_spread;                           // 1 = column sums shared by the tiles of a row (tn_zero_colsum_kernel ran before)
+    float* cs_part;                          // shared column sums: per problem [tiles_n][N1] partial sums at cs_off[p]; NULL = off
+    int cs_off[TN_GROUP_MAX];
 };
 
-// zeroes the column-sum outputs of a grouped launch whose tiles add their shares atomically (one workgroup per problem)
-__global__ void tn_zero_colsum_kernel(const TnGroup g) {
-    const TnProblem& P = g.p[blockIdx.x];
-    if (P.colsum)
-        for (int i = threadIdx.x; i < P.N1; i += blockDim.x) P.colsum[i] = 0.f;
+// adds the per-tile shares of the column sums in tile order (one workgroup per problem); tile rows that are not shared
+// (a tile of the row is a split tail tile) were written by their n0 == 0 tile / the tail reduction and are skipped
+__global__ void tn_colsum_fold_kernel(const TnGroup g) {
+    const int pi = blockIdx.x;
+    const TnProblem& P = g.p[pi];
+    if (!P.colsum) return;
+    const int tiles_n = (P.N2 + 255) / 256;
+    const float* part = g.cs_part + g.cs_off[pi];
+    for (int m = threadIdx.x; m < P.N1; m += blockDim.x) {
+        const int row_last = g.tile_begin[pi] + (m / 256) * tiles_n + tiles_n - 1;
+        if (row_last >= g.full) continue;
+        float s = 0.f;
+        for (int j = 0; j < tiles_n; ++j) s += part[(size_t)j * P.N1 + m];
+        P.colsum[m] = s;
+    }
 }
 
 __device__ __forceinline__ int tn_group_find(const TnGroup& g, int tile) {
@@ -1564,11 +1576,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_tn2_group_ker
     if (whole) {
         // pace group = the 32 whole tiles one XCD runs in one round (block b sits on XCD b % 8, in dispatch order)
         uint32_t* pace = g.pace ? g.pace + (size_t)((((int)blockIdx.x >> 3) / 32) * 8 + ((int)blockIdx.x & 7)) * 32 : nullptr;
-        // the tile row's column sums are shared by its tiles when all of them are whole tiles (g.cs_spread: colsum zeroed)
+        // the tile row's column sums are shared by its tiles when all of them are whole tiles
         const int row_last = g.tile_begin[pi] + (bid / tiles_n) * tiles_n + tiles_n - 1;
-        const bool spread = g.cs_spread && row_last < g.full;
+        const bool spread = g.cs_part != nullptr && P.colsum != nullptr && row_last < g.full;
         tn2_tile<BM, BN, WM, WN, STAGES, SCHED>(P.A, P.B, Kr, P.N1, P.N2, P.lda, P.ldb, P.C, P.ldc, P.colsum, m0, n0, 0, Kr, pace,
-                                                32u, spread ? tiles_n : 0, spread ? bid % tiles_n : 0, g.pace_lag);
+                                                32u, spread ? tiles_n : 0, spread ? bid % tiles_n : 0, g.pace_lag,
+                                                spread ? g.cs_part + g.cs_off[pi] : nullptr);
     } else {
         // slab of (z, tail tile): a dense [BM][BN] tile; the pointers are biased so that the tile's own (m0, n0) indexing of
         // a [*, BN] matrix lands in it (never dereferenced outside the slab: rows / columns beyond N1 / N2 are masked)
@@ -1735,6 +1748,7 @@ int device_cu_count() {
 }
 
 static constexpr size_t TN_PACE_BYTES = 64 * 1024;          // pacing counters: 128 B per (XCD, round), <= 512 groups
+static constexpr size_t TN_CS_BYTES = 4 * 1024 * 1024;      // shared column sums: per-tile partial sums of a grouped launch
 
 // SPN_TN_PACE=1 turns the k pacing of the grouped launch on.  Default OFF, measured (round 3, same box, bench step):
 // without 13.32 ms / step, grouped launch 1 243 TFLOP/s; with 14.29 ms, 882 TFLOP/s.  The tiles of a group are not equally
@@ -1750,7 +1764,7 @@ static bool tn_pace_on() {
 
 size_t gemm_tn_grouped_workspace_bytes(int Kr) {
     (void)Kr;
-    return (size_t)device_cu_count() * (256 * 256 + 256) * sizeof(float) + TN_PACE_BYTES;   // at most one slab per CU
+    return (size_t)device_cu_count() * (256 * 256 + 256) * sizeof(float) + 256 + TN_PACE_BYTES + TN_CS_BYTES;   // at most one slab per CU
 }
 
 int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st) {
@@ -1798,20 +1812,26 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
         g.pace = (uint32_t*)((char*)ws + ((slab_bytes + 255) & ~(size_t)255));
         if (hipMemsetAsync(g.pace, 0, (size_t)groups * 128, st) != hipSuccess) g.pace = nullptr;
     }
-    // shared column sums (SPN_TN_CS_SPREAD=0: the n0 == 0 tile of every row computes them alone, as in round 2)
+    // shared column sums (SPN_TN_CS_SPREAD=0: the n0 == 0 tile of every row computes them alone, as in round 2): partial
+    // sums [tiles_n][N1] per problem behind the slabs and the pacing counters
     static const bool cs_spread = [] {
         const char* e = getenv("SPN_TN_CS_SPREAD");
         return !(e && e[0] == '0');
     }();
-    g.cs_spread = 0;
-    if (cs_spread) {
+    g.cs_part = nullptr;
+    if (cs_spread && ws) {
+        size_t need = 0;
         bool any = false;
-        for (int i = 0; i < n; ++i) any = any || probs[i].colsum != nullptr;
-        if (any) {
-            hipLaunchKernelGGL(tn_zero_colsum_kernel, dim3(n), dim3(256), 0, st, g);
-            SPN_CHECK_LAUNCH();
-            g.cs_spread = 1;
+        for (int i = 0; i < n; ++i) {
+            g.cs_off[i] = (int)need;
+            if (probs[i].colsum) {
+                any = true;
+                need += (size_t)((probs[i].N2 + 255) / 256) * probs[i].N1;
+            }
         }
+        const size_t base = ((slab_bytes + 255) & ~(size_t)255) + TN_PACE_BYTES;
+        if (any && need * sizeof(float) <= TN_CS_BYTES && ws_bytes >= base + need * sizeof(float))
+            g.cs_part = (float*)((char*)ws + base);
     }
     constexpr int LDS = 2 * (256 + 256) * 128;
     auto kern = gemm_tn2_group_kernel<256, 256, 2, 4, 2, 2>;
@@ -1827,6 +1847,10 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
         SPN_CHECK_LAUNCH();
         if (tail) {
             hipLaunchKernelGGL(tn_tail_reduce_kernel, dim3(tail, 32), dim3(256), 0, st, g);
+            SPN_CHECK_LAUNCH();
+        }
+        if (g.cs_part) {
+            hipLaunchKernelGGL(tn_colsum_fold_kernel, dim3(n), dim3(256), 0, st, g);
             SPN_CHECK_LAUNCH();
         }
     }
