@@ -1531,7 +1531,7 @@ struct TnGroup {
     int cs_off[TN_GROUP_MAX];
 };
 
-// adds the per-tile shares of the column sums in tile order (one workgroup per problem); tile rows that are not shared
+// adds the per-tile shares of the column sums in tile order (grid: problems x 256-column blocks); tile rows that are not shared
 // (a tile of the row is a split tail tile) were written by their n0 == 0 tile / the tail reduction and are skipped
 __global__ void tn_colsum_fold_kernel(const TnGroup g) {
     const int pi = blockIdx.x;
@@ -1539,10 +1539,11 @@ __global__ void tn_colsum_fold_kernel(const TnGroup g) {
     if (!P.colsum) return;
     const int tiles_n = (P.N2 + 255) / 256;
     const float* part = g.cs_part + g.cs_off[pi];
-    for (int m = threadIdx.x; m < P.N1; m += blockDim.x) {
+    for (int m = blockIdx.y * blockDim.x + threadIdx.x; m < P.N1; m += gridDim.y * blockDim.x) {
         const int row_last = g.tile_begin[pi] + (m / 256) * tiles_n + tiles_n - 1;
         if (row_last >= g.full) continue;
         float s = 0.f;
+#pragma unroll 4
         for (int j = 0; j < tiles_n; ++j) s += part[(size_t)j * P.N1 + m];
         P.colsum[m] = s;
     }
@@ -1850,7 +1851,7 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
             SPN_CHECK_LAUNCH();
         }
         if (g.cs_part) {
-            hipLaunchKernelGGL(tn_colsum_fold_kernel, dim3(n), dim3(256), 0, st, g);
+            hipLaunchKernelGGL(tn_colsum_fold_kernel, dim3(n, 16), dim3(256), 0, st, g);
             SPN_CHECK_LAUNCH();
         }
     }
