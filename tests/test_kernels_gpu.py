@@ -699,6 +699,28 @@ def test_topk_identical_sets(ops, golden_dir):
         assert list(got2[i]) == row
 
 
+@pytest.mark.parametrize("Ng,K", [(6000, 50), (40000, 50), (300, 256), (37, 50), (5000, 1), (1000, 10)])
+def test_topk_ties_and_edges(ops, Ng, K):
+    """Top-K selection (radix select on (score, ~index)): heavy ties (scores drawn from 7 distinct values, so the K-th score
+    is always tied), ascending-index tie rule, an excluded column per row, fewer candidates than K (-1 fill), K = 1."""
+    g = torch.Generator().manual_seed(Ng + K)
+    Nq = 9
+    vals = torch.tensor([-0.5, -0.25, 0.0, 0.125, 0.3, 0.3000000001, 0.9], dtype=torch.float64)
+    scores = vals[torch.randint(0, 7, (Nq, Ng), generator=g)]
+    scores[1] = 0.25                                           # a whole row of equal scores
+    scores[2] = torch.randn(Ng, generator=g, dtype=torch.float64)     # and one without ties
+    ex = torch.randint(0, Ng, (Nq,), generator=g).to(torch.int32)
+    for exclude in (None, ex):
+        idx, val = ops.topk_from_scores(dev(scores), K, exclude=None if exclude is None else dev(exclude))
+        idx, val = idx.cpu(), val.cpu()
+        for i in range(Nq):
+            order = sorted((j for j in range(Ng) if exclude is None or j != int(exclude[i])),
+                           key=lambda j: (-scores[i, j].item(), j))[:K]
+            want = order + [-1] * (K - len(order))
+            assert idx[i].tolist() == want, (i, Ng, K)
+            assert torch.equal(val[i, :len(order)], scores[i, order])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (4096, 768, 768), (19712, 768, 3072), (1000, 260, 192)])
 def test_gemm_nt_phased_schedule_race_screen(ops, M, N, K):
     """The staggered 8-slot schedule orders LDS-DMA writes and ds_reads only by counted vmcnt + barriers.
