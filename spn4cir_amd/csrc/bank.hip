@@ -1635,7 +1635,7 @@ static bool bank_fused_on() { return bank_mode() != 3; }
 static bool bank_fused_large() { return bank_mode() == 2; }
 bool bank_fused_ok(const BankArgs& a) {
     if (!bank_fused_on() || a.group || a.B <= 0) return false;
-    if (a.bank_scale && a.B >= 128) return false;          // large e4m3 batches expand the shard once per pass instead
+    if (a.bank_scale && a.B >= 256) return false;          // large e4m3 batches expand the shard once per pass instead
     switch (a.D) {
         case 128: case 256: case 512: case 640: case 768: case 1024: return true;
         default: return false;
