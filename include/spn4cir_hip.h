@@ -150,11 +150,11 @@ size_t spn_bank_workspace_bytes(int B, int M, int D);
 /* The forward/backward PAIR of one step: logits_save is spn_bank_logits_bytes(B, M) bytes of device scratch written by the
  * forward call and read by the backward call of the SAME (q, bank, labels, B, M, D, m_begin, inv_tau) - what autograd keeps
  * for `(q @ bank.T) / tau` (models_negplus.py:150-153), in whichever form the shape's kernels want:
- *   default below 256 queries (any B the GEMM pair does not take; e4m3 banks below 256 queries): ONE pass over the bank.  The
+ *   default below 192 queries (any B the GEMM pair does not take; e4m3 banks below 256 queries): ONE pass over the bank.  The
  *     forward call computes the statistics AND the unnormalised query gradient sum_j 2^(z_j log2e - r) bank_j per bank chunk
  *     (flash-attention recurrence; scratch = the chunk partials); the backward call folds them with row_lse and subtracts
  *     the label row - it does not read the bank again.  With label_smoothing != 0 the backward call recomputes instead.
- *   B >= 256 (B % 8 == 0, D >= 512, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
+ *   B >= 192 (B % 8 == 0, D >= 512, bf16 bank): the forward GEMM's epilogue keeps p = exp(logit - tile max) in bf16 and the
  *     backward pass is a transpose-and-scale launch (G^T) plus ONE weight-gradient-shaped GEMM dq = (G^T)^T bank.
  *   spn_bank_config(1), B < 128: barrier-free streaming kernels (csrc/bank2.hip), fp32 logits kept (B * M * 4 B).
  *   otherwise (token-max banks, e4m3 banks at B >= 256): the pair runs the two calls above - same results, logits_save

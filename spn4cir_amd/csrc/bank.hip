@@ -1813,7 +1813,10 @@ static bool bank_gemm_on() {
 // 128 x 256 output is two tiles, the split-K GEMM cannot fill the chip with it - so the path is taken from 256 queries and
 // 512 columns; below that the recomputing stream kernel stays.
 bool bank_saved_path_large(const BankArgs& a) {
-    return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= 256 && a.B % 8 == 0 && a.D >= 512 && a.D % 64 == 0;
+    // crossover against the fused stream pass at M = 40 000, D = 768 (rocprofv3, pair vs fused): B = 160: 81.7 vs 77.7 us, 192: 83.3
+    // vs 87.4, 224: 88.7 vs 96.5, 256: 90.7 vs 111
+    static const int min_b = env_int_min1("SPN_BANK_GEMM_PAIR_MIN", 192);
+    return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= min_b && a.B % 8 == 0 && a.D >= 512 && a.D % 64 == 0;
 }
 static size_t fused_save_bytes(int B, int M, int D);
 size_t bank_saved_bytes_any(int B, int M) {

@@ -401,7 +401,7 @@ def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=True, split_q=Tr
 
 
 @pytest.mark.parametrize("mode", [0, 2], ids=["gemm-pair", "fused"])
-@pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (264, 5001, 512, 0.02),
+@pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (264, 5001, 512, 0.02), (192, 5000, 768, 0.02),
                                         (512, 8000, 768, 0.02), (256, 3000, 1024, 0.05)])
 def test_bank_saved_pair_large_batch(ops, B, M, D, tau, mode):
     """B >= 128: the forward GEMM keeps p = exp(logit - tile max) and the backward pass is G^T + ONE weight-gradient-shaped
