@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         } else {
             wait_vm0();
         }
-        __syncthreads();
+        lds_barrier();
         [[maybe_unused]] float sc_cur[FP8 ? D / 128 : 1];
         if constexpr (FP8) {
 #pragma unroll
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             }
             if constexpr (!F8L) {
                 dequant(t, rbuf, sc_cur);
-                __syncthreads();
+                lds_barrier();
             }
         } else {
             if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = s[mt][nt];
-        __syncthreads();
+        lds_barrier();
         f32x4 sv = {0, 0, 0, 0};
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
             *(bf16x4*)(Gs + (mt_o * 16 + (lane & 15)) * LDG + nt_o * 16 + (lane >> 4) * 4) = gb;
         }
         if constexpr (BWD) {
-            __syncthreads();
+            lds_barrier();
             if constexpr (FUSED) {                       // the accumulators follow the row maximum (lane: query lane & 15 of each mt)
                 const float a0 = As[lane & 15], a1 = As[16 + (lane & 15)];
                 if (__any(a0 != 1.0f || a1 != 1.0f)) {   // the maximum moves in the first tiles of a chunk, then rarely
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fwd_kernel(BankArgs a, BankCh
             am[mt] = fmaxf(am[mt], __shfl_xor(am[mt], 32, 64));
             if ((lane >> 4) == 0) Qm[w * 32 + mt * 16 + lane] = am[mt];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             float m = 0.f;
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fwd_kernel(BankArgs a, BankCh
         else if (behind == 2) wait_vmcnt<2 * NDMA>();
         else if (behind == 1) wait_vmcnt<NDMA>();
         else wait_vmcnt<0>();
-        __syncthreads();
+        lds_barrier();
         const char* T = tiles + buf * RAW_B;
         f32x4 sh[2][2], sl4[2][2];
 #pragma unroll
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fwd_kernel(BankArgs a, BankCh
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = sh[mt][nt] + sl4[mt][nt] * 0.0625f;
-        __syncthreads();
+        lds_barrier();
         f32x4 sv = {0, 0, 0, 0};
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) sv += *(const f32x4*)(Sp + (((ww * 2 + mt_o) * 2 + nt_o) * 64 + lane) * 4);
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, Bank
         else if (behind == 2) wait_vmcnt<2 * NDMA>();
         else if (behind == 1) wait_vmcnt<NDMA>();
         else wait_vmcnt<0>();
-        __syncthreads();
+        lds_barrier();
         if (t + S - 1 < ntiles) stage(t + S - 1);
         const char* T = tiles + (t % S) * RAW_B;
         f32x4 sh[2][2], sl4[2][2];
@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, Bank
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 *(f32x4*)(Sp + (((w * 2 + mt) * 2 + nt) * 64 + lane) * 4) = sh[mt][nt] + sl4[mt][nt] * 0.0625f;
-        __syncthreads();
+        lds_barrier();
         // ---- statistics + G (bank_stream_kernel's FUSED branch: integer lazy reference exponent, label key kept out of G)
         f32x4 sv = {0, 0, 0, 0}, so = {0, 0, 0, 0};
 #pragma unroll
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, Bank
             *(uint32_t*)(G8 + 2 * BQ * TR + go) = g2;
         }
         if (nt_o == 0 && lane < 16) As[mt_o * 16 + lane] = alpha;
-        __syncthreads();
+        lds_barrier();
         {
             const float a0 = As[lane & 15], a1 = As[16 + (lane & 15)];
             if (__any(a0 != 1.0f || a1 != 1.0f)) {

@@ -83,6 +83,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Workgroup barrier for loops that keep LDS-DMA (buffer_load ... lds) in flight across it: __syncthreads() is a
+// workgroup-scope fence, and hipcc counts a pending LDS-DMA as an LDS write of the wave - it emits `s_waitcnt vmcnt(0)` in
+// front of the barrier and drains every prefetched tile (seen in the ISA of the bank kernels: each 32-row tile waited for the
+// tile requested a few hundred cycles earlier).  This form waits for the wave's own ds_* traffic only; completion of the
+// DMA'd tile a phase is about to read is the caller's counted `s_waitcnt vmcnt(N)` BEFORE the barrier, as in the GEMM loops.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 typedef int v2i __attribute__((ext_vector_type(2)));
 
 // LDS transpose read: within each 16-lane group the 16 lanes address a 4x16 block of 16-bit
