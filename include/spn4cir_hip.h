@@ -164,7 +164,8 @@ size_t spn_bank_logits_bytes(int B, int M);
 /* Routing of the pair, process-wide like the SPN_* environment knobs; every mode gives the same results within the
  * documented tolerances: 0 = default (above); 1 = second-generation streaming kernels below 128 queries (also SPN_BANK2=1;
  * slower at 40 000-row banks); 2 = the fused single pass at every batch size (SPN_BANK_FUSED_LARGE=1);
- * 3 = two passes everywhere (SPN_BANK_FUSED=0). */
+ * 3 = two passes everywhere (SPN_BANK_FUSED=0); 4 = default routing, but the fused pass over an e4m3 bank on the kernel that
+ * dequantises each tile into a bf16 image for the dq GEMM (otherwise only taken beyond 2 048 rows per chunk). */
 int spn_bank_config(int mode);
 int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
                             int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,

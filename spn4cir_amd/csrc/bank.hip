@@ -138,10 +138,10 @@ struct BankChunking {
     int rows;       // rows per chunk (multiple of TR)
 };
 
-static BankChunking bank_chunking(int B, int M) {
+static BankChunking bank_chunking(int B, int M, int blocks = 256) {
     BankChunking c;
     c.nq = (B + BQ - 1) / BQ;
-    int n = 256 / c.nq;
+    int n = blocks / c.nq;
     if (n < 1) n = 1;
     const int tiles = (M + TR - 1) / TR;
     if (n > tiles) n = tiles;
@@ -605,19 +605,36 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 gf[mt] = *(const bf16x8*)(Gs + (mt * 16 + (lane & 15)) * LDG + (lane >> 4) * 8);
+            // transposed fragments through the asm read (no vmcnt(0) in front of them, common.h), in two halves: the MFMAs of
+            // the first run while the second half's reads return
+            union TF { s16x4 h[2]; bf16x8 v; } u[NDT];
+            constexpr int H1 = (NDT + 1) / 2;
+            lds_tie(gf[0]);                                  // the G fragments are read (and waited for) before the asm reads
+            lds_tie(gf[1]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                union { s16x4 h[2]; bf16x8 v; } u;
                 const int cb = w * DW + dt * 16;   // first column of this d tile
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
                     const int col = cb + (lane & 3) * 4;
-                    u.h[h] = lds_tr16_b64(T + r * ROWB + (((col >> 3) ^ bank_swz(r & 15)) << 4) + (col & 7) * 2);
+                    u[dt].h[h] = lds_tr16_b64_asm(T + r * ROWB + (((col >> 3) ^ bank_swz(r & 15)) << 4) + (col & 7) * 2);
                 }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) dq[mt][dt] = mfma16b(u.v, gf[mt], dq[mt][dt]);
             }
+            wait_lgkm<2 * (NDT - H1)>();
+#pragma unroll
+            for (int dt = 0; dt < H1; ++dt) { lds_tie(u[dt].h[0]); lds_tie(u[dt].h[1]); }
+#pragma unroll
+            for (int dt = 0; dt < H1; ++dt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) dq[mt][dt] = mfma16b(u[dt].v, gf[mt], dq[mt][dt]);
+            wait_lgkm<0>();
+#pragma unroll
+            for (int dt = H1; dt < NDT; ++dt) { lds_tie(u[dt].h[0]); lds_tie(u[dt].h[1]); }
+#pragma unroll
+            for (int dt = H1; dt < NDT; ++dt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) dq[mt][dt] = mfma16b(u[dt].v, gf[mt], dq[mt][dt]);
         }
     }
 
@@ -992,19 +1009,24 @@ static int launch_bank_fp8_fwd(const BankArgs& a, const BankChunking& c, float* 
 // No bf16 image means no dequantisation pass (a quarter of the F8L kernel's time) and LDS for a five-deep raw ring: four
 // 24 KB tiles in flight per CU, the bytes a streaming bf16 kernel keeps in flight with one.
 static constexpr int FP8F_SLACK = 12;
+// Two workgroups per CU (256 registers per wave, LDS within 80 KB: two or three raw stages): a tile costs a workgroup ~6 000
+// cycles of barrier-separated phases (cycle stamps: 390 DMA issue, 1 480 logits, 1 370 statistics, 1 910 dq, ~900 in
+// barriers) whatever the ring depth, so a second workgroup fills the other's stalls: 141 -> 103 us at 16 x 400 000 x 768 with
+// 512 chunks; with 256 chunks (one workgroup per CU) the 250-register code is no slower than the 354-register, five-stage
+// one (131.7 vs 141.3 us).  D = 1 024 keeps one workgroup per CU (two 32 KB stages + 28 KB).
 template <int D>
 static constexpr int fp8f_stages() {
     constexpr int rest = 4 * 4096 + 4 * BQ * 4 + FP8_MAX_CHUNK_ROWS * 4 + 3 * BQ * TR + BQ * 4 + 64;
-    constexpr int s = (160 * 1024 - rest) / (TR * D);
-    return s > 5 ? 5 : s;
+    constexpr int s = (80 * 1024 - rest) / (TR * D);
+    return s > 5 ? 5 : (s < 2 ? 2 : s);
 }
 
 template <int D>
-__global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, BankChunking ck, float* __restrict__ Op,
+__global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, BankChunking ck, float* __restrict__ Op,
                                                                float* __restrict__ sp) {
     constexpr int DW = D / 4, KSW = DW / 32, NDT = DW / 16, RAW_B = TR * D;
     constexpr int S = fp8f_stages<D>(), NDMA = D / 128;
-    static_assert(S >= 3 && (S - 1) * NDMA <= 63 && D % 128 == 0, "bank width");
+    static_assert(S >= 2 && (S - 1) * NDMA <= 63 && D % 128 == 0, "bank width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tiles = smem;                                   // S x RAW_B
     float* Sp = (float*)(smem + S * RAW_B);               // [4 waves][2 mt][2 nt][64 lanes][4]; reused as Fin at the end
@@ -1236,11 +1258,21 @@ __global__ __launch_bounds__(256, 1) void bank_fp8_fused_kernel(BankArgs a, Bank
         const char* tbase = T + trow * D + (lane & 1) * 8;
         const int tsw = fp8_swz<D>(trow);
         long af[NDT];
+        {
+            v2i av[NDT];
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const int c = (w * DW + dt * 16) >> 4;
-            const v2i av = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i*)(tbase + ((c ^ tsw) << 4)));
-            af[dt] = (long)(((unsigned long)(unsigned)av[1] << 32) | (unsigned long)(unsigned)av[0]);
+            for (int pl = 0; pl < 3; ++pl) { lds_tie(gf[pl][0]); lds_tie(gf[pl][1]); }   // G fragments are in before the asm reads
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int c = (w * DW + dt * 16) >> 4;
+                av[dt] = lds_tr8_b64_asm(tbase + ((c ^ tsw) << 4));      // asm read: no vmcnt(0) in front of it (common.h)
+            }
+            wait_lgkm<0>();
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                lds_tie(av[dt]);
+                af[dt] = (long)(((unsigned long)(unsigned)av[dt][1] << 32) | (unsigned long)(unsigned)av[dt][0]);
+            }
         }
         // term-major: the three products into one accumulator are 2 NDT MFMAs apart, never back to back
 #pragma unroll
@@ -1641,8 +1673,15 @@ bool bank_fused_ok(const BankArgs& a) {
         default: return false;
     }
 }
+// workgroups of the fused pass: 512 (two per CU) for an e4m3 bank once a workgroup of a 256-block grid would walk 24 or more
+// tiles (measured: equal at 100 000 rows and B = 32, 141 -> 103 us at 400 000 rows; at 40 000 rows the extra partials cost
+// more than the overlap gives), 256 otherwise
+static int fused_blocks(int B, int M, bool fp8, int D) {
+    const int nq = (B + BQ - 1) / BQ, per = ((M + TR - 1) / TR) / (256 / nq > 0 ? 256 / nq : 1);
+    return (fp8 && D <= 768 && per >= 24) ? 512 : 256;
+}
 static size_t fused_save_bytes(int B, int M, int D) {
-    const BankChunking c = bank_chunking(B, M);
+    const BankChunking c = bank_chunking(B, M, fused_blocks(B, M, true, 768));     // the larger of the two chunk counts
     return (size_t)c.nchunks * B * (D + 4) * sizeof(float);     // fp32 partials + {m, l, sum z, label z}
 }
 
@@ -1669,7 +1708,7 @@ static int launch_bank_fused(const BankArgs& a, const BankChunking& c, float* Op
 }
 
 static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStream_t st) {
-    const BankChunking c = bank_chunking(a.B, a.M);
+    const BankChunking c = bank_chunking(a.B, a.M, fused_blocks(a.B, a.M, a.bank_scale != nullptr, a.D));
     float* Op = save;                                                    // [nchunks][B][D]
     float* sp = save + (size_t)c.nchunks * a.B * a.D;
     int rc = SPN_ERR_SHAPE;
@@ -1679,7 +1718,7 @@ static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStrea
         const char* e = getenv("SPN_BANK_FP8_FUSED");
         return !(e && e[0] == '0');
     }();
-    const bool f8k = f8 && a.bank_scale && c.rows <= FP8_MAX_CHUNK_ROWS;
+    const bool f8k = f8 && bank_mode() != 4 && a.bank_scale && c.rows <= FP8_MAX_CHUNK_ROWS;
 #define SPN_FUSED(D_) case D_: rc = f8k ? launch_bank_fp8_fused<D_>(a, c, Op, sp, st) : a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
     switch (a.D) {
         SPN_FUSED(128) SPN_FUSED(256) SPN_FUSED(512) SPN_FUSED(640) SPN_FUSED(768) SPN_FUSED(1024)
@@ -1691,7 +1730,7 @@ static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStrea
 }
 
 static int bank_fused_bwd(const BankArgs& a, const float* save, const float* row_lse, float grad_scale, float* dq, hipStream_t st) {
-    const BankChunking c = bank_chunking(a.B, a.M);
+    const BankChunking c = bank_chunking(a.B, a.M, fused_blocks(a.B, a.M, a.bank_scale != nullptr, a.D));
     const float* Op = save;
     const float* sp = save + (size_t)c.nchunks * a.B * a.D;
     ProfScope prof(PK_BANK_BWD, (double)c.nchunks * a.B * (a.D * 4 + 16) + (double)a.B * a.D * 6, st);

@@ -628,10 +628,11 @@ static int launch_dslice_bwd(const BankArgs& a, const DSliceGeom& g, const float
 // cost than the block-cooperative kernels, and at that bank size fixed cost is half of the pass.  SPN_BANK2=1 or
 // spn_bank_config(1) selects them (they win on the backward pass of large e4m3 banks: 137 vs 151 us at 400 000 rows).
 // spn_bank_config mode: 0 = default routing, 1 = these kernels below 128 queries, 2 = the fused single pass also at
-// B >= 256, 3 = two passes everywhere (no fused pass).  Environment defaults: SPN_BANK2=1 -> 1, SPN_BANK_FUSED_LARGE=1 -> 2,
+// B >= 256, 3 = two passes everywhere (no fused pass), 4 = default routing with the e4m3 fused pass on the kernel that keeps a
+// bf16 tile image (the fallback of very long chunks).  Environment defaults: SPN_BANK2=1 -> 1, SPN_BANK_FUSED_LARGE=1 -> 2,
 // SPN_BANK_FUSED=0 -> 3.
 static int g_bank_mode = -1;
-void bank2_config(int mode) { g_bank_mode = (mode >= 0 && mode <= 3) ? mode : 0; }
+void bank2_config(int mode) { g_bank_mode = (mode >= 0 && mode <= 4) ? mode : 0; }
 int bank_mode() {
     if (g_bank_mode < 0) {
         auto is = [](const char* n, char c) { const char* e = getenv(n); return e && e[0] == c; };

@@ -83,6 +83,31 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+typedef int v2i __attribute__((ext_vector_type(2)));
+// Transposed LDS reads as inline asm, for loops that keep LDS-DMA in flight: the builtin forms carry no memory operand, so
+// hipcc assumes they may read what a pending buffer_load ... lds writes and puts `s_waitcnt vmcnt(0)` in front of them - once
+// per tile, draining the prefetch ring (ISA of the bank kernels' dq phase).  The asm forms are invisible to the compiler's
+// counters: the caller waits with wait_lgkm<N>() (N = DS instructions issued after the ones it needs; 4-bit counter) and ties
+// the result registers behind the wait with lds_tie() before using them.
+__device__ __forceinline__ s16x4 lds_tr16_b64_asm(const void* lds_addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)lds_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ v2i lds_tr8_b64_asm(const void* lds_addr) {
+    v2i v;
+    asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)lds_addr) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void lds_tie(T& x) {
+    asm volatile("" : "+v"(x));
+}
+
 // Workgroup barrier for loops that keep LDS-DMA (buffer_load ... lds) in flight across it: __syncthreads() is a
 // workgroup-scope fence, and hipcc counts a pending LDS-DMA as an LDS write of the wave - it emits `s_waitcnt vmcnt(0)` in
 // front of the barrier and drains every prefetched tile (seen in the ISA of the bank kernels: each 32-row tile waited for the
@@ -92,7 +117,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-typedef int v2i __attribute__((ext_vector_type(2)));
 
 // LDS transpose read: within each 16-lane group the 16 lanes address a 4x16 block of 16-bit
 // elements (lane i -> row i>>2, columns (i&3)*4..+3, 8 bytes each); lane i receives column i

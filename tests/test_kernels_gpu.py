@@ -346,6 +346,19 @@ def test_bank_confident_rows(ops, noise):
     assert row_err(ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)) < 3e-2
 
 
+@pytest.mark.parametrize("B,M,D,tau", [(32, 4099, 512, 0.02), (70, 3000, 768, 0.02), (127, 9001, 1024, 0.05), (3, 33, 256, 0.01)])
+def test_bank_fused_e4m3_image_kernel(ops, B, M, D, tau):
+    """spn_bank_config(4): the fused pass over an e4m3 bank on the kernel that dequantises each raw tile into a bf16 image
+    for the dq GEMM (logits still fp8 x fp8) - the path of chunks longer than the 2 048-entry row-scale table."""
+    from oracle import bank_loss
+    from spn4cir_amd import _lib
+    _lib.lib().spn_bank_config(4)
+    try:
+        _saved_pair_case(ops, bank_loss, B, M, D, tau, True, check_z=False)
+    finally:
+        _lib.lib().spn_bank_config(0)
+
+
 def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=True, split_q=True):
     text, refer, bank, ridx, labels = _bank_case(B, M, D, 3 * B + M)
     q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
