@@ -1006,8 +1006,8 @@ static int launch_bank_fp8_fwd(const BankArgs& a, const BankChunking& c, float* 
 //       reference flush to zero, < 2e-6 of the row's largest term each), so the three products accumulate straight into
 //       the dq registers - no per-tile scale, no second accumulator set.  c2 = the chunk's largest row scale rounded up to
 //       a power of two (exact to divide by, exact to multiply back in the epilogue).
-// No bf16 image means no dequantisation pass (a quarter of the F8L kernel's time) and LDS for a five-deep raw ring: four
-// 24 KB tiles in flight per CU, the bytes a streaming bf16 kernel keeps in flight with one.
+// No bf16 image means no dequantisation pass (a quarter of the F8L kernel's time) and 77 KB of LDS per workgroup: two of them
+// fit a CU (below).
 static constexpr int FP8F_SLACK = 12;
 // Two workgroups per CU (256 registers per wave, LDS within 80 KB: two or three raw stages): a tile costs a workgroup ~6 000
 // cycles of barrier-separated phases (cycle stamps: 390 DMA issue, 1 480 logits, 1 370 statistics, 1 910 dq, ~900 in
