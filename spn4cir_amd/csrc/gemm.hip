@@ -49,13 +49,21 @@ __device__ __forceinline__ bf16x8 nt_frag(const char* sT, int r, int c) {
 
 // MI = 16-row MFMA tiles per wave along M: 4 -> the 128x128 tile (2 blocks per CU); 2 -> 64x128 (24 KiB per stage,
 // 3 blocks per CU) for products with fewer 128x128 tiles than CUs (the BERT-side GEMMs of the fusion encoder: 4 096 rows).
+// Round 3: the 64-row variant keeps THREE stages (72 KB, two workgroups per CU) with counted waits and a raw barrier: with
+// two stages and `wait all; barrier; request next; compute` every k tile of a workgroup waited out the L2 latency of the
+// tile it had just requested, hidden only by the two other workgroups of the CU - and a product that needs this kernel has
+// about two workgroups per CU to begin with (the packed text tower: 492 workgroups).
+template <int MI>
+static constexpr int nt_v1_stages() { return MI == 2 ? 3 : 2; }
+
 template <int MODE, int ACT, int MI = 4>
-__global__ __launch_bounds__(NTHREADS, MI == 4 ? 2 : 3) void gemm_nt_kernel(const bf16_t* __restrict__ A,
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ B, int M, int N, int K,
                                                               int lda, int ldb, GemmEpilogue ep) {
     constexpr int BM = 32 * MI;
     constexpr int A_BYTES = BM * 64 * 2, STAGE = A_BYTES + TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int NS = nt_v1_stages<MI>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // NS x STAGE
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = (N + BN - 1) / BN;
@@ -72,16 +80,26 @@ __global__ __launch_bounds__(NTHREADS, MI == 4 ? 2 : 3) void gemm_nt_kernel(cons
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    nt_stage<MI>(rsA, smem, m0, lda, 0, wid, lane);
-    nt_stage<4>(rsB, smem + A_BYTES, n0, ldb, 0, wid, lane);
+    auto stage = [&](int kt, int buf) {
+        char* dst = smem + buf * STAGE;
+        nt_stage<MI>(rsA, dst, m0, lda, kt * BK, wid, lane);
+        nt_stage<4>(rsB, dst + A_BYTES, n0, ldb, kt * BK, wid, lane);
+    };
+    stage(0, 0);
+    if constexpr (NS == 3) {
+        if (nk > 1) stage(1, 1);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        wait_vm0();
-        __syncthreads();   // tile kt landed for every wave; everyone finished reading buf^1
-        if (kt + 1 < nk) {
-            char* nxt = smem + (buf ^ 1) * STAGE;
-            nt_stage<MI>(rsA, nxt, m0, lda, (kt + 1) * BK, wid, lane);
-            nt_stage<4>(rsB, nxt + A_BYTES, n0, ldb, (kt + 1) * BK, wid, lane);
+        const int buf = NS == 3 ? kt % 3 : (kt & 1);
+        if constexpr (NS == 3) {
+            if (kt + 1 < nk) wait_vmcnt<MI + 4>();      // tile kt is in; tile kt + 1 (MI + 4 DMA per wave) may still be in flight
+            else wait_vmcnt<0>();
+            lds_barrier();                               // raw barrier: __syncthreads() would drain the tile in flight (common.h)
+            if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);   // = the buffer of tile kt - 1, read by everyone before this barrier
+        } else {
+            wait_vm0();
+            __syncthreads();   // tile kt landed for every wave; everyone finished reading buf^1
+            if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         }
         const char* sA = smem + buf * STAGE;
         const char* sB = sA + A_BYTES;
@@ -160,6 +178,21 @@ int gemm_cfg() {
     return cfg;
 }
 
+template <int MODE, int ACT, int MI>
+static int launch_nt_v1(int tiles, hipStream_t st, const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb,
+                        const GemmEpilogue& ep) {
+    constexpr int LDS = nt_v1_stages<MI>() * (32 * MI * 64 * 2 + TILE_BYTES);
+    auto kern = gemm_nt_kernel<MODE, ACT, MI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHREADS), LDS, st, A, B, M, N, K, lda, ldb, ep);
+    return SPN_OK;
+}
+
 int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
             const GemmEpilogue& ep, hipStream_t st) {
     // 256x256 tiles need roughly half of the 256 CUs worth of tiles to pay off (measured break-even between 63 and 150
@@ -180,10 +213,9 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
 #define SPN_LAUNCH_NT(MODE_, ACT_)                                                                                       \
     do {                                                                                                                 \
-        if (half) hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_, 2>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K, \
-                                     lda, ldb, ep);                                                                      \
-        else hipLaunchKernelGGL((gemm_nt_kernel<MODE_, ACT_, 4>), dim3(tiles), dim3(NTHREADS), 0, st, A, B, M, N, K,      \
-                                lda, ldb, ep);                                                                           \
+        const int rc_ = half ? launch_nt_v1<MODE_, ACT_, 2>(tiles, st, A, B, M, N, K, lda, ldb, ep)                      \
+                             : launch_nt_v1<MODE_, ACT_, 4>(tiles, st, A, B, M, N, K, lda, ldb, ep);                     \
+        if (rc_) return rc_;                                                                                             \
     } while (0)
     if (mode == GEMM_STORE) {
         if (ep.act == ACT_NONE) SPN_LAUNCH_NT(GEMM_STORE, ACT_NONE);
