@@ -246,6 +246,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    # SPN_BENCH_SHARE_GPU=1 (debugging aid for 1-GPU boxes): every rank uses device 0 and the process group runs over gloo -
+    # the N-rank control flow of this script (sharding, bank modes, touched-row exchange, max-over-ranks timing) end to end
+    # without N GPUs; the number it prints is meaningless
+    share = os.environ.get("SPN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -253,7 +259,10 @@ def main():
     # gradient all-reduce - with a 1-rank group
     force_dp = os.environ.get("SPN_DP_FORCE_COLLECTIVES") == "1"
     if world > 1 or force_dp:
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         dist.barrier()
         C.CDLL(None).fflush(None)          # emit RCCL's start-up banner now, not after the result line
 

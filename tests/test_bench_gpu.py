@@ -1,0 +1,34 @@
+"""bench.py's N-rank control flow on a 1-GPU box: two ranks share device 0 over gloo (SPN_BENCH_SHARE_GPU=1), so that the
+sharding of the triplets, the bank-mode selection and its alternative measurement, the touched-row embedding exchange, the
+max-over-ranks timing and the single JSON line of rank 0 run end to end (the printed rate is meaningless)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "sharded"])
+def test_bench_two_ranks_shared_gpu(mode):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SPN_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-recall", "--no-cpu-baseline", "--no-packed", "--bank-mode", mode]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 512
+    assert d["metric"] == "triplets/sec" and d["value"] > 0 and d["scaling"] == "weak"
+    assert "bank_mode_alt" in d and "roofline" in d
+    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
