@@ -346,6 +346,41 @@ def test_bank_confident_rows(ops, noise):
     assert row_err(ops.bank_grad_q(qb, bank_b, dev(labels), 1.0 / tau, lse, 1.0 / B)) < 3e-2
 
 
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
+@pytest.mark.parametrize("B,M,D", [(32, 40000, 768), (16, 200000, 768), (100, 9001, 1024), (40, 12000, 256)])
+def test_bank_stream_kernels_race_screen(ops, B, M, D, fp8):
+    """The stream kernels order their LDS-DMA tile ring, the partial-sum exchange and the asm transposed reads by counted
+    `vmcnt` / hand-counted `lgkmcnt` waits and RAW barriers (no compiler fence).  Screen for races: 24 launches of the fused
+    pair and of the two-pass pair, half of them while a bandwidth-heavy copy runs on a second stream, must all be
+    bit-identical to the first."""
+    g = torch.Generator().manual_seed(B + M + D)
+    bank = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=-1)
+    q = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    labels = dev(torch.randint(0, M, (B,), generator=g))
+    _, qb, _ = ops.combine_l2norm_fwd(None, None, dev(q))
+    bank_b = ops.prepare_bank(dev(bank), "fp8" if fp8 else "bf16")
+    save = ops.bank_logits_buffer(B, M, "cuda")
+
+    def run():
+        st = ops.bank_stats_fwd(qb, bank_b, labels, 50.0, save=save)
+        lse, _, _ = ops.bank_loss_finalize(st, M)
+        dq = ops.bank_grad_q(qb, bank_b, labels, 50.0, lse, 1.0 / B, saved=save)
+        st2 = ops.bank_stats_fwd(qb, bank_b, labels, 50.0)
+        dq2 = ops.bank_grad_q(qb, bank_b, labels, 50.0, lse, 1.0 / B)
+        return st, dq, st2, dq2
+
+    first = [t.clone() for t in run()]
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    for it in range(24):
+        if it % 2:
+            with torch.cuda.stream(side):
+                big.add_(1.0)
+        for a, b in zip(run(), first):
+            assert torch.equal(a, b), it
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B,M,D,tau", [(32, 4099, 512, 0.02), (70, 3000, 768, 0.02), (127, 9001, 1024, 0.05), (3, 33, 256, 0.01)])
 def test_bank_fused_e4m3_image_kernel(ops, B, M, D, tau):
     """spn_bank_config(4): the fused pass over an e4m3 bank on the kernel that dequantises each raw tile into a bf16 image
