@@ -344,12 +344,13 @@ def main():
     if not args.no_packed:
         cu, total = trainer.tower.cu_seqlens(ids_all[sl])
         cu = cu.to(dev)
+        ids_p = ids[:, :trainer.tower.live_length(ids_all[sl])].contiguous()     # padding columns only beyond the longest caption
         for _ in range(max(2, args.warmup)):
-            lp = trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
+            lp = trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            lp = trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
+            lp = trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
         barrier()
         dtp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
@@ -364,7 +365,7 @@ def main():
             lib.spn_prof_enable(max(64, 200 * args.kernel_pass_steps))
             lib.spn_prof_select(0xFFFFFFFF, 1)
             for _ in range(args.kernel_pass_steps):
-                trainer.step(ids, ridx, labels, cu, total, ids_host=ids_host)
+                trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
             torch.cuda.synchronize()
             lib.spn_prof_disable()
             packed["kernels"] = collect_kernels(lib, args.kernel_pass_steps, total, W)

@@ -295,6 +295,7 @@ class CIRPlus(nn.Module):
         if torch.is_tensor(text):
             if self.pack_eot and not text.is_cuda:
                 self._set_pack(text)
+                text = text[:, :self.tower.live_length(text)]         # padding columns only beyond the longest caption
             return text.to(self.device, torch.int32).contiguous()
         if self.tokenizer is None:
             from .tokenizer import tokenize as clip_tokenize      # clip.tokenize (clip/clip.py:206-247)
@@ -304,6 +305,7 @@ class CIRPlus(nn.Module):
             raise RuntimeError(f"token id {int(ids.max())} outside the model's vocabulary ({self.tower.vocab})")
         if self.pack_eot:
             self._set_pack(ids)
+            ids = ids[:, :self.tower.live_length(ids)]
         return ids.to(self.device, torch.int32).contiguous()
 
     def _set_pack(self, ids_host):

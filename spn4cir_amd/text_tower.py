@@ -130,6 +130,16 @@ class TextTower:
         cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
         return cu, int(cu[-1])
 
+    @staticmethod
+    def live_length(ids_host, multiple=16):
+        """Host helper for the packed mode: the longest live caption of a CPU id matrix, rounded up to `multiple` and
+        capped at its width.  Columns beyond it hold padding only (they are dead in the packed layout anyway), so the caller
+        may pass `ids[:, :live_length]` - the towers take any L <= context length - and the whole-head attention kernels
+        then run with ceil(L / 16) instead of ceil(77 / 16) waves per (caption, head)."""
+        ids_host = torch.as_tensor(ids_host)
+        longest = int(ids_host.argmax(dim=-1).max()) + 1
+        return min(int(ids_host.shape[1]), (longest + multiple - 1) // multiple * multiple)
+
     def forward(self, ids, cu_seqlens=None, total_rows=0):
         """ids int32 [B, L] on device -> fp32 [B, D]; activations are kept for backward().
 

@@ -162,6 +162,41 @@ def test_packed_rows_ragged_cases(B, L, lens):
     assert (1 - cosine(f_pack.cpu(), ref)).max() < 1e-3
 
 
+@pytest.mark.parametrize("B,L,longest", [(40, 77, 19), (9, 77, 33), (6, 77, 77), (5, 77, 1)])
+def test_packed_trimmed_ids_equal_full_width(B, L, longest):
+    """TextTower.live_length: in the packed mode the id matrix may be cut behind the longest caption (rounded up to 16) -
+    the dropped columns hold padding only.  Features are unchanged, gradients agree (positional rows beyond the cut get
+    their exact zeros), and the attention kernels run with fewer waves per (caption, head)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import clip_text
+    from spn4cir_amd.text_tower import TextTower
+    W, H, layers, D, vocab = 256, 4, 2, 128, 1000
+    sd = clip_text.synthetic_text_state_dict(width=W, layers=layers, embed_dim=D, vocab=vocab, ctx=77, seed=6)
+    t = TextTower(W, layers, H, D, vocab, 77, "cuda")
+    t.load_clip_state_dict(sd)
+    g = torch.Generator().manual_seed(longest)
+    ids_host = torch.randint(1, vocab - 2, (B, L), generator=g, dtype=torch.int32)
+    eot = torch.randint(0, longest, (B,), generator=g)
+    eot[0] = longest - 1
+    for b in range(B):
+        ids_host[b, eot[b]] = vocab - 1
+        ids_host[b, eot[b] + 1:] = 0
+    Lr = t.live_length(ids_host)
+    assert Lr == min(L, (longest + 15) // 16 * 16)
+    dfeats = torch.randn(B, D, generator=g).cuda()
+    cu, total = t.cu_seqlens(ids_host)
+    f_full = t.forward(ids_host.cuda(), cu.cuda(), total).clone()
+    g_full = t.backward(dfeats).clone()
+    f_trim = t.forward(ids_host[:, :Lr].contiguous().cuda(), cu.cuda(), total).clone()
+    g_trim = t.backward(dfeats).clone()
+    assert (f_trim - f_full).abs().max() < 1e-6
+    vf, vt = t.named_views(g_full), t.named_views(g_trim)
+    for key in vf:
+        err = ((vt[key] - vf[key]).norm() / vf[key].norm().clamp_min(1e-12)).item()
+        assert err < 1e-3, (key, err)
+
+
 def test_eot_is_first_maximum_and_long_rows():
     """clip/model.py:356 pools x[arange, ids.argmax(-1)]: the FIRST maximum on ties; positions beyond one wave's 64
     lanes included (the argmax kernel merges (value, position) pairs across lanes)."""
