@@ -72,15 +72,41 @@ def parse():
                    help="extra steps AFTER the timed region with every kernel class timed, for the kernels[] breakdown")
     p.add_argument("--no-packed", action="store_true", help="skip the extra (not headline) packed-EOT measurement")
     p.add_argument("--no-recall", action="store_true", help="skip the Recall@10 / top-K identity block")
-    p.add_argument("--recall-queries", type=int, default=256,
-                   help="queries of the synthetic retrieval check (SURVEY 8d names 2 000; the CPU oracle encodes every one "
-                        "of them in fp32, ~0.05 s each on 32 threads, so the default is a bounded sample)")
+    p.add_argument("--recall-queries", type=int, default=2000,
+                   help="queries of the synthetic retrieval check (SURVEY 8d: 2 000; the CPU oracle encodes every one of "
+                        "them in fp32, ~0.05 s each on 32 threads)")
+    p.add_argument("--no-extra-configs", action="store_true",
+                   help="skip the blip_config4 / fp8_config5 blocks (BASELINE configs 4 and 5 on one GPU, after the timed region)")
     p.add_argument("--recall-gallery", type=int, default=6000)
     p.add_argument("--cpu-batch", type=int, default=16)
     p.add_argument("--cpu-steps", type=int, default=3)
     p.add_argument("--cpu-threads", type=int, default=32)
     p.add_argument("--cpu-budget-s", type=float, default=20.0)
     return p.parse_args()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (never exec: this
+    process must not touch the GPU - no torch.cuda call has happened yet), relay its output with rank 0's JSON line
+    last, and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.pop("MASTER_PORT", None)          # the default set above belongs to single-process runs
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = p.stdout.splitlines()
+    result = [l for l in lines if l.startswith('{"metric"')]
+    for l in lines:
+        if not l.startswith('{"metric"'):
+            print(l)
+    for l in result[-1:]:
+        print(l, flush=True)
+    return p.returncode
 
 
 def cpu_baseline(args, sd, target, refer):
@@ -131,6 +157,145 @@ def cpu_baseline(args, sd, target, refer):
                       f"D={target.shape[1]}, fp32, torch CPU kernels, {threads} threads of {avail} available cores), "
                       f"after 1 warm-up step",
             "ms_per_step": round(dt * 1e3, 1)}
+
+
+def cpu_baseline_config1(args):
+    """BASELINE config 1 on the host cores (clip4cir/train.py --wo_bank -> clip4cir/models.py:151-167): CLIP ViT-B/32
+    (text 512 x 12 x 8 heads, vision 768 x 12 x 12 heads, patch 32, D = 512), B = 4, in-batch negatives, both towers
+    trainable, AdamW lr 2e-5 - the oracle's restatement (oracle.clip_text / clip_vision / bank_loss.inbatch_step) with
+    torch autograd; the reference additionally recomputes the towers under torch.utils.checkpoint (+1 forward)."""
+    from oracle import bank_loss, clip_text, clip_vision
+    from spn4cir_amd import synthetic
+    B = 4
+    threads = torch.get_num_threads()
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-B/32"]
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    sd.update(clip_vision.synthetic_vision_state_dict(768, 12, 32, 224, D, seed=5))
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.AdamW([{"params": list(params.values()), "lr": 2e-5, "betas": (0.9, 0.999), "eps": 1e-7}])
+    ids = synthetic.token_ids(B, seed=1)
+    g = torch.Generator().manual_seed(0)
+    ref_img, tgt_img = torch.randn(B, 3, 224, 224, generator=g), torch.randn(B, 3, 224, 224, generator=g)
+
+    def step():
+        opt.zero_grad()
+        loss = bank_loss.inbatch_step(clip_vision.encode_image(params, ref_img), clip_text.encode_text(params, ids),
+                                      clip_vision.encode_image(params, tgt_img), args.tau)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 3 and (n == 0 or time.perf_counter() - t0 < args.cpu_budget_s / 2):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "triplets/sec", "cores": threads, "kind": "port", "ms_per_step": round(dt * 1e3, 1),
+            "sample": f"{n} steps of B={B}, CLIP ViT-B/32 (both towers trainable, 224x224 images, in-batch negatives, fp32, "
+                      f"autograd without the reference's checkpoint recompute), after 1 warm-up step"}
+
+
+def blip_config4_block(args, dev):
+    """BASELINE config 4 on ONE GPU (blip4cir/train.py:110-129 -> models.py:95-121): BERT-base fusion encoder (12 x 768,
+    cross-attention over 577 image tokens), B = 128, 32-token captions, 30 000 x 256 bank, tau 0.03 (learnable), AdamW,
+    for the reference's encoder width (768) and BASELINE's ViT-L (1024).  Not the headline."""
+    from spn4cir_amd.fusion import BlipStage2Trainer, FusionEncoder
+    out = {}
+    B, L, S, M, images = 128, 32, 577, 30000, 1000
+    for E in (768, 1024):
+        g = torch.Generator().manual_seed(0)
+        enc = FusionEncoder(768, 12, 12, 3072, E, 256, 30524, 512, dev)
+        with torch.no_grad():
+            for k, v in enc.named_views().items():
+                if k.endswith("LayerNorm.weight"):
+                    v.fill_(1.0)
+                elif v.dim() >= 2:
+                    v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(dev))
+        enc.mark_stale()
+        ids = torch.randint(1000, 30522, (B, L), generator=g, dtype=torch.int32)
+        ids[:, 0] = 30523
+        lens = torch.randint(6, L + 1, (B,), generator=g)
+        mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int32)
+        ids, mask = (ids * mask).to(dev), mask.to(dev)
+        ref_bank = torch.randn(images, S, E, device=dev)
+        ridx = torch.randint(0, images, (B,), generator=g).to(dev)
+        labels = torch.randint(0, M, (B,), generator=g).to(dev)
+        tr = BlipStage2Trainer(enc, tau=0.03, lr=5e-6, bank_mode="replicated")
+        tr.set_bank(torch.nn.functional.normalize(torch.randn(M, 256, generator=g)))
+        for _ in range(3):
+            loss = tr.step(ids, mask, ref_bank[ridx], labels)
+        torch.cuda.synchronize()
+        n, t0 = 10, time.perf_counter()
+        for _ in range(n):
+            loss = tr.step(ids, mask, ref_bank[ridx], labels)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        T, TS, W, I = B * L, B * S, 768, 3072
+        fwd = 12 * (2 * T * W * 3 * W + 2 * T * W * W * 2 + 2 * TS * E * 2 * W + 2 * T * W * I * 2
+                    + 4 * B * 12 * L * L * 64 + 4 * B * 12 * L * S * 64)
+        out[f"enc_width_{E}"] = {"value": round(B / dt, 1), "unit": "triplets/sec", "ms_per_step": round(dt * 1e3, 3),
+                                 "model_tflops": round(3 * fwd / dt / 1e12, 1),
+                                 "frac_of_bf16_peak": round(3 * fwd / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                 "loss_last": round(float(loss.item()), 5)}
+        del tr, enc, ref_bank
+        torch.cuda.empty_cache()
+    out["workload"] = (f"blip4cir stage-2 step: BERT-base fusion (12 x 768, cross-attention over {S} image tokens), B={B}, "
+                       f"L={L}, bank {M}x256, tau 0.03 learnable, AdamW; reference tokens gathered from a device-resident "
+                       f"[{images}, {S}, E] fp32 bank; 10 steps after 3 warm-up; 1 GPU")
+    return out
+
+
+def fp8_config5_block(args, sd, model_cls, dev):
+    """BASELINE config 5's bank on ONE GPU: M = 100 000 rows x 768 stored e4m3 + per-row scale, the fp8-MFMA similarity pass,
+    beside the same step on the bf16 bank, at the per-GPU batches of the 8-GPU run (32 = strong scaling, 256 = weak)."""
+    from spn4cir_amd import synthetic
+    from spn4cir_amd.trainer import Stage2Trainer
+    M = 100000
+    D = sd["text_projection"].shape[1]
+    target, refer = synthetic.banks(M, D, seed=2)
+    model = model_cls(sd, tau=args.tau, device=dev, plus=True)
+    lib = __import__("spn4cir_amd._lib", fromlist=["lib"]).lib()
+    out = {}
+    for B in (32, 256):
+        ids = synthetic.token_ids(B, seed=1).to(dev)
+        ridx, labels = [t.to(dev) for t in synthetic.triplet_indices(B, M, seed=4)]
+        ent = {}
+        for dt_name in ("fp8", "bf16"):
+            tr = Stage2Trainer(model, lr=2e-5)
+            tr.set_banks(refer, target, bank_dtype=dt_name)
+            for _ in range(3):
+                loss = tr.step(ids, ridx, labels)
+            torch.cuda.synchronize()
+            n, t0 = 8, time.perf_counter()
+            for _ in range(n):
+                loss = tr.step(ids, ridx, labels)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            lib.spn_prof_enable(256)
+            lib.spn_prof_select(0x30, 1)
+            for _ in range(4):
+                tr.step(ids, ridx, labels)
+            torch.cuda.synchronize()
+            lib.spn_prof_disable()
+            pair = 0.0
+            for kid in (4, 5):
+                ms, work, nl = C.c_double(), C.c_double(), C.c_int()
+                lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(nl))
+                pair += ms.value / max(1, nl.value) * 1e3
+            lib.spn_prof_reset()
+            nbytes = M * D * (1 if dt_name == "fp8" else 2)
+            ent[dt_name] = {"triplets_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "bank_pair_us": round(pair, 1),
+                            "bank_GBps_one_read": round(nbytes / (pair * 1e-6) / 1e9, 1) if pair > 0 else None,
+                            "loss_last": round(float(loss.item()), 5)}
+            del tr
+        ent["loss_abs_diff"] = round(abs(ent["fp8"]["loss_last"] - ent["bf16"]["loss_last"]), 6)
+        out[f"B{B}"] = ent
+    out["workload"] = (f"config-2 step (ViT-L/14 text tower) over a {M} x {D} bank stored e4m3 + fp32 row scale vs bf16; "
+                       f"bank_pair_us = HIP-event time of the bank forward + backward kernels; 8 steps after 3 warm-up; 1 GPU")
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def recall_block(args, sd, model, dev):
@@ -209,7 +374,7 @@ def recall_block(args, sd, model, dev):
                                     "topk_identical_frac": {"10": bf["topk_identical_frac_10"], "50": bf["topk_identical_frac_50"]},
                                     "text_feature_max_1_minus_cos": float((1 - cosb).max())},
             "queries": nq, "gallery_rows": ng, "embed_dim": D,
-            "sample": f"{nq} of SURVEY 8d's 2 000 queries (--recall-queries); oracle encode {cpu_s:.1f} s on the host cores, "
+            "sample": f"{nq} queries (SURVEY 8d: 2 000; --recall-queries); oracle encode {cpu_s:.1f} s on the host cores, "
                       f"exact tower {exact_s * 1e3:.0f} ms on the GPU"}
 
 
@@ -241,8 +406,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            raise SystemExit(self_launch(args.gpus))     # one process per GPU under torch.distributed.run, as a child
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
@@ -474,8 +639,14 @@ def main():
                 out["recall_at_10"] = rec["recall_at_10"]
                 out["topk_identical_frac"] = rec["topk_identical_frac"]
                 out["recall"] = rec
+        if world == 1 and not args.no_extra_configs:
+            del trainer
+            torch.cuda.empty_cache()
+            out["blip_config4"] = blip_config4_block(args, dev)
+            out["fp8_config5"] = fp8_config5_block(args, sd, CIRPlus, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
+            out["cpu_baseline"]["config1"] = cpu_baseline_config1(args)
     if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()

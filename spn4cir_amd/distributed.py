@@ -42,22 +42,22 @@ def shard_range(total, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-_gather_bufs = {}
-
-
-def all_gather_cat(x, group=None):
+def all_gather_cat(x, group=None, cache=None):
     """Concatenation of every rank's x along dim 0 (equal shapes on all ranks), gathered by ONE collective straight into a
-    preallocated [world * n, ...] buffer (all_gather_into_tensor: no per-rank temporaries, no torch.cat pass).  The buffer
-    is cached per (shape, dtype, device, group) and reused by the next step's call with the same key: callers consume the
-    result inside the step (the bank kernels read it before the next forward overwrites it)."""
+    [world * n, ...] buffer (all_gather_into_tensor: no per-rank temporaries, no torch.cat pass).  `cache` (a dict owned by
+    the caller) keeps that buffer per (shape, dtype, device) for the caller's next call with the same key - only a caller
+    that consumes the result before its next call may pass one (BankLossDP: one forward in flight per instance); without
+    it every call gets a fresh buffer."""
     world, _ = _world(group)
     if _skip(world):
         return x
     x = x.contiguous()
-    key = (tuple(x.shape), x.dtype, str(x.device), id(group))
-    out = _gather_bufs.get(key)
+    key = (tuple(x.shape), x.dtype, str(x.device))
+    out = cache.get(key) if cache is not None else None
     if out is None:
-        out = _gather_bufs[key] = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if cache is not None:
+            cache[key] = out
     dist.all_gather_into_tensor(out, x, group=group)
     return out
 
@@ -83,6 +83,11 @@ class BankLossDP:
             raise ValueError(mode)
         self.ops, self.group, self.mode = ops, group, mode
         self.world, self.rank = _world(group)
+        # gather buffers of the sharded mode, private to this instance and reused step after step.  They back ctx['q'] /
+        # ctx['labels'] until backward(ctx) has run: a second forward before that (gradient accumulation, an eval forward
+        # between forward and backward) gets fresh buffers instead of overwriting the pending step's queries.
+        self._bufs = {}
+        self._pending_ctx = 0
 
     def forward(self, qb_local, labels_local, bank, m_begin, M_total, inv_tau, label_smoothing=0.0):
         """qb_local [B_local, Dp] bf16 L2-normalised queries, labels_local [B_local] int64 GLOBAL bank
@@ -107,10 +112,12 @@ class BankLossDP:
             B_global = qb_local.shape[0] * self.world
             return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss / B_global, bank=bank, m_begin=m_begin,
                         M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False, saved=saved)
-        q_all = all_gather_cat(qb_local, self.group)
-        labels_all = all_gather_cat(labels_local, self.group)
+        cache = self._bufs if self._pending_ctx == 0 else None
+        self._pending_ctx += 1
+        q_all = all_gather_cat(qb_local, self.group, cache)
+        labels_all = all_gather_cat(labels_local, self.group, cache)
         stats, saved = stats_fwd(q_all, labels_all)                                     # [B, 4] over my shard
-        stats_all = all_gather_cat(stats.unsqueeze(0), self.group)                      # [G, B, 4]
+        stats_all = all_gather_cat(stats.unsqueeze(0), self.group, cache)               # [G, B, 4]
         lse, row, mean = ops.bank_loss_finalize(stats_all, M_total, label_smoothing)    # identical everywhere
         return dict(q=q_all, labels=labels_all, lse=lse, loss=mean, bank=bank, m_begin=m_begin, M_total=M_total,
                     inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True, saved=saved)
@@ -123,6 +130,7 @@ class BankLossDP:
                                   M_total=ctx["M_total"], label_smoothing=ctx["ls"], m_begin=ctx["m_begin"], **kw)
         if ctx["gathered"]:
             dq = reduce_scatter_rows(dq, self.group)
+            self._pending_ctx = max(0, self._pending_ctx - 1)
         return dq
 
 
@@ -141,23 +149,35 @@ class SparseRowReducer:
 
     Per rank (G - 1) * cap * W * 4 bytes arrive (G = 8, cap = 5.3 k, W = 768: 114 MB) against the 2 (G - 1) / G * 152 MB
     = 266 MB a ring all-reduce of the dense matrix moves; with real captions (a vocabulary of a few thousand words) the
-    gap is far larger.  Summation order differs from an all-reduce only in the order of G addends per element."""
+    gap is far larger.  Every rank sums the G contributions of a row in the SAME order (rank 0, 1, .. G-1, its own
+    included, starting from zero), so the replicas' gradients stay bit-identical for any G (fp32 addition does not
+    associate: adding "the others" onto the own value would give rank-dependent last bits from G = 3 on)."""
+
+    _host_groups = {}            # one CPU (gloo) group per process and device group, shared by every reducer
 
     def __init__(self, group=None):
         self.group = group
         self.world, self.rank = _world(group)
-        self.host_group = None
-        if not _skip(self.world) and dist.get_backend(group) != "gloo":
-            self.host_group = dist.new_group(backend="gloo")     # collective: every rank constructs its reducer
-        elif not _skip(self.world):
-            self.host_group = group
+        self.host_group = None   # created on the first plan() call (a collective: every rank plans in the same step)
         self._plan = None
         self._work = None
+
+    def _host(self):
+        if self.host_group is None:
+            if dist.get_backend(self.group) == "gloo":
+                self.host_group = self.group
+            else:
+                key = id(self.group)
+                if key not in SparseRowReducer._host_groups:
+                    SparseRowReducer._host_groups[key] = dist.new_group(backend="gloo")
+                self.host_group = SparseRowReducer._host_groups[key]
+        return self.host_group
 
     def plan(self, ids_host):
         if _skip(self.world):
             self._plan = None
             return
+        self._host()
         uniq = torch.unique(ids_host.reshape(-1).to(torch.int64))
         n = torch.tensor([uniq.numel()], dtype=torch.int64)
         counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
@@ -197,9 +217,12 @@ class SparseRowReducer:
         self._work.wait()
         self._work = None
         cap = pl["cap"]
+        u = pl["counts"][self.rank]
+        if u:
+            grad2d.index_fill_(0, pl["rows_dev"][self.rank], 0.0)    # own rows come back through recv, in rank order
         for r in range(self.world):
             c = pl["counts"][r]
-            if r != self.rank and c:
+            if c:      # the ids of one rank are unique: no two addends of a call hit the same element
                 grad2d.index_add_(0, pl["rows_dev"][r], pl["recv"][r * cap:r * cap + c])
         self._plan = None
 

@@ -32,3 +32,20 @@ def test_bench_two_ranks_shared_gpu(mode):
     assert d["metric"] == "triplets/sec" and d["value"] > 0 and d["scaling"] == "weak"
     assert "bank_mode_alt" in d and "roofline" in d
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher in front (how a driver may call it): the parent starts
+    torch.distributed.run as a child process before touching the GPU, relays rank 0's JSON line last and returns rc 0."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SPN_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-recall",
+           "--no-cpu-baseline", "--no-packed", "--no-alt-bank-mode", "--no-extra-configs"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    last = p.stdout.strip().splitlines()[-1]
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["value"] > 0

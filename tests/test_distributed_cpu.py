@@ -153,18 +153,24 @@ def _sparse_worker(rank, world, port, out):
             red.start(grad)
             red.finish(grad)
             ok = ok and torch.allclose(grad, dense, atol=1e-5, rtol=1e-5)
+            # replicas must stay BIT-identical (the AdamW state has no re-sync): every rank's result equals rank 0's
+            both = [torch.empty_like(grad) for _ in range(world)]
+            dist.all_gather(both, grad)
+            ok = ok and all(torch.equal(both[0], b) for b in both[1:])
         out.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-def test_sparse_embedding_row_exchange_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_embedding_row_exchange(world):
     """SparseRowReducer (the token-embedding gradient as touched rows: host-side plan over gloo, one all-gather, index_add)
-    equals the dense all-reduce, for unequal per-rank row counts, shared rows and changing ids."""
+    equals the dense all-reduce, for unequal per-rank row counts, shared rows and changing ids - and is bitwise equal on
+    every rank (3 ranks: fp32 addition does not associate, so the summation order must not depend on the rank)."""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = [out.get(timeout=120) for _ in procs]
