@@ -165,8 +165,14 @@ size_t spn_bank_logits_bytes(int B, int M);
  * documented tolerances: 0 = default (above); 1 = second-generation streaming kernels below 128 queries (also SPN_BANK2=1;
  * slower at 40 000-row banks); 2 = the fused single pass at every batch size (SPN_BANK_FUSED_LARGE=1);
  * 3 = two passes everywhere (SPN_BANK_FUSED=0); 4 = default routing, but the fused pass over an e4m3 bank on the kernel that
- * dequantises each tile into a bf16 image for the dq GEMM (otherwise only taken beyond 2 048 rows per chunk). */
+ * dequantises each tile into a bf16 image for the dq GEMM (otherwise only taken beyond 2 048 rows per chunk).
+ * Mode 1 exists only in the experiments build (make EXPERIMENTS=1 -> libspn4cir_hip_exp.so); the shipped library returns
+ * SPN_ERR_ARG for it. */
 int spn_bank_config(int mode);
+/* Every SPN_* environment variable is captured once, when the library is loaded; the kernels' A/B switches read that
+ * snapshot only.  Writes a JSON object {"experiments_build": 0|1, "env": {"SPN_X": "value", ...}} (NUL-terminated, truncated
+ * to cap) and returns the size needed.  No reference counterpart (the reference has no native code). */
+int spn_config_dump(char* buf, int cap);
 int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
                             int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
                             size_t ws_bytes, void* stream);

@@ -83,6 +83,7 @@ _SIGS = {
     "spn_bank_workspace_bytes": (sz, [i32, i32, i32]),
     "spn_bank_logits_bytes": (sz, [i32, i32]),
     "spn_bank_config": (i32, [i32]),
+    "spn_config_dump": (i32, [C.c_char_p, i32]),
     "spn_bank_stats_fwd_save": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
     "spn_bank_grad_q_saved": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_bank_workspace_bytes_fp8": (sz, [i32, i32, i32]),
@@ -187,3 +188,14 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().spn_error_string(rc).decode()
         raise RuntimeError(f"spn4cir_hip {what} failed: {msg} (code {rc})")
+
+
+def config_dump():
+    """The library's run-time configuration as a dict: {"experiments_build": 0|1, "env": {every SPN_* variable present when
+    the library was loaded}} - the kernels' A/B switches read that snapshot only (csrc/config.hip)."""
+    import json
+    L = lib()
+    n = L.spn_config_dump(None, 0)
+    buf = C.create_string_buffer(n)
+    L.spn_config_dump(buf, n)
+    return json.loads(buf.value.decode())

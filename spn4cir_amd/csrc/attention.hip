@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
 // SPN_ATTN_FLASH=1 forces the tiled (flash-style) kernels even where the whole-head ones apply
 static bool attn_force_flash() {
     static const bool f = [] {
-        const char* e = getenv("SPN_ATTN_FLASH");
+        const char* e = spn_env("SPN_ATTN_FLASH");
         return e && e[0] == '1';
     }();
     return f;

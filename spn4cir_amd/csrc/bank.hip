@@ -1340,7 +1340,7 @@ static int launch_bank_fp8_fused(const BankArgs& a, const BankChunking& c, float
 // SPN_BANK_FP8_MFMA=0 keeps the forward pass of an fp8 bank on the dequantise-to-bf16 path (A/B switch)
 static bool bank_fp8_mfma_on() {
     static const bool on = [] {
-        const char* e = getenv("SPN_BANK_FP8_MFMA");
+        const char* e = spn_env("SPN_BANK_FP8_MFMA");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -1556,7 +1556,7 @@ static int launch_tokmax(const BankArgs& a, const BankChunking& c, const float* 
 // SPN_TOKMAX_BLOCK=1 keeps the block-cooperative kernel for D <= 256 too (A/B switch for the tests)
 static bool tokmax_wave_path(const BankArgs& a) {
     static const bool off = [] {
-        const char* e = getenv("SPN_TOKMAX_BLOCK");
+        const char* e = spn_env("SPN_TOKMAX_BLOCK");
         return e && e[0] == '1';
     }();
     return a.group && !off && (a.D == 128 || a.D == 256);
@@ -1661,6 +1661,40 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
 }
 
 // ---- fused forward + backward pass (one bank read per step); save buffer = [nchunks][B][D] O partials, [nchunks][B][4] stats
+// Routing of the forward / backward pair, process-wide (spn_bank_config): 0 = default, 1 = second-generation streaming pair
+// below 128 queries (csrc/bank2.hip - compiled only into -DSPN_EXPERIMENTS builds: measured slower),
+// 2 = the fused single pass also at B >= 256, 3 = two passes everywhere, 4 = default routing with the e4m3 fused pass on the
+// kernel that keeps a bf16 tile image.  Environment defaults (read when the library is loaded): SPN_BANK2=1 -> 1,
+// SPN_BANK_FUSED_LARGE=1 -> 2, SPN_BANK_FUSED=0 -> 3.
+static int g_bank_mode = -1;
+int bank_config(int mode) {
+#ifndef SPN_EXPERIMENTS
+    if (mode == 1) return SPN_ERR_ARG;          // the streaming pair is not part of this build
+#endif
+    g_bank_mode = (mode >= 0 && mode <= 4) ? mode : 0;
+    return SPN_OK;
+}
+int bank_mode() {
+    if (g_bank_mode < 0) {
+        auto is = [](const char* n, char c) { const char* e = spn_env(n); return e && e[0] == c; };
+        g_bank_mode = is("SPN_BANK_FUSED_LARGE", '1') ? 2 : is("SPN_BANK_FUSED", '0') ? 3 : 0;
+#ifdef SPN_EXPERIMENTS
+        if (is("SPN_BANK2", '1')) g_bank_mode = 1;
+#endif
+    }
+    return g_bank_mode;
+}
+int bank_saved_ld(int M) { return (M + 31) / 32 * 32; }
+size_t bank_saved_bytes(int B, int M) { return (size_t)B * bank_saved_ld(M) * sizeof(float); }
+#ifndef SPN_EXPERIMENTS
+bool bank_saved_path(const BankArgs&) { return false; }
+size_t bank2_workspace_bytes(int, int, int) { return 0; }
+int bank2_stats_fwd(const BankArgs&, float*, float*, float*, size_t, hipStream_t) { return SPN_ERR_ARG; }
+int bank2_grad_q(const BankArgs&, const float*, const float*, float, int64_t, float, float*, float*, size_t, hipStream_t) {
+    return SPN_ERR_ARG;
+}
+#endif
+
 static bool bank_fused_on() { return bank_mode() != 3; }
 // mode 2: the fused stream pass also at B >= 256, D >= 512, where the default is the GEMM forward pass that keeps p + the
 // G^T / TN-GEMM backward pass
@@ -1715,7 +1749,7 @@ static int bank_fused_fwd(const BankArgs& a, float* stats, float* save, hipStrea
     // e4m3 bank: the all-fp8-MFMA kernel when the chunk's row scales fit its LDS table (SPN_BANK_FP8_FUSED=0: the kernel that
     // dequantises each tile into a bf16 image for the dq GEMM)
     static const bool f8 = [] {
-        const char* e = getenv("SPN_BANK_FP8_FUSED");
+        const char* e = spn_env("SPN_BANK_FP8_FUSED");
         return !(e && e[0] == '0');
     }();
     const bool f8k = f8 && bank_mode() != 4 && a.bank_scale && c.rows <= FP8_MAX_CHUNK_ROWS;
@@ -1842,7 +1876,7 @@ static LargeSave large_save_at(void* base, int B, int M) {
 }
 static bool bank_gemm_on() {
     static const bool use_gemm = [] {
-        const char* e = getenv("SPN_BANK_GEMM");
+        const char* e = spn_env("SPN_BANK_GEMM");
         return !(e && e[0] == '0');
     }();
     return use_gemm;

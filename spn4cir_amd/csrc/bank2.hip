@@ -115,7 +115,7 @@ static RowTileGeom rowtile_geom(int B, int M) {
     if (rows > 4 * RT_MAX_ROWS_PER_WAVE) rows = 4 * RT_MAX_ROWS_PER_WAVE;
     g.rows_per_block = rows;
     g.nchunks = (M + rows - 1) / rows;
-    static const int dbg = [] { const char* e = getenv("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = spn_env("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
     return g;
 }
@@ -432,7 +432,7 @@ static DSliceGeom dslice_geom(int B, int M, int D) {
     g.rows_per_chunk = rows;
     g.nch = (M + rows - 1) / rows;
     g.sliced = 0;
-    static const int dbg = [] { const char* e = getenv("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
+    static const int dbg = [] { const char* e = spn_env("SPN_BANK2_DBG"); return e ? atoi(e) : 0; }();
     g.dbg = dbg;
     return g;
 }
@@ -631,16 +631,7 @@ static int launch_dslice_bwd(const BankArgs& a, const DSliceGeom& g, const float
 // B >= 256, 3 = two passes everywhere (no fused pass), 4 = default routing with the e4m3 fused pass on the kernel that keeps a
 // bf16 tile image (the fallback of very long chunks).  Environment defaults: SPN_BANK2=1 -> 1, SPN_BANK_FUSED_LARGE=1 -> 2,
 // SPN_BANK_FUSED=0 -> 3.
-static int g_bank_mode = -1;
-void bank2_config(int mode) { g_bank_mode = (mode >= 0 && mode <= 4) ? mode : 0; }
-int bank_mode() {
-    if (g_bank_mode < 0) {
-        auto is = [](const char* n, char c) { const char* e = getenv(n); return e && e[0] == c; };
-        g_bank_mode = is("SPN_BANK2", '1') ? 1 : is("SPN_BANK_FUSED_LARGE", '1') ? 2 : is("SPN_BANK_FUSED", '0') ? 3 : 0;
-    }
-    return g_bank_mode;
-}
-static bool bank2_on() { return bank_mode() == 1; }
+static bool bank2_on() { return bank_mode() == 1; }   // bank.hip: spn_bank_config / SPN_BANK2
 
 // The saved-logits pair serves plain (one row = one target) banks, bf16 or e4m3, at per-call batches below 128 queries
 bool bank_saved_path(const BankArgs& a) {
@@ -650,10 +641,6 @@ bool bank_saved_path(const BankArgs& a) {
         default: return false;
     }
 }
-
-int bank_saved_ld(int M) { return (M + 31) / 32 * 32; }
-
-size_t bank_saved_bytes(int B, int M) { return (size_t)B * bank_saved_ld(M) * sizeof(float); }
 
 size_t bank2_workspace_bytes(int B, int M, int D) {
     if (B >= 128 || D % 128) return 0;
@@ -690,10 +677,6 @@ int bank2_stats_fwd(const BankArgs& a, float* stats, float* zsave, float* ws, si
 int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, float label_smoothing, int64_t M_total,
                  float grad_scale, float* dq, float* ws, size_t ws_bytes, hipStream_t st) {
     DSliceGeom g = dslice_geom(a.B, a.M, a.D);
-    {   // timing experiment only (results wrong): address the plain bank as if it were the slice-major copy
-        static const bool exp_sliced = [] { const char* e = getenv("SPN_BANK2_EXP_SLICED"); return e && e[0] == '1'; }();
-        if (exp_sliced) g.sliced = 1;
-    }
     if (ws_bytes < (size_t)g.nch * a.B * a.D * sizeof(float)) return SPN_ERR_WORKSPACE;
     const int ldz = bank_saved_ld(a.M);
     const float inv_m = 1.0f / (float)M_total;

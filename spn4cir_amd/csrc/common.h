@@ -15,10 +15,13 @@
     } while (0)
 
 #include <stdlib.h>
+// value of an SPN_* environment variable AS IT WAS WHEN THE LIBRARY WAS LOADED (config.hip; nullptr if unset): the only way
+// the kernels' A/B switches read the environment, so that spn_config_dump() shows everything that can have changed them
+const char* spn_env(const char* name);
 // integer tuning knob from the environment: values < 1 or unparsable text fall back to the default (a zero-block grid
 // would fail the launch or leave outputs unwritten)
 static inline int env_int_min1(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = spn_env(name);
     if (!e || !*e) return dflt;
     char* end = nullptr;
     const long v = strtol(e, &end, 10);

@@ -286,7 +286,7 @@ static size_t fusion_defer_layer_bytes(const FusionCfg& c) {
 
 static bool fusion_tn_group_on() {
     static const bool on = [] {
-        const char* e = getenv("SPN_TN_GROUP");
+        const char* e = spn_env("SPN_TN_GROUP");
         return !(e && e[0] == '0');
     }();
     return on;

@@ -172,7 +172,7 @@ bool gemm_use_v1() {
 // SPN_GEMM_CFG: 0 = v1 kernels of this file (128x128, 2 blocks/CU); 1/2/3 = gemm2.hip tile configs (default 3)
 int gemm_cfg() {
     static const int cfg = [] {
-        const char* e = getenv("SPN_GEMM_CFG");
+        const char* e = spn_env("SPN_GEMM_CFG");
         return e ? atoi(e) : 3;   // measured best on the tower shapes: 256x256 tile, staged epilogue
     }();
     return cfg;
@@ -207,7 +207,7 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
     // fewer 128x128 tiles than CUs: 64-row tiles, three workgroups per CU (SPN_NT_SMALL_MI=4 keeps the 128-row tile)
-    static const int small_mi = [] { const char* e = getenv("SPN_NT_SMALL_MI"); return e ? atoi(e) : 2; }();
+    static const int small_mi = [] { const char* e = spn_env("SPN_NT_SMALL_MI"); return e ? atoi(e) : 2; }();
     const bool half = small_mi == 2 && t128 < 256;
     const int tiles = ((M + (half ? 64 : BM) - 1) / (half ? 64 : BM)) * ((N + BN - 1) / BN);
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
@@ -417,7 +417,7 @@ int gemm_tn(const bf16_t* A, const bf16_t* B, int Kr, int N1, int N2, int lda, i
             float alpha, int accumulate, float* colsum_out, float* ws, size_t ws_bytes, hipStream_t st) {
     // small outputs (e.g. 768x768) give the 256x256 tiling too few workgroups: v1 (128x128) is faster there
     static const size_t tn2_min = [] {
-        const char* e = getenv("SPN_TN2_MIN");           // experiment knob: smallest N1*N2 routed to the 256x256 kernel
+        const char* e = spn_env("SPN_TN2_MIN");           // experiment knob: smallest N1*N2 routed to the 256x256 kernel
         return e ? (size_t)atoll(e) : (size_t)768 * 2304;
     }();
     if (!gemm_use_v1() && (size_t)N1 * N2 >= tn2_min)

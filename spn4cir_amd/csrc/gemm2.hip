@@ -14,7 +14,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#ifdef SPN_EXPERIMENTS
 #include "gemm3_nt_clobbers.inc"
+#endif
 
 // in-kernel probes (clock / phase timers, bottleneck-elimination switches; several overwrite output bytes) exist only in
 // -DSPN_GEMM_PROBES experiment builds: in the shipped library the tests fold to constants and the code is gone
@@ -798,7 +800,7 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     e.stag_from = 0;
     e.stag_ticks = 0;
     if constexpr (SCHED == 2) {
-        static const int stag_us = [] { const char* v = getenv("SPN_GEMM_STAGGER_US"); return v ? atoi(v) : 6; }();   // measured: 0 / 6 / 10 / 14 / 18 us -> 13.38 / 13.31 / 13.32 / 13.33 / 13.36 ms per step
+        static const int stag_us = [] { const char* v = spn_env("SPN_GEMM_STAGGER_US"); return v ? atoi(v) : 6; }();   // measured: 0 / 6 / 10 / 14 / 18 us -> 13.38 / 13.31 / 13.32 / 13.33 / 13.36 ms per step
         const int cus = device_cu_count(), rem = tiles % cus;
         if (stag_us > 0 && tiles > cus && rem > 0 && MODE != GEMM_BANKSTATS) {
             e.stag_from = rem;                                  // first-round workgroups [rem, cus) are delayed
@@ -811,6 +813,7 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     return SPN_OK;
 }
 
+#ifdef SPN_EXPERIMENTS   // the hand-scheduled 4-wave kernel: measured slower in the step, not in the shipped library
 // Epilogue of gemm_nt3: FULL 256x256 tiles only (the launcher routes anything else to gemm_nt2), straight-line code, and
 // wave-private: wave (wr, wc) owns the 128x128 sub-tile rows wr*128.., columns wc*128.. and turns it row-major through
 // its OWN 32 KB of LDS, so after the one barrier that ends the k loop no wave waits for another - with one wave per SIMD
@@ -1055,7 +1058,7 @@ static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
     // SPN_NT3_VAR (-DSPN_NT3_ABL experiment builds, plain-store kernel only): ablation variants of the main loop, results
     // are wrong by design - 1 no DMA, 2 no fragment reads, 3 no barrier, 4 MFMA only.  Not in the shipped library.
     static const int var = [] {
-        const char* e = getenv("SPN_NT3_VAR");
+        const char* e = spn_env("SPN_NT3_VAR");
         return e ? atoi(e) : 0;
     }();
     if (mode == GEMM_STORE && ep.act == ACT_NONE && var) {
@@ -1086,9 +1089,11 @@ static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
     return SPN_ERR_ARG;
 }
 
+#endif  // SPN_EXPERIMENTS
+
 static bool nt_phased() {
     static const bool v = [] {
-        const char* e = getenv("SPN_GEMM_NT_PHASED");
+        const char* e = spn_env("SPN_GEMM_NT_PHASED");
         return !(e && e[0] == '0');
     }();
     return v;
@@ -1096,7 +1101,7 @@ static bool nt_phased() {
 
 static bool tn_phased() {
     static const bool v = [] {
-        const char* e = getenv("SPN_GEMM_TN_PHASED");
+        const char* e = spn_env("SPN_GEMM_TN_PHASED");
         return !(e && e[0] == '0');
     }();
     return v;
@@ -1104,7 +1109,7 @@ static bool tn_phased() {
 
 static bool gemm_spread() {
     static const bool v = [] {
-        const char* e = getenv("SPN_GEMM_SPREAD");
+        const char* e = spn_env("SPN_GEMM_SPREAD");
         return !(e && e[0] == '0');
     }();
     return v;
@@ -1158,14 +1163,14 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
     static const int direct = [] {
-        const char* e = getenv("SPN_GEMM_EPI_DIRECT");
+        const char* e = spn_env("SPN_GEMM_EPI_DIRECT");
         return (e && e[0] == '1') ? 1 : 0;
     }();
     // SPN_GEMM_DBG: in-kernel probes / bottleneck-elimination switches (some overwrite the first bytes of the output):
     // compiled only into -DSPN_GEMM_PROBES experiment builds (tools/build_variant.sh), never into the shipped library
 #ifdef SPN_GEMM_PROBES
     static const int dbg = [] {
-        const char* e = getenv("SPN_GEMM_DBG");
+        const char* e = spn_env("SPN_GEMM_DBG");
         return e ? atoi(e) : 0;
     }();
 #else
@@ -1176,9 +1181,11 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     e2.dbg = dbg;
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
     switch (gemm_cfg()) {
+#ifdef SPN_EXPERIMENTS
         case 7:                                                                   // 4 waves, hand-scheduled loop
             if (nt3_ok(M, N, mode, e2)) return dispatch_nt3(A, B, M, N, K, lda, ldb, mode, e2, st);
             return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
+#endif
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
             if (nt_phased()) return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
@@ -1757,7 +1764,7 @@ static constexpr size_t TN_CS_BYTES = 4 * 1024 * 1024;      // shared column sum
 // the shared panels save in L2 misses is less than what the fast tiles lose waiting.
 static bool tn_pace_on() {
     static const bool on = [] {
-        const char* e = getenv("SPN_TN_PACE");
+        const char* e = spn_env("SPN_TN_PACE");
         return e && e[0] == '1';
     }();
     return on;
@@ -1816,7 +1823,7 @@ int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_
     // shared column sums (SPN_TN_CS_SPREAD=0: the n0 == 0 tile of every row computes them alone, as in round 2): partial
     // sums [tiles_n][N1] per problem behind the slabs and the pacing counters
     static const bool cs_spread = [] {
-        const char* e = getenv("SPN_TN_CS_SPREAD");
+        const char* e = spn_env("SPN_TN_CS_SPREAD");
         return !(e && e[0] == '0');
     }();
     g.cs_part = nullptr;
@@ -1875,7 +1882,7 @@ size_t gemm_tn2_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b)
 // SPN_TN_PAIR=0 keeps the two launches (A/B switch)
 bool gemm_tn2_pair_ok(int N1a, int N2a) {
     static const bool off = [] {
-        const char* e = getenv("SPN_TN_PAIR");
+        const char* e = spn_env("SPN_TN_PAIR");
         return e && e[0] == '0';
     }();
     return !off && gemm_cfg() == 3 && tn_phased() && (size_t)N1a * N2a >= (size_t)768 * 2304;

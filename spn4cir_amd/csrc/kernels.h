@@ -133,6 +133,8 @@ int grad_unscale_check(float* g, size_t n, float inv_scale, float* found_inf, hi
 // norm.hip
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t* y_bf16, float* y_f32, float* mean,
                   float* rstd, int rows, int W, float eps, hipStream_t st);
+int layernorm_fwd_add(const float* x, const bf16_t* y, const float* gamma, const float* beta, float* x_out, bf16_t* y_bf16,
+                      float* mean, float* rstd, int rows, int W, float eps, hipStream_t st);
 int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, const float* gamma, const float* mean,
                   const float* rstd, float* dx, int accumulate_dx, bf16_t* dx_bf16, float* dgamma, float* dbeta,
                   int accumulate_dparam, int rows, int W, float* ws, size_t ws_bytes, hipStream_t st);
@@ -195,7 +197,7 @@ int bank_stats_fwd(const BankArgs& a, float* stats /*[B,4]*/, float* ws, size_t 
 int bank_stats_fold(const float* ws, int n, int B, float* stats, hipStream_t st);
 // bank2.hip: barrier-free kernels for batches below 128 queries, backward from saved logits
 bool bank_saved_path(const BankArgs& a);
-void bank2_config(int mode);
+int bank_config(int mode);
 int bank_mode();
 int bank_saved_ld(int M);
 size_t bank_saved_bytes(int B, int M);

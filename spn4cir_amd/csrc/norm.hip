@@ -13,23 +13,30 @@ static constexpr int LN_MAXV_LIMIT = 8;   // float4 per lane -> W <= 2048
 // (3 per CU) 17.8 us, 256: 33 us, 512: 21.6, 1 024: 18.1, 2 048: 19.3.
 // EXACT: W == 256 * LN_MAXV (768, 1024, ...): every lane owns LN_MAXV full column quads, no bounds tests (each one was
 // an exec-mask branch around its load / store)
-template <int LN_MAXV, bool EXACT>
+// ADD: the residual add of the block in front is fused in - the row is x + yin (yin bf16: the out-projection / c_proj GEMM
+// result), the sum is written to xo (fp32 residual stream) and normalised.  yin may alias yb: a wave holds its whole row in
+// registers before it stores anything, and rows belong to exactly one wave.
+template <int LN_MAXV, bool EXACT, bool ADD = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, bf16_t* __restrict__ yb,
+                                                            const float* __restrict__ beta, bf16_t* yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, int rows, int W, float eps) {
+                                                            float* __restrict__ rstd, int rows, int W, float eps,
+                                                            const bf16_t* yin = nullptr, float* __restrict__ xo = nullptr) {
     // persistent: wave w walks rows w, w + nwaves, ... with the next row's loads in flight under the current row's two
     // reductions and stores
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int nv = W >> 2;   // float4 count per row
     f32x4 gm[LN_MAXV], bt[LN_MAXV], v[LN_MAXV], nx[LN_MAXV];
+    [[maybe_unused]] bf16x4 ya[LN_MAXV], ny[LN_MAXV];
+    const bf16x4 zero4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + i * 64;
         gm[i] = (EXACT || c < nv) ? *(const f32x4*)(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         bt[i] = (EXACT || c < nv) ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         v[i] = (wave < rows && (EXACT || c < nv)) ? *(const f32x4*)(x + (size_t)wave * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (ADD) ya[i] = (wave < rows && (EXACT || c < nv)) ? *(const bf16x4*)(yin + (size_t)wave * W + c * 4) : zero4;
     }
     for (int row = wave; row < rows; row += nwaves) {
         const int nrow = row + nwaves;
@@ -37,6 +44,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         for (int i = 0; i < LN_MAXV; ++i) {
             const int c = lane + i * 64;
             nx[i] = (nrow < rows && (EXACT || c < nv)) ? *(const f32x4*)(x + (size_t)nrow * W + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (ADD) ny[i] = (nrow < rows && (EXACT || c < nv)) ? *(const bf16x4*)(yin + (size_t)nrow * W + c * 4) : zero4;
+        }
+        if constexpr (ADD) {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c = lane + i * 64;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += bf2f(ya[i][e]);
+                if (EXACT || c < nv) *(f32x4*)(xo + (size_t)row * W + c * 4) = v[i];
+            }
         }
         float s = 0.f;
 #pragma unroll
@@ -74,7 +91,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) v[i] = nx[i];
+        for (int i = 0; i < LN_MAXV; ++i) {
+            v[i] = nx[i];
+            if constexpr (ADD) ya[i] = ny[i];
+        }
     }
 }
 
@@ -99,6 +119,34 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
     else if (W <= 1024) SPN_LN_FWD(4);
     else SPN_LN_FWD(8);
 #undef SPN_LN_FWD
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// x_out = x + y (y bf16, may alias y_bf16), then LayerNorm of x_out: the residual add of the GEMM in front fused into the
+// normalisation that follows it (tower.hip: block_fwd with a deferred residual).  180 MB instead of 90 MB per call at
+// [19 712, 768], but the GEMM in front stores 30 MB of bf16 instead of reading and writing 2 x 60 MB of fp32 in its epilogue.
+int layernorm_fwd_add(const float* x, const bf16_t* y, const float* gamma, const float* beta, float* x_out, bf16_t* y_bf16,
+                      float* mean, float* rstd, int rows, int W, float eps, hipStream_t st) {
+    if (rows <= 0 || !x || !y || !x_out || !y_bf16) return SPN_ERR_ARG;
+    if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
+    static const int cap = env_int_min1("SPN_LNF_BLOCKS", 768);
+    const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
+#define SPN_LN_FWD_ADD(V_)                                                                                      \
+    do {                                                                                                        \
+        if (W == 256 * V_)                                                                                      \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<V_, true, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, \
+                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out);                            \
+        else                                                                                                    \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<V_, false, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, \
+                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out);                            \
+    } while (0)
+    if (W <= 256) SPN_LN_FWD_ADD(1);
+    else if (W <= 512) SPN_LN_FWD_ADD(2);
+    else if (W <= 768) SPN_LN_FWD_ADD(3);
+    else if (W <= 1024) SPN_LN_FWD_ADD(4);
+    else SPN_LN_FWD_ADD(8);
+#undef SPN_LN_FWD_ADD
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -12,6 +12,7 @@ struct BlockCfg {
     // T == 0 means the dense B*L layout
     int T = 0;
     const int32_t* cu = nullptr;
+    int fuse_resid = 0;   // block_fwd: residual adds deferred into the following LayerNorm (tower.hip)
     int rows() const { return T > 0 ? T : B * L; }
 };
 
@@ -98,7 +99,8 @@ size_t block_act_bytes(const BlockCfg& c);
 BlockActs block_acts_at(char* base, const BlockCfg& c);
 size_t block_bwd_scratch_bytes(const BlockCfg& c);
 size_t block_op_ws_bytes(const BlockCfg& c);
-int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st);
+int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st, const float* x_prev = nullptr,
+              bf16_t* y_out = nullptr);
 // Optional overlap of the weight-gradient (TN) GEMMs with the rest of a block's backward: they feed nothing
 // downstream, so they run on a side stream behind events while the main stream continues with the data path
 // (NT GEMMs, LayerNorm / attention backward).  dxb_alt: second bf16 residual-gradient buffer [T, W] (the TN

@@ -1,0 +1,37 @@
+"""The experiments build (make -C spn4cir_amd/csrc EXPERIMENTS=1 -> libspn4cir_hip_exp.so: the same C-ABI plus the kernels that
+were measured slower and left out of the shipped library - csrc/bank2.hip's streaming pair, the hand-scheduled 4-wave NT GEMM)
+keeps passing its parity tests: the tests that need those kernels skip in the main run and run here, in a child pytest that
+loads the variant through SPN_LIB_PATH."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXP_LIB = os.path.join(ROOT, "spn4cir_amd", "libspn4cir_hip_exp.so")
+
+
+def test_experiments_library_exports_the_same_abi():
+    """CPU: the variant loads and carries every symbol of include/spn4cir_hip.h (no compute calls)."""
+    if not os.path.exists(EXP_LIB):
+        pytest.skip("experiments build absent (python -c 'import __graft_entry__ as g; g.build()')")
+    code = ("from spn4cir_amd import _lib; L = _lib.lib(); "
+            "missing = [s for s in _lib.header_symbols() if not hasattr(L, s)]; assert not missing, missing; "
+            "assert _lib.config_dump()['experiments_build'] == 1")
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPN_LIB_PATH=EXP_LIB), cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_experiment_kernels_parity():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    assert os.path.exists(EXP_LIB), "experiments build absent: __graft_entry__.build() makes it"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-x", "-q", "-k",
+                        "saved_logits_pair or nt3_hand_scheduled"], env=dict(os.environ, SPN_LIB_PATH=EXP_LIB), cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "skipped" not in p.stdout.splitlines()[-1], p.stdout[-500:]
