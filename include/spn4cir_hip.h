@@ -180,6 +180,17 @@ int spn_bank_grad_q_saved(const void* q_bf16, int ldq, const void* bank, const f
                           int M, int D, int m_begin, float inv_tau, const float* logits_saved, const float* row_lse,
                           float label_smoothing, int64_t M_total, float grad_scale, float* dq, void* ws, size_t ws_bytes,
                           void* stream);
+/* The whole loss step of clip4cir/models_negplus.py:150-154 (forward) and its autograd gradient w.r.t. the queries in ONE
+ * call, for a bank held entirely by this process (one shard: labels are rows of `bank`, M = M_total) and label smoothing 0:
+ * the single pass over the bank followed by ONE tail launch that folds the chunk statistics and partials - row_lse [B],
+ * row_loss [B], loss_mean [1] (summed in index order: bit-reproducible) and dq [B, D] fp32 = grad_scale * d(sum of row
+ * losses)/dq.  Replaces spn_bank_stats_fwd_save + spn_bank_loss_finalize + spn_bank_grad_q_saved (four launches, three of
+ * them launch-bound) where spn_bank_step_ok(B, M, D, fp8) is 1; otherwise SPN_ERR_SHAPE and the caller uses the three calls.
+ * logits_save: spn_bank_logits_bytes(B, M) bytes of device scratch. */
+int spn_bank_step_ok(int B, int M, int D, int fp8);
+int spn_bank_step(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B, int M,
+                  int D, float inv_tau, float grad_scale, float* logits_save, float* row_lse, float* row_loss, float* loss_mean,
+                  float* dq, void* stream);
 /* fp8 bank (BASELINE config 5): the static bank stored as OCP e4m3 bytes [M, Dp] + one fp32 scale per row
  * (row max -> 448), halving the only HBM stream of the loss.  The kernels dequantise a tile into LDS (x scale,
  * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /
@@ -456,6 +467,20 @@ int spn_fusion_fwd(const spn_fusion_cfg* cfg, const float* params, const void* w
                    const int32_t* mask, const float* enc, void* acts, float* proj_out, void* stream);
 int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                    void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* The same backward pass in phases, for data-parallel callers that start a layer group's gradient all-reduce while the layers
+ * below are still running (blip4cir/train.py has no DDP): phase 0 = head (text_proj; needs dproj), 1 = layers
+ * [l_lo, l_hi) from the top down INCLUDING their weight gradients (the flat range of those layers is final when the call
+ * returns), 2 = tail (embeddings).  Call 0, then 1 over disjoint groups from layers-1 down to 0, then 2; the residual gradient
+ * stays in ws between the calls. */
+int spn_fusion_bwd_phase(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                         void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, int phase, int l_lo, int l_hi,
+                         void* stream);
+/* out[b, :D] = bf16(x[b, :] * s), out[b, D:ldo] = 0, s = *scale_dev or 1 / *scale_dev (reciprocal != 0): the query scaled by
+ * a DEVICE-resident temperature (blip4cir/models.py:29 keeps tau as an nn.Parameter; logits = (q / tau) . bank with the bank
+ * calls at inv_tau = 1 - no host read of tau inside a step). */
+int spn_scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, void* out_bf16, int B, int D, int ldo,
+                        void* stream);
 
 /* ---------------------------------------------------------------- opt-in kernel timing
  * HIP events recorded on the launch stream around the main kernels (bench.py's live roofline).

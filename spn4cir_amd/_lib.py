@@ -84,6 +84,10 @@ _SIGS = {
     "spn_bank_logits_bytes": (sz, [i32, i32]),
     "spn_bank_config": (i32, [i32]),
     "spn_config_dump": (i32, [C.c_char_p, i32]),
+    "spn_bank_step_ok": (i32, [i32, i32, i32, i32]),
+    "spn_fusion_bwd_phase": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "spn_scale_cast_bf16": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
+    "spn_bank_step": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "spn_bank_stats_fwd_save": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
     "spn_bank_grad_q_saved": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_bank_workspace_bytes_fp8": (sz, [i32, i32, i32]),

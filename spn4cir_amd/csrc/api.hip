@@ -214,6 +214,21 @@ int spn_bank_grad_q_saved(const void* q_bf16, int ldq, const void* bank, const f
     return bank_grad_q(a, row_lse, label_smoothing, M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream), logits_saved);
 }
 
+int spn_bank_step_ok(int B, int M, int D, int fp8) {
+    BankArgs a = make_bank(nullptr, D, nullptr, nullptr, B, M, D, 0, 1.0f);
+    static const float one = 1.0f;
+    a.bank_scale = fp8 ? &one : nullptr;          // only tested against nullptr
+    return bank_step_ok(a) ? 1 : 0;
+}
+
+int spn_bank_step(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B, int M,
+                  int D, float inv_tau, float grad_scale, float* logits_save, float* row_lse, float* row_loss, float* loss_mean,
+                  float* dq, void* stream) {
+    BankArgs a = make_bank(q_bf16, ldq, bank, labels, B, M, D, 0, inv_tau);
+    a.bank_scale = bank_scale;
+    return bank_step(a, logits_save, grad_scale, row_lse, row_loss, loss_mean, dq, ST(stream));
+}
+
 size_t spn_bank_workspace_bytes(int B, int M, int D) { return bank_workspace_bytes(B, M, D); }
 size_t spn_bank_workspace_bytes_fp8(int B, int M, int D) { return bank_workspace_bytes_fp8(B, M, D); }
 
@@ -479,6 +494,20 @@ int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* w
                    void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream) {
     if (!cfg || !params || !weights_bf16 || !ids || !acts || !dproj || !grads || !ws) return SPN_ERR_ARG;
     return fusion_bwd(fc(cfg), params, CBF(weights_bf16), ids, (char*)acts, dproj, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
+int spn_fusion_bwd_phase(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                         void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, int phase, int l_lo, int l_hi,
+                         void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return fusion_bwd_phase(fc(cfg), params, CBF(weights_bf16), ids, (char*)acts, dproj, grads, (char*)ws, ws_bytes, phase, l_lo,
+                            l_hi, ST(stream));
+}
+
+int spn_scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, void* out_bf16, int B, int D, int ldo,
+                        void* stream) {
+    if (!x || !scale_dev || !out_bf16) return SPN_ERR_ARG;
+    return scale_cast_bf16(x, scale_dev, reciprocal, BF(out_bf16), B, D, ldo, ST(stream));
 }
 
 int spn_text_bwd_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,

@@ -696,6 +696,8 @@ __global__ __launch_bounds__(256, 1) void bank_stream_kernel(BankArgs a, BankChu
                     o[0] = m * 0.6931471805599453f; o[1] = l; o[2] = sl; o[3] = lab;    // the reference exponent in natural-log units
                 }
             }
+            // arrival counter of bank_step_tail_kernel (the word behind the statistics partials): reset by the launch in front of it
+            if (blockIdx.x == 0 && tid == 0) *(int*)(ws2 + (size_t)ck.nchunks * a.B * 4) = 0;
         }
     }
 }
@@ -763,6 +765,110 @@ __global__ __launch_bounds__(256) void bank_fused_combine_kernel(const float* __
                 t -= v * cl;
             }
             dq[(size_t)b * lddq + col] = t * alpha;
+        }
+    }
+}
+
+// The whole tail of a single-shard step in ONE launch (bank_step): fold of the chunk statistics (what bank_stats_fold_kernel +
+// bank_loss_finalize_kernel do in two launches of a handful of workgroups - 4 us each, launch-bound), the fold of the chunk
+// partials with the label row subtracted (bank_fused_combine_kernel), row_lse / row_loss, and the mean loss.  Block =
+// (64 columns, one query) as in the combine kernel; every block folds its query's nch x {m, l, sum z, label z} itself
+// (4 KB from L2 - cheaper than a launch boundary).  The mean is summed in a FIXED order by the wave that arrives last
+// (ticket on a counter the pass in front resets; release / acquire at agent scope): bit-reproducible, no atomics on floats.
+template <bool FP8>
+__global__ __launch_bounds__(256) void bank_step_tail_kernel(const float* __restrict__ Op, const float* __restrict__ sp, int nch,
+                                                            int B, int D, const void* __restrict__ bank, const float* __restrict__ scale,
+                                                            const int64_t* __restrict__ labels, int M, float alpha,
+                                                            float* __restrict__ dq, int lddq, float* __restrict__ row_lse,
+                                                            float* row_loss, float* __restrict__ loss_mean, int* counter) {
+    __shared__ float red[16][16][5];
+    __shared__ float fm[4], fl[4], fz[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cq = tid & 15, rl = tid >> 4;
+    const int b = blockIdx.y, c = (blockIdx.x * 16 + cq) * 4;
+    const size_t so = (size_t)B * D, ss = (size_t)B * 4;
+    const float* st = sp + (size_t)b * 4;
+    // ---- statistics of query b over all chunks
+    float m = -INFINITY, l = 0.f, zlab = -INFINITY;
+    for (int i = tid; i < nch; i += 256) {
+        const f32x4 p = *(const f32x4*)(st + (size_t)i * ss);
+        const float mn = fmaxf(m, p[0]);
+        if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+        m = mn;
+        zlab = fmaxf(zlab, p[3]);
+    }
+    {
+        const float mw = wave_max(m);
+        l = (m > -INFINITY) ? l * __expf(m - mw) : 0.f;
+        l = wave_sum(l);
+        zlab = wave_max(zlab);
+        if (lane == 0) { fm[w] = mw; fl[w] = l; fz[w] = zlab; }
+    }
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(fm[0], fm[1]), fmaxf(fm[2], fm[3]));
+    float lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lt += (fm[k] > -INFINITY) ? fl[k] * __expf(fm[k] - mx) : 0.f;
+    const float ls = mx + logf(lt);
+    const float z = fmaxf(fmaxf(fz[0], fz[1]), fmaxf(fz[2], fz[3]));
+    // ---- dq[b, 64 columns] = alpha (sum_c exp(m_c - lse) O_c - (1 - p_label) bank[label])
+    f32x4 s = {0, 0, 0, 0};
+    const bool in = c < D;
+    const float* o = Op + (size_t)b * D + (in ? c : 0);
+    int r = rl;
+    for (; r + 48 < nch; r += 64) {
+        const f32x4 v0 = *(const f32x4*)(o + (size_t)r * so), v1 = *(const f32x4*)(o + (size_t)(r + 16) * so);
+        const f32x4 v2 = *(const f32x4*)(o + (size_t)(r + 32) * so), v3 = *(const f32x4*)(o + (size_t)(r + 48) * so);
+        const float* s0 = st + (size_t)r * ss;
+        const float m0 = s0[0], m1 = s0[16 * ss], m2 = s0[32 * ss], m3 = s0[48 * ss];
+        s += v0 * __expf(m0 - ls);
+        s += v1 * __expf(m1 - ls);
+        s += v2 * __expf(m2 - ls);
+        s += v3 * __expf(m3 - ls);
+    }
+    for (; r < nch; r += 16) s += *(const f32x4*)(o + (size_t)r * so) * __expf(st[(size_t)r * ss] - ls);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cq][e] = s[e];
+    __syncthreads();
+    if (tid < 64) {                                                  // thread = one column of the block
+        const int col = blockIdx.x * 64 + tid;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tid >> 2][tid & 3];
+        if (col < D) {
+            const int64_t lab = labels[b];
+            if (lab >= 0 && lab < (int64_t)M) {
+                const float cl = 1.0f - __expf(z - ls);
+                float v;
+                if constexpr (FP8) {
+                    const uint32_t w4 = *(const uint32_t*)((const uint8_t*)bank + (size_t)lab * D + (col & ~3));
+                    const f32x2 p2 = (col & 2) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)w4, true) : __builtin_amdgcn_cvt_pk_f32_fp8((int)w4, false);
+                    v = bf2f(f2bf(p2[col & 1] * scale[lab]));
+                } else {
+                    v = bf2f(((const bf16_t*)bank)[(size_t)lab * D + col]);
+                }
+                t -= v * cl;
+            }
+            dq[(size_t)b * lddq + col] = t * alpha;
+        }
+        // ---- per-row outputs and the mean loss (the blocks of column group 0, wave 0)
+        if (blockIdx.x == 0) {
+            int ticket = 0;
+            if (tid == 0) {
+                row_lse[b] = ls;
+                row_loss[b] = ls - z;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ticket = __shfl(ticket, 0, 64);
+            if (ticket == B - 1) {                                   // every row_loss is published: sum them in index order
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                float acc = 0.f;
+                for (int i = tid; i < B; i += 64) acc += __hip_atomic_load(row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc = wave_sum(acc);
+                if (tid == 0) *loss_mean = acc / (float)B;
+            }
         }
     }
 }
@@ -1316,6 +1422,7 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
             o[0] = m * 0.6931471805599453f; o[1] = l; o[2] = sl; o[3] = lab;
         }
     }
+    if (blockIdx.x == 0 && tid == 0) *(int*)(sp + (size_t)ck.nchunks * a.B * 4) = 0;   // bank_step_tail_kernel's arrival counter
 }
 
 template <int D>
@@ -1716,7 +1823,7 @@ static int fused_blocks(int B, int M, bool fp8, int D) {
 }
 static size_t fused_save_bytes(int B, int M, int D) {
     const BankChunking c = bank_chunking(B, M, fused_blocks(B, M, true, 768));     // the larger of the two chunk counts
-    return (size_t)c.nchunks * B * (D + 4) * sizeof(float);     // fp32 partials + {m, l, sum z, label z}
+    return (size_t)c.nchunks * B * (D + 4) * sizeof(float) + 64;     // fp32 partials + {m, l, sum z, label z} + arrival counter
 }
 
 template <int D, bool FP8>
@@ -1775,6 +1882,47 @@ static int bank_fused_bwd(const BankArgs& a, const float* save, const float* row
     else
         hipLaunchKernelGGL(bank_fused_combine_kernel<false>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, row_lse,
                            (const void*)a.bank, (const float*)nullptr, a.labels, a.m_begin, a.M, grad_scale * a.inv_tau, dq, a.D);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// One shard holding the whole bank, no label smoothing: the step's forward AND backward w.r.t. the queries in two launches
+// (the single pass over the bank + bank_step_tail_kernel) instead of four (pass, statistics fold, finalize, combine).
+static int bank_check(const BankArgs& a);
+bool bank_step_ok(const BankArgs& a) {
+    return bank_fused_ok(a) && !bank_saved_path(a) && !(bank_saved_path_large(a) && !bank_fused_large());
+}
+int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean, float* dq,
+              hipStream_t st) {
+    int rc = bank_check(a);
+    if (rc) return rc;
+    if (!save || !row_lse || !row_loss || !loss_mean || !dq || a.m_begin != 0) return SPN_ERR_ARG;
+    if (!bank_step_ok(a)) return SPN_ERR_SHAPE;
+    const BankChunking c = bank_chunking(a.B, a.M, fused_blocks(a.B, a.M, a.bank_scale != nullptr, a.D));
+    float* Op = save;
+    float* sp = save + (size_t)c.nchunks * a.B * a.D;
+    static const bool f8 = [] {
+        const char* e = spn_env("SPN_BANK_FP8_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    const bool f8k = f8 && bank_mode() != 4 && a.bank_scale && c.rows <= FP8_MAX_CHUNK_ROWS;
+    rc = SPN_ERR_SHAPE;
+#define SPN_FUSED(D_) case D_: rc = f8k ? launch_bank_fp8_fused<D_>(a, c, Op, sp, st) : a.bank_scale ? launch_bank_fused<D_, true>(a, c, Op, sp, st) : launch_bank_fused<D_, false>(a, c, Op, sp, st); break;
+    switch (a.D) {
+        SPN_FUSED(128) SPN_FUSED(256) SPN_FUSED(512) SPN_FUSED(640) SPN_FUSED(768) SPN_FUSED(1024)
+        default: return SPN_ERR_SHAPE;
+    }
+#undef SPN_FUSED
+    if (rc) return rc;
+    ProfScope prof(PK_BANK_BWD, (double)c.nchunks * a.B * (a.D * 4 + 16) + (double)a.B * a.D * 6, st);
+    const dim3 grid((a.D + 63) / 64, a.B);
+    int* counter = (int*)(sp + (size_t)c.nchunks * a.B * 4);
+    if (a.bank_scale)
+        hipLaunchKernelGGL(bank_step_tail_kernel<true>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, (const void*)a.bank,
+                           a.bank_scale, a.labels, a.M, grad_scale * a.inv_tau, dq, a.D, row_lse, row_loss, loss_mean, counter);
+    else
+        hipLaunchKernelGGL(bank_step_tail_kernel<false>, grid, dim3(256), 0, st, Op, sp, c.nchunks, a.B, a.D, (const void*)a.bank,
+                           (const float*)nullptr, a.labels, a.M, grad_scale * a.inv_tau, dq, a.D, row_lse, row_loss, loss_mean, counter);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

@@ -24,6 +24,25 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) y[(n8 << 3) + threadIdx.x] = f2bf(x[(n8 << 3) + threadIdx.x]);
 }
 
+__global__ void scale_cast_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale_dev, int reciprocal,
+                                       bf16_t* __restrict__ y, int B, int D, int ldo) {
+    const float s = reciprocal ? 1.0f / *scale_dev : *scale_dev;
+    const size_t n = (size_t)B * ldo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / ldo), c = (int)(i % ldo);
+        y[i] = c < D ? f2bf(x[(size_t)b * D + c] * s) : (bf16_t)0.f;
+    }
+}
+
+int scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, bf16_t* y, int B, int D, int ldo, hipStream_t st) {
+    if (B <= 0 || D <= 0 || ldo < D) return SPN_ERR_ARG;
+    const size_t n = (size_t)B * ldo;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(scale_cast_bf16_kernel, dim3(blocks), dim3(256), 0, st, x, scale_dev, reciprocal, y, B, D, ldo);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
     if (n == 0) return SPN_OK;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, x, y, n);

@@ -320,8 +320,29 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
 }
 
 // dproj: gradient w.r.t. the text_proj output [B, Dp] (i.e. after spn_combine_l2norm_bwd)
+// phases (bit mask): 1 = head (text_proj), 2 = the layers [l_lo, l_hi) from the top down incl. their deferred weight
+// gradients (final when the call returns), 4 = tail (embeddings).  The residual gradient lives in the workspace between the
+// calls (the carve-up is identical in every phase), so a data-parallel caller can hand a group's gradient range to its
+// all-reduce while the layers below are still running (spn_fusion_bwd_phase; FusionEncoder.backward_phased).
+static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                           const float* dproj, float* grads, char* ws, size_t ws_bytes, int phases, int l_lo, int l_hi,
+                           hipStream_t st);
+
 int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
                const float* dproj, float* grads, char* ws, size_t ws_bytes, hipStream_t st) {
+    return fusion_bwd_impl(c, params, wb, ids, acts, dproj, grads, ws, ws_bytes, 7, 0, c.layers, st);
+}
+
+int fusion_bwd_phase(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                     const float* dproj, float* grads, char* ws, size_t ws_bytes, int phase, int l_lo, int l_hi, hipStream_t st) {
+    if (phase < 0 || phase > 2) return SPN_ERR_ARG;
+    if (phase == 1 && (l_lo < 0 || l_hi > c.layers || l_lo >= l_hi)) return SPN_ERR_ARG;
+    return fusion_bwd_impl(c, params, wb, ids, acts, dproj, grads, ws, ws_bytes, 1 << phase, l_lo, l_hi, st);
+}
+
+static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                           const float* dproj, float* grads, char* ws, size_t ws_bytes, int phases, int l_lo, int l_hi,
+                           hipStream_t st) {
     SPN_TRYF(fusion_check(c));
     if (ws_bytes < fusion_ws_bytes(c)) return SPN_ERR_WORKSPACE;
     FusionLayout t;
@@ -362,13 +383,16 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     const size_t opws_bytes = ws_bytes - (size_t)(p - ws);
 
     // head: text_proj
-    SPN_TRYF(cast_f32_bf16(dproj, dprojb, (size_t)c.B * c.Dp, st));
-    SPN_TRYF(gemm_tn(dprojb, A.h0b, c.B, c.Dp, W, c.Dp, W, grads + t.proj_w, W, 1.0f, 0, grads + t.proj_b, opws,
-                     opws_bytes, st));
-    SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, dh0, st));
-    SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
+    if (phases & 1) {
+        if (!dproj) return SPN_ERR_ARG;
+        SPN_TRYF(cast_f32_bf16(dproj, dprojb, (size_t)c.B * c.Dp, st));
+        SPN_TRYF(gemm_tn(dprojb, A.h0b, c.B, c.Dp, W, c.Dp, W, grads + t.proj_w, W, 1.0f, 0, grads + t.proj_b, opws,
+                         opws_bytes, st));
+        SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, dh0, st));
+        SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
+    }
 
-    for (int l = c.layers - 1; l >= 0; --l) {
+    for (int l = (phases & 2) ? l_hi - 1 : -1; l >= l_lo; --l) {
         FusionLayerActs a = fusion_layer_acts_at(A.layers + A.layer_bytes * l, c);
         const float* pp = params + t.layers + t.layer_size * l;
         float* gp = grads + t.layers + t.layer_size * l;
@@ -453,6 +477,7 @@ int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         SPN_TRYF(gemm_tn_grouped(qT + i, nT - i < TN_GROUP_MAX ? nT - i : TN_GROUP_MAX, T, opws, opws_bytes, st));
     if (nS) SPN_TRYF(gemm_tn_grouped(qS, nS, TS, opws, opws_bytes, st));
     SPN_TRYF(fold_flush());
+    if (!(phases & 4)) return SPN_OK;
     // embeddings: x0 = LN(word[ids] + pos)
     SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
                            grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));

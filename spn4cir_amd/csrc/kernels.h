@@ -81,6 +81,8 @@ int gemm_cfg();
 
 // elementwise.hip
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
+// y[b, :D] = bf16(x[b, :] * s), y[b, D:ldo] = 0; s = *scale_dev (device scalar) or its reciprocal
+int scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, bf16_t* y, int B, int D, int ldo, hipStream_t st);
 int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);             // y[c][r] = x[r][c]
 int cast_transpose_f32_bf16(const float* x, bf16_t* y, bf16_t* yt, int rows, int cols, hipStream_t st);
 struct CastTransposeSet {           // up to 4 matrices per repetition (element offsets), see cast_transpose_multi
@@ -207,6 +209,11 @@ size_t bank2_workspace_bytes(int B, int M, int D);
 int bank2_stats_fwd(const BankArgs& a, float* stats, float* zsave, float* ws, size_t ws_bytes, hipStream_t st);
 int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, float label_smoothing, int64_t M_total,
                  float grad_scale, float* dq, float* ws, size_t ws_bytes, hipStream_t st);
+// the whole loss step of ONE shard that holds the full bank (m_begin = 0), label smoothing 0, in two launches; SPN_ERR_SHAPE
+// when the single-pass kernels do not serve the shape (bank_step_ok) - callers then use the three calls
+bool bank_step_ok(const BankArgs& a);
+int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean, float* dq,
+              hipStream_t st);
 // finalize on the owner of all shards' stats: row_lse, row_loss and the mean loss
 int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
                        float* row_lse, float* row_loss, float* loss_mean, hipStream_t st);

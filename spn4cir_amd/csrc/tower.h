@@ -88,6 +88,9 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
                const float* enc, char* acts, float* proj_out, hipStream_t st);
 int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
                const float* dproj, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
+// phase 0 = head (needs dproj), 1 = layers [l_lo, l_hi) top-down with their weight gradients, 2 = tail (embeddings)
+int fusion_bwd_phase(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                     const float* dproj, float* grads, char* ws, size_t ws_bytes, int phase, int l_lo, int l_hi, hipStream_t st);
 
 void block_param_offsets(int W, int64_t off[13]);
 int64_t block_bf16_size(int W);

@@ -104,6 +104,22 @@ class BankLossDP:
             return ops.bank_stats_fwd(q, bank, labels, inv_tau, m_begin, save=save), save
 
         if self.mode == "replicated" or _skip(self.world):
+            # the whole bank on this rank, no label smoothing: forward and backward w.r.t. q in two launches (spn_bank_step)
+            step_ok = getattr(ops, "bank_step_ok", None)
+            if (step_ok is not None and label_smoothing == 0.0 and m_begin == 0 and bank.shape[0] == M_total
+                    and step_ok(qb_local.shape[0], M_total, qb_local.shape[1], bank)):
+                save = ops.bank_logits_buffer(qb_local.shape[0], M_total, qb_local.device)
+                if save is not None:
+                    B_global = qb_local.shape[0] * self.world
+                    lse, row, mean, dq = ops.bank_step(qb_local, bank, labels_local, inv_tau, 1.0 / B_global, save)
+                    loss = mean
+                    if not _skip(self.world):
+                        loss = row.sum().reshape(1)
+                        dist.all_reduce(loss, group=self.group)      # reporting only
+                        loss = loss / B_global
+                    return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss, bank=bank, m_begin=m_begin,
+                                M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False,
+                                saved=None, dq=dq)
             stats, saved = stats_fwd(qb_local, labels_local)
             lse, row, mean = ops.bank_loss_finalize(stats, M_total, label_smoothing)
             loss = row.sum().reshape(1)
@@ -124,6 +140,8 @@ class BankLossDP:
 
     def backward(self, ctx, loss_scale=1.0):
         """-> d(loss_scale * global mean loss)/d(q_local)  [B_local, Dp] fp32"""
+        if ctx.get("dq") is not None:                    # bank_step already produced d(mean loss)/dq
+            return ctx["dq"] if loss_scale == 1.0 else ctx["dq"] * loss_scale
         gs = loss_scale / ctx["B_global"]
         kw = {"saved": ctx["saved"]} if ctx.get("saved") is not None else {}
         dq = self.ops.bank_grad_q(ctx["q"], ctx["bank"], ctx["labels"], ctx["inv_tau"], ctx["lse"], gs,

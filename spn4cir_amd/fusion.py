@@ -128,6 +128,47 @@ class FusionEncoder:
         return self.grads
 
 
+    def layer_spans(self):
+        """Flat-gradient ranges in the order backward_phased finishes them: [head (text_proj), layer L-1, ..., layer 0,
+        tail (embeddings)]."""
+        lay = self._lay
+        out = [(int(lay.proj_w), self.n_params)]
+        for l in reversed(range(self.layers)):
+            b = int(lay.layers + lay.layer_size * l)
+            out.append((b, b + int(lay.layer_size)))
+        out.append((0, int(lay.layers)))
+        return out
+
+    def backward_phased(self, dproj, on_span_ready, groups=None):
+        """backward() in phases (spn_fusion_bwd_phase): on_span_ready(start, end) is called right after the launches that
+        finish the flat-gradient range [start, end) have been enqueued - head, then the layers in `groups` (block counts from
+        the top, summing to `layers`; a group's weight gradients are one set of grouped launches behind its data path), then
+        the embeddings: the DDP bucket hook, as TextTower.backward_phased."""
+        ids, cfg = self._last
+        dproj = dproj.contiguous()
+        groups = groups or [self.layers]
+        if sum(groups) != self.layers or any(g <= 0 for g in groups):
+            raise ValueError(f"groups {groups} must split {self.layers} layers")
+        spans = self.layer_spans()
+
+        def phase(k, lo, hi):
+            check(lib().spn_fusion_bwd_phase(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(self._acts), _p(dproj),
+                                             _p(self.grads), _p(self._ws), self._ws.numel(), k, lo, hi, _stream()),
+                  "fusion_bwd_phase")
+        phase(0, 0, 0)
+        on_span_ready(*spans[0])
+        hi = self.layers
+        for g in groups:
+            lo = hi - g
+            phase(1, lo, hi)
+            for l in reversed(range(lo, hi)):
+                on_span_ready(*spans[1 + (self.layers - 1 - l)])
+            hi = lo
+        phase(2, 0, 0)
+        on_span_ready(*spans[-1])
+        return self.grads
+
+
 class BlipBankStep:
     """blip4cir/models.py:95-121 on the kernels: q = normalize(text_proj(fusion(ref_tokens, text)[:,0])),
     loss = CE(q @ target_bank.T / tau).  tau is learnable there (nn.Parameter, models.py:29): its gradient
@@ -160,12 +201,14 @@ class BlipStage2Trainer:
     AdamW(lr, betas (0.9, 0.999), eps 1e-7) and default weight decay."""
 
     def __init__(self, encoder, tau=0.03, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="sharded", label_smoothing=0.0, learn_tau=True, bucket_elems=8 << 20):
+                 bank_mode="auto", label_smoothing=0.0, learn_tau=True, bucket_elems=8 << 20):
         from . import distributed as dp
         self.enc, self.group = encoder, group
+        self._bank_mode_arg = bank_mode      # "auto": replicated below 10^6 bank rows (set_bank), as bench.py --bank-mode auto
         self.lr, self.betas, self.eps, self.wd, self.ls = lr, betas, eps, weight_decay, label_smoothing
         self.world, self.rank = dp._world(group)
-        self.loss_dp = dp.BankLossDP(ops, group, bank_mode if (self.world > 1 or dp._FORCE) else "replicated")
+        first = "replicated" if bank_mode == "auto" else bank_mode
+        self.loss_dp = dp.BankLossDP(ops, group, first if (self.world > 1 or dp._FORCE) else "replicated")
         self.reducer = dp.GradBucketReducer(encoder.grads, group, bucket_elems)
         self._shard_range = dp.shard_range
         self.m = torch.zeros_like(encoder.params)
@@ -183,6 +226,10 @@ class BlipStage2Trainer:
         """target_bank fp32 [M, Dp], L2-normalised rows; sharded mode keeps only this rank's rows on the device."""
         dev = self.enc.device
         self._M_total = target_bank.shape[0]
+        if self._bank_mode_arg == "auto" and self.world > 1:
+            # a 30 000 x 256 bank is 15 MB: sharding it puts three latency-bound collectives on the critical path to save a
+            # few microseconds of bank kernel; the all-gather variant pays from ~10^6 rows (DESIGN.md section 6)
+            self.loss_dp.mode = "sharded" if self._M_total >= 1000000 else "replicated"
         if self.loss_dp.mode == "sharded" and self.world > 1:
             b, e = self._shard_range(self._M_total, self.world, self.rank)
             self._m_begin = b
@@ -195,16 +242,21 @@ class BlipStage2Trainer:
         """ids/mask int32 [B_local, L], ref_tokens fp32 [B_local, S, E], labels int64 [B_local] global bank rows.
         Returns the global mean loss (1-element device tensor)."""
         enc = self.enc
-        tau = float(self.tau.item()) if self.learn_tau else float(self.tau[0])
+        from .trainer import wgrad_groups
         proj = enc.forward(ids, mask, ref_tokens)
-        q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
-        ctx = self.loss_dp.forward(qb, labels, self._bank, self._m_begin, self._M_total, 1.0 / tau, self.ls)
-        dq = self.loss_dp.backward(ctx)[:, :enc.Dp].contiguous()
+        q, _, inv = ops.combine_l2norm_fwd(None, None, proj)
+        # the temperature is a parameter that lives on the device (models.py:29): logits = (q / tau) . bank with the bank
+        # kernels at inv_tau = 1, every factor of tau applied by device-side scalars - no host read, so the host keeps
+        # enqueueing the next step while this one runs
+        inv_tau = torch.reciprocal(self.tau)
+        qs = ops.scale_cast_bf16(q, self.tau, reciprocal=True, ldo=self._bank.shape[1])
+        ctx = self.loss_dp.forward(qs, labels, self._bank, self._m_begin, self._M_total, 1.0, self.ls)
+        dqk = self.loss_dp.backward(ctx)[:, :enc.Dp].contiguous()         # d loss / d (q / tau)
         if self.learn_tau:
-            self._tau_g.copy_((-(q * dq).sum() / tau).reshape(1))
-        dproj = ops.combine_l2norm_bwd(q, inv, dq)
-        enc.backward(dproj)
-        self.reducer.on_span_ready(0, enc.n_params)
+            self._tau_g.copy_((-(q * dqk).sum() * inv_tau * inv_tau).reshape(1))      # d loss / d tau
+        dproj = ops.combine_l2norm_bwd(q, inv, dqk, scale=inv_tau)
+        groups = wgrad_groups(enc.layers, self.world)
+        enc.backward_phased(dproj, self.reducer.on_span_ready, groups if self.world > 1 else None)
         self.reducer.finish()
         self.step_count += 1
         ops.adamw_step(enc.params, enc.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)

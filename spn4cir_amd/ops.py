@@ -386,6 +386,44 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
 
 
 # -------------------------------------------------------------------------------- AdamW
+def scale_cast_bf16(x, scale_dev, reciprocal=False, ldo=None):
+    """bf16(x * s) with s = the 1-element fp32 DEVICE tensor scale_dev (or 1 / s), zero padded to ldo columns: a query
+    scaled by a learnable temperature without reading it on the host (spn_scale_cast_bf16)."""
+    _req(x, torch.float32, "x")
+    if scale_dev.dtype != torch.float32 or not scale_dev.is_cuda or scale_dev.numel() != 1:
+        raise ValueError("scale_dev must be a 1-element fp32 device tensor")
+    B, D = x.shape
+    ldo = ldo or bank_dim(D)
+    out = torch.empty(B, ldo, dtype=torch.bfloat16, device=x.device)
+    check(lib().spn_scale_cast_bf16(_p(x.contiguous()), _p(scale_dev), 1 if reciprocal else 0, _p(out), B, D, ldo, _stream()),
+          "scale_cast_bf16")
+    return out
+
+
+def bank_step_ok(B, M, Dp, bank):
+    """True when bank_step serves this shape (the single-pass kernels: see spn_bank_step_ok)."""
+    return bool(lib().spn_bank_step_ok(B, M, Dp, 1 if isinstance(bank, Fp8Bank) else 0))
+
+
+def bank_step(q_bf16, bank_bf16, labels, inv_tau, grad_scale, save):
+    """Forward and backward of the bank loss for a bank held entirely by this process, label smoothing 0, in two launches
+    (spn_bank_step): -> (row_lse [B], row_loss [B], loss_mean [1], dq [B, Dp] fp32 = grad_scale * d(sum row_loss)/dq)."""
+    B, Dp = q_bf16.shape
+    M = bank_bf16.shape[0]
+    dev = q_bf16.device
+    fp8 = isinstance(bank_bf16, Fp8Bank)
+    data, scale = (bank_bf16.data, bank_bf16.scale) if fp8 else (bank_bf16, None)
+    if save is None or not save.is_cuda or save.numel() * save.element_size() < lib().spn_bank_logits_bytes(B, M):
+        raise ValueError("save: device scratch of spn_bank_logits_bytes(B, M) bytes (ops.bank_logits_buffer)")
+    lse = torch.empty(B, dtype=torch.float32, device=dev)
+    row = torch.empty(B, dtype=torch.float32, device=dev)
+    mean = torch.empty(1, dtype=torch.float32, device=dev)
+    dq = torch.empty(B, Dp, dtype=torch.float32, device=dev)
+    check(lib().spn_bank_step(_p(q_bf16), Dp, _p(data), _p(scale), _p(labels), B, M, Dp, inv_tau, grad_scale, _p(save), _p(lse),
+                              _p(row), _p(mean), _p(dq), _stream()), "bank_step")
+    return lse, row, mean, dq
+
+
 def bank_stats_fwd_tokmax(q_bf16, bank_tok_bf16, labels, inv_tau, t_begin=0):
     """Token-max bank (spn_bank_stats_fwd_tokmax): bank_tok_bf16 [n_targets, 32, Dp] bf16, labels = target ids."""
     B, Dp = q_bf16.shape

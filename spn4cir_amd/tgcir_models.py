@@ -426,10 +426,12 @@ class TgcirStage2Trainer:
     (spn4cir_amd.distributed.BankLossDP), both flat gradient buffers all-reduced, one fused AdamW launch per buffer
     (lr, betas (0.9, 0.999), eps 1e-7, torch's default weight decay - what optim.AdamW(param_groups) configures)."""
 
-    def __init__(self, model, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None, bank_mode="sharded",
+    def __init__(self, model, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None, bank_mode="auto",
                  label_smoothing=0.0, bucket_elems=8 << 20):
         from . import distributed as dp
         self.model, self.group = model, group
+        self._bank_mode_arg = bank_mode      # "auto": replicated below 10^6 bank rows (set_banks), as bench.py --bank-mode auto
+        bank_mode = "replicated" if bank_mode == "auto" else bank_mode
         self.text, self.head = model.text, model.head
         self.lr, self.betas, self.eps, self.wd, self.ls = lr, betas, eps, weight_decay, label_smoothing
         self.world, self.rank = dp._world(group)
@@ -449,6 +451,8 @@ class TgcirStage2Trainer:
         dev = self.text.device
         self.refer_bank = refer_bank.to(dev, torch.float32).contiguous()
         self._M_total = target_bank.shape[0]
+        if self._bank_mode_arg == "auto" and self.world > 1:
+            self.loss_dp.mode = "sharded" if self._M_total >= 1000000 else "replicated"
         if self.loss_dp.mode == "sharded" and self.world > 1:
             b, e = self._shard_range(self._M_total, self.world, self.rank)
             self._m_begin = b

@@ -451,6 +451,43 @@ def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=True, split_q=Tr
         assert rel_err(d0[:, :D], dq_ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
+@pytest.mark.parametrize("B,M,D,tau", [(32, 40000, 768, 0.02), (4, 500, 128, 0.01), (33, 1500, 640, 0.02), (1, 7, 128, 0.02),
+                                        (127, 9001, 1024, 0.05), (160, 40000, 768, 0.02), (32, 100000, 768, 0.02),
+                                        (128, 30000, 256, 0.03)])
+def test_bank_step_single_call(ops, B, M, D, tau, fp8):
+    """spn_bank_step (one pass over the bank + ONE tail launch) against the three-call path it replaces
+    (spn_bank_stats_fwd_save + spn_bank_loss_finalize + spn_bank_grad_q_saved): same dq to fp32 summation order, lse / row loss to
+    2e-5, and against the oracle on the same rounded operands; the mean is bit-reproducible from call to call."""
+    from oracle import bank_loss
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 7 * B + M)
+    q, qb, inv = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    bank_b = ops.prepare_bank(dev(bank), "fp8" if fp8 else "bf16")
+    Dp = qb.shape[1]
+    if not ops.bank_step_ok(B, M, Dp, bank_b):
+        pytest.skip("shape not served by the single-pass kernels")
+    lab = dev(labels)
+    save = ops.bank_logits_buffer(B, M, "cuda")
+    lse, row, mean, dq = ops.bank_step(qb, bank_b, lab, 1.0 / tau, 1.0 / B, save)
+    save2 = ops.bank_logits_buffer(B, M, "cuda")
+    stats = ops.bank_stats_fwd(qb, bank_b, lab, 1.0 / tau, save=save2)
+    lse3, row3, mean3 = ops.bank_loss_finalize(stats, M)
+    dq3 = ops.bank_grad_q(qb, bank_b, lab, 1.0 / tau, lse3, 1.0 / B, saved=save2)
+    assert (lse - lse3).abs().max() < 2e-5 and (row - row3).abs().max() < 2e-5
+    assert abs(mean.item() - mean3.item()) < 2e-5 * max(1.0, abs(mean3.item()))
+    assert rel_err(dq, dq3) < 1e-5
+    if not fp8:      # oracle on the operands the kernels see (the e4m3 kernels' operand model: test_bank_fused_single_pass)
+        qr, br = qb[:, :D].cpu().float(), bank_b[:, :D].cpu().float()
+        lse_ref, lab_ref, row_ref = bank_loss.infonce_stats(qr, br, labels, tau)
+        assert (lse.cpu().double() - lse_ref).abs().max() < 2e-4
+        assert abs(mean.item() - row_ref.mean().item()) < 2e-4
+        dq_ref = bank_loss.infonce_grad_q(qr, br, labels, tau)
+        assert rel_err(dq[:, :D], dq_ref) < 1.5e-2
+    # run-to-run: the ticketed mean and every output are bit-identical
+    lse_b, row_b, mean_b, dq_b = ops.bank_step(qb, bank_b, lab, 1.0 / tau, 1.0 / B, save)
+    assert torch.equal(mean, mean_b) and torch.equal(row, row_b) and torch.equal(dq, dq_b)
+
+
 @pytest.mark.parametrize("mode", [0, 2], ids=["gemm-pair", "fused"])
 @pytest.mark.parametrize("B,M,D,tau", [(256, 40000, 768, 0.02), (128, 3000, 256, 0.03), (264, 5001, 512, 0.02), (192, 5000, 768, 0.02),
                                         (512, 8000, 768, 0.02), (256, 3000, 1024, 0.05)])
