@@ -627,6 +627,9 @@ def main():
             "step_model_tflops": round(tps * FLOP_PER_TRIPLET / 1e12 / world, 1),
             "step_frac_of_bf16_peak": round(tps * FLOP_PER_TRIPLET / 1e12 / world / PEAK_BF16_TFLOPS, 4),
             "roofline": roof,
+            # every SPN_* variable the library saw when it was loaded (its A/B switches read that snapshot only): a stray
+            # one that changes a kernel is visible next to the number
+            "lib_config": _lib.config_dump(),
         }
         out.update(extra)
         if packed:

@@ -169,6 +169,9 @@ size_t spn_bank_logits_bytes(int B, int M);
  * Mode 1 exists only in the experiments build (make EXPERIMENTS=1 -> libspn4cir_hip_exp.so); the shipped library returns
  * SPN_ERR_ARG for it. */
 int spn_bank_config(int mode);
+/* Process-wide kernel selection of the GEMMs, for A/B runs and tests (same results either way): key 0 = the persistent
+ * multi-round NT kernel (value 1 on, 0 off, -1 back to the SPN_GEMM_PERSIST default).  SPN_ERR_ARG for an unknown key. */
+int spn_gemm_config(int key, int value);
 /* Every SPN_* environment variable is captured once, when the library is loaded; the kernels' A/B switches read that
  * snapshot only.  Writes a JSON object {"experiments_build": 0|1, "env": {"SPN_X": "value", ...}} (NUL-terminated, truncated
  * to cap) and returns the size needed.  No reference counterpart (the reference has no native code). */

@@ -84,6 +84,7 @@ _SIGS = {
     "spn_bank_logits_bytes": (sz, [i32, i32]),
     "spn_bank_config": (i32, [i32]),
     "spn_config_dump": (i32, [C.c_char_p, i32]),
+    "spn_gemm_config": (i32, [i32, i32]),
     "spn_bank_step_ok": (i32, [i32, i32, i32, i32]),
     "spn_fusion_bwd_phase": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "spn_scale_cast_bf16": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),

@@ -195,6 +195,11 @@ int spn_bank_grad_q(const void* q_bf16, int ldq, const void* bank_bf16, const in
 size_t spn_bank_logits_bytes(int B, int M) { return bank_saved_bytes_any(B, M); }
 int spn_bank_config(int mode) { return bank_config(mode); }
 
+int spn_gemm_config(int key, int value) {
+    if (key == 0) { gemm_nt_persist_set(value); return SPN_OK; }
+    return SPN_ERR_ARG;
+}
+
 int spn_bank_stats_fwd_save(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B,
                             int M, int D, int m_begin, float inv_tau, float* stats, float* logits_save, void* ws,
                             size_t ws_bytes, void* stream) {

@@ -782,35 +782,33 @@ __global__ __launch_bounds__(256) void bank_step_tail_kernel(const float* __rest
                                                             float* __restrict__ dq, int lddq, float* __restrict__ row_lse,
                                                             float* row_loss, float* __restrict__ loss_mean, int* counter) {
     __shared__ float red[16][16][5];
-    __shared__ float fm[4], fl[4], fz[4];
+    __shared__ float fm[1], fl[1], fz[1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cq = tid & 15, rl = tid >> 4;
     const int b = blockIdx.y, c = (blockIdx.x * 16 + cq) * 4;
     const size_t so = (size_t)B * D, ss = (size_t)B * 4;
     const float* st = sp + (size_t)b * 4;
-    // ---- statistics of query b over all chunks
-    float m = -INFINITY, l = 0.f, zlab = -INFINITY;
-    for (int i = tid; i < nch; i += 256) {
-        const f32x4 p = *(const f32x4*)(st + (size_t)i * ss);
-        const float mn = fmaxf(m, p[0]);
-        if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
-        m = mn;
-        zlab = fmaxf(zlab, p[3]);
-    }
-    {
+    // ---- statistics of query b over all chunks: wave 0 repeats bank_stats_fold_kernel's arithmetic (lanes stride 64, the same
+    // merge order) and bank_loss_finalize_kernel's single-shard lse, so that lse - hence every p and dq - is BIT-identical to
+    // the three-call path (a sharded data-parallel step then reproduces the single-process one as before)
+    if (w == 0) {
+        float m = -INFINITY, l = 0.f, zlab = -INFINITY;
+        for (int i = lane; i < nch; i += 64) {
+            const f32x4 p = *(const f32x4*)(st + (size_t)i * ss);
+            const float mn = fmaxf(m, p[0]);
+            if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+            m = mn;
+            zlab = fmaxf(zlab, p[3]);
+        }
         const float mw = wave_max(m);
         l = (m > -INFINITY) ? l * __expf(m - mw) : 0.f;
         l = wave_sum(l);
         zlab = wave_max(zlab);
-        if (lane == 0) { fm[w] = mw; fl[w] = l; fz[w] = zlab; }
+        if (lane == 0) { fm[0] = mw; fl[0] = l; fz[0] = zlab; }
     }
     __syncthreads();
-    const float mx = fmaxf(fmaxf(fm[0], fm[1]), fmaxf(fm[2], fm[3]));
-    float lt = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) lt += (fm[k] > -INFINITY) ? fl[k] * __expf(fm[k] - mx) : 0.f;
-    const float ls = mx + logf(lt);
-    const float z = fmaxf(fmaxf(fz[0], fz[1]), fmaxf(fz[2], fz[3]));
+    const float ls = fm[0] + logf(fl[0]);
+    const float z = fz[0];
     // ---- dq[b, 64 columns] = alpha (sum_c exp(m_c - lse) O_c - (1 - p_label) bank[label])
     f32x4 s = {0, 0, 0, 0};
     const bool in = c < D;
@@ -1127,9 +1125,12 @@ static constexpr int fp8f_stages() {
     return s > 5 ? 5 : (s < 2 ? 2 : s);
 }
 
-template <int D>
+// GT = number of e5m2 terms that carry G: 3 (~2^-9, a bf16 G) or 2 (6 significant bits: 2^-7, still 8x finer than the e4m3
+// bank values G multiplies; 24 of a tile's 120 MFMAs per wave and a third of the term arithmetic less - SPN_BANK_FP8_GTERMS)
+template <int D, int GT>
 __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, BankChunking ck, float* __restrict__ Op,
                                                                float* __restrict__ sp) {
+    static_assert(GT == 2 || GT == 3, "G terms");
     constexpr int DW = D / 4, KSW = DW / 32, NDT = DW / 16, RAW_B = TR * D;
     constexpr int S = fp8f_stages<D>(), NDMA = D / 128;
     static_assert(S >= 2 && (S - 1) * NDMA <= 63 && D % 128 == 0, "bank width");
@@ -1334,15 +1335,17 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
             g1 = (uint32_t)p1;
             lo = __builtin_amdgcn_cvt_pk_f32_bf8(p1, false); hi = __builtin_amdgcn_cvt_pk_f32_bf8(p1, true);
             r0 -= lo[0]; r1 -= lo[1]; r2 -= hi[0]; r3 -= hi[1];
-            int p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, 0, false);
-            p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r2, r3, p2, true);
-            g2 = (uint32_t)p2;
+            if constexpr (GT == 3) {
+                int p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r0, r1, 0, false);
+                p2 = __builtin_amdgcn_cvt_pk_bf8_f32(r2, r3, p2, true);
+                g2 = (uint32_t)p2;
+            }
         }
         {
             const int go = (mt_o * 16 + (lane & 15)) * TR + nt_o * 16 + (lane >> 4) * 4;
             *(uint32_t*)(G8 + go) = g0;
             *(uint32_t*)(G8 + BQ * TR + go) = g1;
-            *(uint32_t*)(G8 + 2 * BQ * TR + go) = g2;
+            if constexpr (GT == 3) *(uint32_t*)(G8 + 2 * BQ * TR + go) = g2;
         }
         if (nt_o == 0 && lane < 16) As[mt_o * 16 + lane] = alpha;
         lds_barrier();
@@ -1354,9 +1357,9 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
             }
         }
         // ---- dq[q][d] += sum_key G[q][key] raw[key][d]:  D[i = d][j = query], k = key (one 32-step, three bf8 terms)
-        long gf[3][2];
+        long gf[GT][2];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < GT; ++pl)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 gf[pl][mt] = *(const long*)(G8 + pl * BQ * TR + (mt * 16 + (lane & 15)) * TR + (lane >> 4) * 8);
@@ -1367,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
         {
             v2i av[NDT];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) { lds_tie(gf[pl][0]); lds_tie(gf[pl][1]); }   // G fragments are in before the asm reads
+            for (int pl = 0; pl < GT; ++pl) { lds_tie(gf[pl][0]); lds_tie(gf[pl][1]); }   // G fragments are in before the asm reads
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 const int c = (w * DW + dt * 16) >> 4;
@@ -1382,7 +1385,7 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
         }
         // term-major: the three products into one accumulator are 2 NDT MFMAs apart, never back to back
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < GT; ++pl)
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -1425,10 +1428,19 @@ __global__ __launch_bounds__(256, 2) void bank_fp8_fused_kernel(BankArgs a, Bank
     if (blockIdx.x == 0 && tid == 0) *(int*)(sp + (size_t)ck.nchunks * a.B * 4) = 0;   // bank_step_tail_kernel's arrival counter
 }
 
-template <int D>
-static int launch_bank_fp8_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
+// SPN_BANK_FP8_GTERMS=3: G of the all-fp8 fused pass as three e5m2 terms (round 3's form); default 2
+static int fp8_gterms() {
+    static const int n = [] {
+        const char* e = spn_env("SPN_BANK_FP8_GTERMS");
+        return (e && e[0] == '3') ? 3 : 2;
+    }();
+    return n;
+}
+
+template <int D, int GT>
+static int launch_bank_fp8_fused_t(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
     const size_t lds = (size_t)fp8f_stages<D>() * TR * D + 4 * 4096 + 4 * BQ * 4 + FP8_MAX_CHUNK_ROWS * 4 + 3 * BQ * TR + BQ * 4;
-    auto kern = bank_fp8_fused_kernel<D>;
+    auto kern = bank_fp8_fused_kernel<D, GT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1442,6 +1454,11 @@ static int launch_bank_fp8_fused(const BankArgs& a, const BankChunking& c, float
     }
     SPN_CHECK_LAUNCH();
     return SPN_OK;
+}
+
+template <int D>
+static int launch_bank_fp8_fused(const BankArgs& a, const BankChunking& c, float* Op, float* sp, hipStream_t st) {
+    return fp8_gterms() == 3 ? launch_bank_fp8_fused_t<D, 3>(a, c, Op, sp, st) : launch_bank_fp8_fused_t<D, 2>(a, c, Op, sp, st);
 }
 
 // SPN_BANK_FP8_MFMA=0 keeps the forward pass of an fp8 bank on the dequantise-to-bf16 path (A/B switch)

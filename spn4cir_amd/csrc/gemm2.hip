@@ -813,6 +813,303 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     return SPN_OK;
 }
 
+// ----------------------------------------------------------------------------------- NT, persistent
+// gemm_nt2p: the 8-slot staggered schedule of gemm_nt2_kernel<.., SCHED 2> as ONE workgroup per CU that walks several output
+// tiles, with the operand stream running ACROSS tile boundaries: the k tiles of a workgroup's tiles form one sequence g = 0,
+// 1, 2 ... (LDS stage g & 1), and the chunk issues "k tile + 1" / "k tile + 2" of the last k tiles of a tile already fetch
+// the first k tiles of the NEXT tile - when the epilogue of tile i ends, k tile 0 of tile i + 1 is in LDS (all four chunks)
+// and the workgroup enters its main loop without the 2.0-2.6 k cycle prologue (first DMA + L2 / HBM latency) every
+// non-persistent workgroup pays, and without a dispatch in between.  Only multi-round launches take it (more tiles than
+// CUs: the qkv projection 693, fc / d-activation 924 tiles); a single-round launch has nothing to hide.
+// LDS: the two 64 KB stages only.  At the end of a tile stage (g + 1) & 1 holds the next tile's k tile 0; the issue of the
+// next tile's k tile 1 (chunks c0, c1, normally slots 2, 3 of the last k tile) is HELD BACK until the epilogue is done, so
+// that the stage of the tile's last k tile is free for the accumulator staging: four passes of 64 rows (32 from each M half
+// - all eight waves write in every pass, 8 ds_write_b128 each) instead of two passes of 128.
+// vmcnt: the epilogue's loads and stores sit in the same in-order counter as the DMA; they are older than every DMA of the
+// next tile, so the counted waits of the loop stay valid (they only get more conservative) - and k tile 0 of a non-first
+// tile needs none: everything it reads landed before the epilogue (vmcnt(0) in slot 3 of the last k tile).
+template <int MODE, int ACT, bool OUT_F32, bool OUT_BF16, bool AUX_OUT>
+__device__ __forceinline__ void nt_epilogue_p(f32x16 (&acc)[4][2], char* sbuf, int m0, int n0, int wr, int wc, int wid, int lane,
+                                              const GemmEpilogue& ep) {
+    constexpr int BN = 256, NW = 8, LPR = 32, RPI = 2, ITERS = 4;      // 64 staging rows per pass = 4 x (8 waves x 2 rows)
+    float* sC = (float*)sbuf;
+    const int u = lane % LPR, n = n0 + u * 8;
+    f32x4 bias_lo = {0, 0, 0, 0}, bias_hi = {0, 0, 0, 0};
+    if (ep.bias) {
+        bias_lo = *(const f32x4*)(ep.bias + n);
+        bias_hi = *(const f32x4*)(ep.bias + n + 4);
+    }
+    const float alpha = ep.alpha;
+    const int srow_l = wid * RPI + lane / LPR;                         // staging row of this lane, + it * 16
+    auto pack8 = [](f32x4 x, f32x4 y) {
+        bf16x8 pk = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3]), f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+        return pk;
+    };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // staging row sr of pass p is tile row (sr < 32 ? 0 : 128) + 32 p + (sr & 31)
+        size_t obase[ITERS];
+        [[maybe_unused]] bf16x8 pf_aux[ITERS];
+        [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int sr = srow_l + it * NW * RPI;
+            const int m = m0 + (sr & 32) * 4 + p * 32 + (sr & 31);
+            obase[it] = (size_t)m * ep.ldc + n;
+            if constexpr (MODE == GEMM_DACT) pf_aux[it] = *(const bf16x8*)(ep.aux_in + obase[it]);
+            if constexpr (MODE == GEMM_RESID) {
+                const float* rp = ep.resid + (size_t)m * ep.ldr + n;
+                pf_r0[it] = *(const f32x4*)rp;
+                pf_r1[it] = *(const f32x4*)(rp + 4);
+            }
+        }
+        __syncthreads();                       // the stage (p = 0) / the previous pass is no longer read
+        {
+            const int sr = wr * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int unit = (wc * 64 + j * 32 + 8 * g) / 4 + (lane >> 5);
+                    const f32x4 v = {acc[p][j][4 * g], acc[p][j][4 * g + 1], acc[p][j][4 * g + 2], acc[p][j][4 * g + 3]};
+                    *(f32x4*)(sC + sr * BN + (stage_slot<BN>(unit, sr) << 2)) = v;
+                }
+        }
+        __syncthreads();
+        f32x4 t0[ITERS], t1[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int rr = srow_l + it * NW * RPI;
+            t0[it] = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u, rr) << 2));
+            t1[it] = *(const f32x4*)(sC + rr * BN + (stage_slot<BN>(2 * u + 1, rr) << 2));
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            f32x4 v0 = t0[it] * alpha + bias_lo, v1 = t1[it] * alpha + bias_hi;
+            const size_t o = obase[it];
+            if constexpr (MODE == GEMM_STORE && ACT != ACT_NONE) {
+                if constexpr (AUX_OUT) {
+                    if (ep.aux_grad) {                            // block-uniform
+                        f32x4 g0, g1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            act_and_grad_into(ACT, v0[e], v0[e], g0[e]);
+                            act_and_grad_into(ACT, v1[e], v1[e], g1[e]);
+                        }
+                        *(bf16x8*)(ep.aux_out + o) = pack8(g0, g1);
+                    } else {
+                        *(bf16x8*)(ep.aux_out + o) = pack8(v0, v1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                            v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
+                        v1[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v1[e]) : gelu_erf_f(v1[e]);
+                    }
+                }
+            } else if constexpr (MODE == GEMM_RESID) {
+                v0 += pf_r0[it];
+                v1 += pf_r1[it];
+            } else if constexpr (MODE == GEMM_DACT) {
+                const bf16x8 pa = pf_aux[it];
+                if (ep.aux_grad) {                                // block-uniform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] *= bf2f(pa[e]); v1[e] *= bf2f(pa[4 + e]); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = bf2f(pa[e]), x1 = bf2f(pa[4 + e]);
+                        v0[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x0) : gelu_erf_grad_f(x0);
+                        v1[e] *= ACT == ACT_QUICKGELU ? quick_gelu_grad_f(x1) : gelu_erf_grad_f(x1);
+                    }
+                }
+            }
+            if constexpr (OUT_F32) {
+                *(f32x4*)(ep.out_f32 + o) = v0;
+                *(f32x4*)(ep.out_f32 + o + 4) = v1;
+            }
+            if constexpr (OUT_BF16) *(bf16x8*)(ep.out_bf16 + o) = pack8(v0, v1);
+        }
+    }
+    __syncthreads();                           // the staging rows are read: the stage may take DMA again
+}
+
+template <int MODE, int ACT, bool OUT_F32, bool OUT_BF16, bool AUX_OUT>
+__global__ __launch_bounds__(512, 2) void gemm_nt2p_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, int M, int N,
+                                                          int K, int lda, int ldb, GemmEpilogue ep, int ntiles) {
+    constexpr int BKT = 64, A_BYTES = 256 * BKT * 2, STAGE = 2 * A_BYTES, TM = 128, TN = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int tiles_n = N / 256, nk = K / BKT;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
+    // tile sequence of this workgroup: full rounds take tile  r G + xcd_remap(b, G)  (the workgroups of an XCD share operand
+    // panels in its L2), the last, partial round is spread over all XCDs: workgroups b < rem take  full G + xcd_remap(b, rem)
+    const int G = gridDim.x, full = ntiles / G, rem = ntiles - full * G;
+    auto tile_of = [&](int r) -> int {
+        if (r < full) return r * G + xcd_remap(blockIdx.x, G);
+        if (r == full && (int)blockIdx.x < rem) return full * G + xcd_remap(blockIdx.x, rem);
+        return -1;
+    };
+    // stage chunk c (16 KB: the rows one slot reads, gemm_nt2_kernel) of the k tile at k0 of tile (m0, n0) into stage buffer sb
+    auto chunk = [&](int c, int m0, int n0, int k0, char* sb, int lane) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = wid * 2 + t;
+            int row0;
+            if (c == 0 || c == 3) row0 = (i < 8 ? 0 : 128) + (c == 3 ? 64 : 0) + (i & 7) * 8;
+            else row0 = (i >> 2) * 64 + (c == 2 ? 32 : 0) + (i & 3) * 8;
+            const int r = row0 + (lane >> 3);
+            const int cc = nt2_swz<BKT>(r, lane & 7);
+            if (c == 0 || c == 3)
+                glds16(rsA, sb + row0 * 128, ((uint32_t)(m0 + r) * (uint32_t)lda + (uint32_t)(k0 + cc * 8)) * 2u);
+            else
+                glds16(rsB, sb + A_BYTES + row0 * 128, ((uint32_t)(n0 + r) * (uint32_t)ldb + (uint32_t)(k0 + cc * 8)) * 2u);
+        }
+    };
+    int t_cur = tile_of(0);
+    int m0 = (t_cur / tiles_n) * 256, n0 = (t_cur % tiles_n) * 256;
+    int par = 0;                               // LDS stage of the current k tile
+    chunk(0, m0, n0, 0, smem, lane0); chunk(1, m0, n0, 0, smem, lane0); chunk(2, m0, n0, 0, smem, lane0); chunk(3, m0, n0, 0, smem, lane0);
+    chunk(0, m0, n0, BKT, smem + STAGE, lane0); chunk(1, m0, n0, BKT, smem + STAGE, lane0);
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    for (int r = 0;; ++r) {
+        const int t_next = tile_of(r + 1);
+        const bool has_next = t_next >= 0;
+        const int m0n = has_next ? (t_next / tiles_n) * 256 : 0, n0n = has_next ? (t_next % tiles_n) * 256 : 0;
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));         // opaque per tile: keeps the lane-dependent addresses out of the tile loop's preheader
+        const int arow = wr * TM + (lane & 31), brow = wc * TN + (lane & 31), cl = lane >> 5;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+        if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger the lower half by one barrier
+        bf16x8 a[2][4], b0[4], b1[4];
+#define SPN_PSLOT_MFMA(I0, J, BREG)                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+        asm volatile("" : "+v"(BREG[0]), "+v"(BREG[1]), "+v"(BREG[2]), "+v"(BREG[3]));                  \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                              \
+            acc[I0][J] = mfma32(BREG[kk], a[0][kk], acc[I0][J]);                                        \
+            acc[I0 + 1][J] = mfma32(BREG[kk], a[1][kk], acc[I0 + 1][J]);                                \
+        }                                                                                               \
+        asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]));                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        __builtin_amdgcn_s_barrier();                                                                   \
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* sA = smem + par * STAGE;
+            const char* sB = sA + A_BYTES;
+            char* s1 = smem + (par ^ 1) * STAGE;       // stage of the k tile after this one
+            char* s2 = smem + par * STAGE;             // ... and of the one after that (this stage again)
+            const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+            const bool v1 = in1 || has_next;                                   // a k tile follows (this tile's or the next tile's first)
+            const bool v2 = in2 || (kt + 2 == nk && has_next);                 // the next tile's k tile 1 waits for the epilogue
+            const int m1 = in1 ? m0 : m0n, n1 = in1 ? n0 : n0n, k1 = in1 ? (kt + 1) * BKT : 0;
+            const int m2 = in2 ? m0 : m0n, n2 = in2 ? n0 : n0n, k2 = in2 ? (kt + 2) * BKT : 0;
+            const bool skipw = kt == 0 && r > 0;       // everything k tile 0 of a later tile reads landed before the epilogue
+            // slot 0
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b0[kk] = nt2_frag<BKT>(sB, brow, kk * 2 + cl);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a[0][kk] = nt2_frag<BKT>(sA, arow, kk * 2 + cl);
+                a[1][kk] = nt2_frag<BKT>(sA, arow + 32, kk * 2 + cl);
+            }
+            if (v1) chunk(2, m1, n1, k1, s1, lane);
+            if (!skipw) { if (v1) wait_vmcnt<8>(); else wait_vmcnt<0>(); }      // c2 of this k tile, read in slot 1
+            SPN_PSLOT_MFMA(0, 0, b0)
+            // slot 1
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b1[kk] = nt2_frag<BKT>(sB, brow + 32, kk * 2 + cl);
+            if (v1) chunk(3, m1, n1, k1, s1, lane);
+            if (!skipw) { if (v1) wait_vmcnt<8>(); else wait_vmcnt<0>(); }      // c3 of this k tile, read in slot 2
+            SPN_PSLOT_MFMA(0, 1, b1)
+            // slot 2
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                a[0][kk] = nt2_frag<BKT>(sA, arow + 64, kk * 2 + cl);
+                a[1][kk] = nt2_frag<BKT>(sA, arow + 96, kk * 2 + cl);
+            }
+            if (v2) chunk(0, m2, n2, k2, s2, lane);
+            SPN_PSLOT_MFMA(2, 1, b1)
+            // slot 3
+            if (v2) chunk(1, m2, n2, k2, s2, lane);
+            if (v1) { if (v2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }          // c0, c1 of the following k tile, read in its slot 0
+            SPN_PSLOT_MFMA(2, 0, b0)
+            par ^= 1;
+        }
+#undef SPN_PSLOT_MFMA
+        if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two halves
+        // `par` now names the stage of the next tile's k tile 0; the other one (this tile's last k tile) stages the epilogue
+        nt_epilogue_p<MODE, ACT, OUT_F32, OUT_BF16, AUX_OUT>(acc, smem + (par ^ 1) * STAGE, m0, n0, wr, wc, wid, lane, ep);
+        if (!has_next) break;
+        m0 = m0n; n0 = n0n;
+        chunk(0, m0, n0, BKT, smem + (par ^ 1) * STAGE, lane);        // the held-back first half of the new tile's k tile 1
+        chunk(1, m0, n0, BKT, smem + (par ^ 1) * STAGE, lane);
+    }
+}
+
+template <int MODE, int ACT, bool OUT_F32, bool OUT_BF16, bool AUX_OUT>
+static int launch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, const GemmEpilogue& ep,
+                       hipStream_t st) {
+    constexpr int LDS = 131072;
+    auto kern = gemm_nt2p_kernel<MODE, ACT, OUT_F32, OUT_BF16, AUX_OUT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = (M / 256) * (N / 256), cus = device_cu_count();
+    hipLaunchKernelGGL(kern, dim3(tiles < cus ? tiles : cus), dim3(512), LDS, st, A, B, M, N, K, lda, ldb, ep, tiles);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// SPN_GEMM_PERSIST=0 keeps every NT product on the one-tile-per-workgroup kernel (A/B switch)
+static int g_nt_persist = -1;                  // spn_gemm_config(0, v): -1 = the environment default, 0 = off, 1 = on
+void gemm_nt_persist_set(int v) { g_nt_persist = v < 0 ? -1 : (v ? 1 : 0); }
+static bool nt_persist_on() {
+    static const bool v = [] {
+        const char* e = spn_env("SPN_GEMM_PERSIST");
+        return !(e && e[0] == '0');
+    }();
+    return g_nt_persist < 0 ? v : g_nt_persist != 0;
+}
+
+// the persistent kernel takes multi-round products of full tiles with the epilogues the towers use; returns false otherwise
+static bool dispatch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode, const GemmEpilogue& ep,
+                          hipStream_t st, int* rc) {
+    if (!nt_persist_on() || M % 256 || N % 256 || K < 128 || ep.direct_store || ep.ldc % 8) return false;
+    const int tiles = (M / 256) * (N / 256);
+    if (tiles <= device_cu_count()) return false;
+    const bool b16 = ep.out_bf16 && !ep.out_f32, f32o = ep.out_f32 && !ep.out_bf16;
+#define SPN_NT2P(MODE_, ACT_, F_, B_, A_) (*rc = launch_nt2p<MODE_, ACT_, F_, B_, A_>(A, B, M, N, K, lda, ldb, ep, st), true)
+    if (mode == GEMM_STORE && ep.act == ACT_NONE && b16) return SPN_NT2P(GEMM_STORE, ACT_NONE, false, true, false);
+    if (mode == GEMM_STORE && ep.act == ACT_NONE && f32o) return SPN_NT2P(GEMM_STORE, ACT_NONE, true, false, false);
+    if (mode == GEMM_STORE && ep.act == ACT_QUICKGELU && b16 && ep.aux_out) return SPN_NT2P(GEMM_STORE, ACT_QUICKGELU, false, true, true);
+    if (mode == GEMM_STORE && ep.act == ACT_GELU_ERF && b16 && ep.aux_out) return SPN_NT2P(GEMM_STORE, ACT_GELU_ERF, false, true, true);
+    if (mode == GEMM_DACT && ep.act == ACT_QUICKGELU && b16 && ep.aux_in) return SPN_NT2P(GEMM_DACT, ACT_QUICKGELU, false, true, false);
+    if (mode == GEMM_DACT && ep.act == ACT_GELU_ERF && b16 && ep.aux_in) return SPN_NT2P(GEMM_DACT, ACT_GELU_ERF, false, true, false);
+    if (mode == GEMM_RESID && f32o && ep.resid && ep.ldr % 4 == 0) return SPN_NT2P(GEMM_RESID, ACT_NONE, true, false, false);
+#undef SPN_NT2P
+    return false;
+}
+
 #ifdef SPN_EXPERIMENTS   // the hand-scheduled 4-wave kernel: measured slower in the step, not in the shipped library
 // Epilogue of gemm_nt3: FULL 256x256 tiles only (the launcher routes anything else to gemm_nt2), straight-line code, and
 // wave-private: wave (wr, wc) owns the 128x128 sub-tile rows wr*128.., columns wc*128.. and turns it row-major through
@@ -1188,7 +1485,11 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
 #endif
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
-            if (nt_phased()) return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
+            if (nt_phased()) {
+                int rc = SPN_OK;
+                if (dispatch_nt2p(A, B, M, N, K, lda, ldb, mode, e2, st, &rc)) return rc;      // multi-round: persistent walk
+                return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
+            }
             return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 6: return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);   // 8-slot staggered
         default: return dispatch_nt2<256, 256, 4, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);

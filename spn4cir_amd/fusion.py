@@ -108,8 +108,8 @@ class FusionEncoder:
             self._stale = False
             self._seen_version = self.params._version
         if self._key != (B, L, S):
-            self._acts = torch.empty(lib().spn_fusion_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-            self._ws = torch.empty(lib().spn_fusion_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self._acts = ops.scratch_bytes(lib().spn_fusion_act_bytes(C.byref(cfg)), self.device)
+            self._ws = ops.scratch_bytes(lib().spn_fusion_ws_bytes(C.byref(cfg)), self.device)
             self._key = (B, L, S)
         ids = ids.to(self.device, torch.int32).contiguous()
         mask = None if mask is None else mask.to(self.device, torch.int32).contiguous()

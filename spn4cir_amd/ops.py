@@ -30,12 +30,25 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_POISON = os.environ.get("SPN_DEBUG_POISON") == "1"
+
+
+def scratch_bytes(nbytes, device):
+    """Uninitialised device scratch (uint8).  SPN_DEBUG_POISON=1 fills every such allocation with 0xFF bytes - NaN as fp32
+    and as bf16 - so that a kernel that reads scratch it never wrote shows up as NaN in its output instead of as
+    allocator-dependent noise (tests/test_poison_gpu.py runs the training steps that way)."""
+    buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    if _POISON:
+        buf.fill_(255)
+    return buf
+
+
 def workspace(nbytes, device, slot="default"):
     """Grow-only scratch buffer per (device, slot); ops on one stream use it sequentially."""
     key = (str(device), slot)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        buf = scratch_bytes(max(int(nbytes), 256), device)
         _ws_cache[key] = buf
     return buf
 
@@ -317,7 +330,7 @@ def bank_logits_buffer(B, M, device):
     n = lib().spn_bank_logits_bytes(B, M)
     if n > BANK_LOGITS_MAX_BYTES:
         return None
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    return scratch_bytes(n, device)
 
 
 def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0, save=None):

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, lib
 from .ops import _p, _stream
 
@@ -110,15 +110,19 @@ class TextTower:
 
     # ------------------------------------------------------------------ compute
     def _buffers(self, B, L, need_ws, T=0):
-        cfg = self._cfg(B, L)      # arenas are sized for the dense layout, which bounds every packed one
-        if self._acts_key != (B, L):
-            self._acts = None
-            self._acts = torch.empty(lib().spn_text_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-            self._acts_key = (B, L)
-            self._ws = None
+        """Activation arena and backward workspace, sized ONCE per batch capacity for the full context length (the dense
+        [B, L_ctx] layout bounds every shorter or packed one): the packed callers cut the id matrix behind the longest
+        caption, so L changes from batch to batch - keying the arenas on (B, L) dropped and re-allocated 6 + 3 GB at
+        ViT-L/14, B = 256 whenever the length bucket moved.  They grow only when B does."""
+        if self._acts_key is None or B > self._acts_key:
+            self._acts = self._ws = None
+            cap = self._cfg(B, self.ctx)
+            self._acts = ops.scratch_bytes(lib().spn_text_act_bytes(C.byref(cap)), self.device)
+            self._acts_key = B
         if need_ws and self._ws is None:
-            self._ws = torch.empty(lib().spn_text_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-        return self._cfg(B, L, T) if T else cfg
+            cap = self._cfg(self._acts_key, self.ctx)
+            self._ws = ops.scratch_bytes(lib().spn_text_ws_bytes(C.byref(cap)), self.device)
+        return self._cfg(B, L, T)
 
     @staticmethod
     def cu_seqlens(ids_host):
@@ -173,7 +177,7 @@ class TextTower:
         B, L = ids.shape
         cfg = self._cfg(B, L)
         need = lib().spn_text_exact_ws_bytes(C.byref(cfg))
-        ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = ops.scratch_bytes(need, self.device)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         check(lib().spn_text_fwd_exact(C.byref(cfg), _p(self.params), _p(ids), _p(ws), ws.numel(), _p(feats), _stream()),
               "text_fwd_exact")

@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, lib
 from .ops import _p, _stream
 from .text_tower import _BLOCK_KEYS
@@ -122,7 +122,7 @@ class VisionTower:
         image = image.to(self.device, torch.float32).contiguous()
         B = image.shape[0]
         cfg = self._cfg(B)
-        ws = torch.empty(lib().spn_vision_exact_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+        ws = ops.scratch_bytes(lib().spn_vision_exact_ws_bytes(C.byref(cfg)), self.device)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         check(lib().spn_vision_fwd_exact(C.byref(cfg), _p(self.params), _p(image), _p(ws), ws.numel(), _p(feats), _stream()),
               "vision_fwd_exact")
@@ -140,8 +140,8 @@ class VisionTower:
         self._refresh(cfg)
         if self._train_B != B:
             self._acts = self._bws = None
-            self._acts = torch.empty(lib().spn_vision_train_act_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-            self._bws = torch.empty(lib().spn_vision_bwd_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self._acts = ops.scratch_bytes(lib().spn_vision_train_act_bytes(C.byref(cfg)), self.device)
+            self._bws = ops.scratch_bytes(lib().spn_vision_bwd_ws_bytes(C.byref(cfg)), self.device)
             self._train_B = B
         if self.grads is None:
             self.grads = torch.zeros_like(self.params)
@@ -177,7 +177,7 @@ class VisionTower:
         self._refresh(cfg)
         need = lib().spn_vision_ws_bytes(C.byref(cfg))
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = ops.scratch_bytes(need, self.device)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         tokens = None
         if return_tokens:

@@ -101,8 +101,14 @@ def test_packed_matches_dense_at_full_size():
 
 
 def _fusion_sd(layers, W, I, E, Dp, vocab, max_pos, seed):
-    """BertModel(add_cross_attention) + text_proj state-dict with med.py's key names; init as BertPreTrainedModel (normal
-    0.02) scaled up on the attention / FFN matrices so that attention is not uniform; non-trivial LayerNorm affine."""
+    """BertModel(add_cross_attention) + text_proj state-dict with med.py's key names: BertPreTrainedModel's normal init scaled
+    up on the query / key / value / intermediate matrices so that attention is not uniform, non-trivial LayerNorm affine, and
+    SMALL residual-branch outputs (attention / cross-attention / FFN output.dense at std 0.01).  The last point keeps the
+    12-layer post-LN stack from rank-collapsing: with all matrices at std 0.04 the mean pairwise cosine between the positions'
+    hidden states grows 0.20, 0.45, 0.67, ... 0.9996, 0.9998 over the layers (every position carries the same vector at the
+    top: the near-uniform cross-attention over 577 random image tokens adds one common vector per layer), the query / key
+    gradients of the top layers are then the remainder of a cancelling sum and no bf16 attention backward reproduces them to
+    better than ~0.2; with this init it ends at 0.47 and every tensor is held to the same gate."""
     g = torch.Generator().manual_seed(seed)
     r = lambda *s, std=0.02: torch.randn(*s, generator=g) * std
     sd = {"embeddings.word_embeddings.weight": r(vocab, W), "embeddings.position_embeddings.weight": r(max_pos, W),
@@ -113,13 +119,29 @@ def _fusion_sd(layers, W, I, E, Dp, vocab, max_pos, seed):
             sd[p + a + ".self.query.weight"] = r(W, W, std=0.04); sd[p + a + ".self.query.bias"] = r(W, std=0.05)
             sd[p + a + ".self.key.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.key.bias"] = r(W, std=0.05)
             sd[p + a + ".self.value.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.value.bias"] = r(W, std=0.05)
-            sd[p + a + ".output.dense.weight"] = r(W, W, std=0.04); sd[p + a + ".output.dense.bias"] = r(W, std=0.05)
+            sd[p + a + ".output.dense.weight"] = r(W, W, std=0.01); sd[p + a + ".output.dense.bias"] = r(W, std=0.05)
             sd[p + a + ".output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + a + ".output.LayerNorm.bias"] = r(W, std=0.05)
         sd[p + "intermediate.dense.weight"] = r(I, W, std=0.04); sd[p + "intermediate.dense.bias"] = r(I, std=0.05)
-        sd[p + "output.dense.weight"] = r(W, I, std=0.04); sd[p + "output.dense.bias"] = r(W, std=0.05)
+        sd[p + "output.dense.weight"] = r(W, I, std=0.01); sd[p + "output.dense.bias"] = r(W, std=0.05)
         sd[p + "output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + "output.LayerNorm.bias"] = r(W, std=0.05)
     sd["text_proj.weight"] = r(Dp, W, std=0.05); sd["text_proj.bias"] = r(Dp, std=0.05)
     return sd
+
+
+def test_fusion_init_is_not_rank_collapsed():
+    """The claim the gradient gates of test_blip_fusion_full_shape rest on, checked on the oracle (CPU, 12 x 768): the mean
+    pairwise cosine between the positions' hidden states after the last layer stays far from 1 with _fusion_sd's init."""
+    from oracle import bert_fusion
+    W, layers, I, Dp, vocab, max_pos = 768, 12, 3072, 256, 30524, 512
+    sd = _fusion_sd(layers, W, I, 768, Dp, vocab, max_pos, seed=0)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1000, 30522, (2, 32), generator=g, dtype=torch.int32)
+    ids[:, 0] = 30523
+    with torch.no_grad():
+        h = bert_fusion.fusion_forward(sd, ids, torch.ones(2, 32, dtype=torch.int32), torch.randn(2, 577, 768, generator=g))
+    hn = torch.nn.functional.normalize(h[0], dim=-1)
+    mean_cos = ((hn @ hn.t()).sum() - 32) / (32 * 31)
+    assert mean_cos < 0.7, mean_cos
 
 
 @pytest.mark.parametrize("enc_width", [768, 1024])
@@ -191,7 +213,7 @@ def test_blip_fusion_full_shape(enc_width):
     dq = ops.bank_grad_q(qb, bank_b, labels[:b].cuda(), 1.0 / tau, lse, 1.0 / b)[:, :Dp].contiguous()
     grads = enc_model.backward(ops.combine_l2norm_bwd(q, inv, dq))
     views = enc_model.named_views(grads)
-    bad = {}
+    bad, worst = {}, (0.0, None)
     for k, p in params.items():
         ref = p.grad
         if k == "embeddings.position_embeddings.weight":
@@ -205,19 +227,10 @@ def test_blip_fusion_full_shape(enc_width):
             assert got.norm() < 1e-2 * vref and ref.norm() < 1e-2 * vref, k
             continue
         e = _rel(got, ref)
-        gate = 5e-2
-        if ".self.query." in k or ".self.key." in k:
-            # A randomly initialised 12-layer post-LN encoder is rank-collapsed near its top (all positions carry almost the
-            # same hidden state), so the score gradient dS = P (dP - delta) of the last layers multiplies nearly identical
-            # key / query rows and the true dQ / dK are the small remainder of a cancelling sum (sum_j dS_j = 0); the bf16
-            # rounding of dS in front of the MFMA (2^-9 per element, as in any bf16 attention backward) is then a visible
-            # fraction of it.  With only B = 8 [ENC] rows feeding the loss nothing averages it out: measured 0.18-0.29 on
-            # layers 10-11, < 5e-2 below.  The direction must still be right.
-            gate = 0.35
-            cosv = torch.nn.functional.cosine_similarity(got.double().flatten(), ref.double().flatten(), dim=0).item()
-            assert cosv > 0.93, (k, cosv)
-        if not e < gate:
+        worst = max(worst, (e, k))
+        if not e < 5e-2:
             bad[k] = e
+    print(f"blip fusion enc_width {enc_width}: worst gradient error {worst[0]:.3e} ({worst[1]})")
     assert not bad, bad
 
 
@@ -258,3 +271,52 @@ def test_fp8_bank_trainer_step_100k():
         ooptim.adamw_step(p, views[k].cpu(), torch.zeros_like(p), torch.zeros_like(p), 1, lr)
         moved = (p - sd[k]).norm()
         assert moved > 0 and (model.tower.named_views()[k].cpu() - p).norm() < 1e-3 * moved, k
+
+
+def test_config1_vitb32_inbatch_step_every_gradient():
+    """BASELINE config 1 at its real size (clip4cir/train.py --wo_bank -> models.py:151-167): CLIP ViT-B/32 - text 512 x 12 x 8
+    heads, vision 768 x 12 x 12 heads, patch 32, 224 x 224 images (50 tokens), D = 512 - B = 4, in-batch negatives, both towers
+    trainable.  Loss and EVERY parameter gradient (spn_vision_bwd + spn_text_bwd through CIRPlus(wo_bank=True).forward /
+    autograd) against the oracle's autograd on the same seeded weights and images.  The small-fixture test
+    (test_model_gpu.py::test_config1_inbatch_step_matches_reference) pins the same path to the reference's own capture."""
+    _need_gpu()
+    from oracle import bank_loss, clip_text, clip_vision
+    from spn4cir_amd import synthetic
+    from spn4cir_amd.models import CIRPlus
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-B/32"]
+    B, tau = 4, 0.01
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    sd.update(clip_vision.synthetic_vision_state_dict(768, 12, 32, 224, D, seed=5))
+    ids = synthetic.token_ids(B, seed=1)
+    g = torch.Generator().manual_seed(0)
+    ref_img, tgt_img = torch.randn(B, 3, 224, 224, generator=g), torch.randn(B, 3, 224, 224, generator=g)
+    model = CIRPlus(sd, tau=tau, device=torch.device("cuda"), wo_bank=True)
+    out = model.forward(ids, None, None, None, refer_image=ref_img.cuda(), target_image=tgt_img.cuda())
+    loss = out["bbc_loss"]
+    loss.backward()
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()}
+    ref = bank_loss.inbatch_step(clip_vision.encode_image(params, ref_img), clip_text.encode_text(params, ids.long()),
+                                 clip_vision.encode_image(params, tgt_img), tau)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-2 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    named = dict(model.clip.named_parameters())
+    worst, worst_key, n = 0.0, None, 0
+    for k, p in params.items():
+        if p.grad is None or float(p.grad.abs().max()) == 0.0:
+            continue                                        # logit_scale-like entries the step does not touch
+        gk = named[k].grad
+        assert gk is not None, k
+        if k == "token_embedding.weight":                   # only the rows of the batch's ids carry gradient
+            rows = torch.unique(ids.long())
+            err = _rel(gk.cpu()[rows], p.grad[rows])
+        else:
+            err = _rel(gk.cpu(), p.grad)
+        if err > worst:
+            worst, worst_key = err, k
+        # B = 4: four [EOS] rows and 2 x 4 class tokens carry the whole loss at tau = 0.01, so a parameter gradient is a sum over
+        # very few effective rows and the bf16 operand rounding averages out less than at B = 8 .. 256 (observed worst 5.0e-2 on
+        # one LayerNorm bias, median 1e-2); the gate is 1.6 x the observed worst
+        assert err < 8e-2, (k, err)
+        n += 1
+    assert n >= 12 * 12 * 2 + 8
+    print(f"config 1 (ViT-B/32, B=4): loss {loss.item():.5f} oracle {ref.item():.5f}; worst gradient error {worst:.3e} ({worst_key}) over {n} tensors")

@@ -168,7 +168,16 @@ def test_blip_trainer_two_ranks_match_single_process(golden_dir, mode):
     for rank, losses, params, tau in res:
         assert max(abs(a - b) for a, b in zip(losses, ref_losses)) < 2e-3, (losses, ref_losses)
         assert abs(tau - ref_tau) < 1e-5 * max(1.0, abs(ref_tau))
-        d = (torch.from_numpy(params) - ref_params).abs().max().item()
+        diff = (torch.from_numpy(params) - ref_params).abs()
+        # d loss / d key.bias is EXACTLY zero (softmax is invariant to a shift common to all keys of a query): both runs hold
+        # rounding noise there, AdamW normalises it to steps of ~lr, and the last-bit order of the embedding-gradient atomics
+        # decides its sign - those entries are held to a few lr, everything else to reduction-order noise
+        for k, off, shape in enc.spans():
+            if k.endswith(".self.key.bias"):
+                n = int(np.prod(shape))
+                assert diff[off:off + n].max().item() < 4e-3, (k, diff[off:off + n].max().item())
+                diff[off:off + n] = 0
+        d = diff.max().item()
         assert d < 5e-4, d          # two AdamW steps at lr 1e-3: split-K / reduction-order noise only
 
 

@@ -105,19 +105,21 @@ from spn4cir_amd.trainer import Stage2Trainer
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 sd, target, refer, ids, ridx, labels = _setup()
-def run(mode):
+def run(mode, sparse=False):
     model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
     tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode)
     tr.set_banks(refer, target)
-    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    # sparse: the touched-row exchange of the token-embedding gradient - the extra gloo group next to NCCL, the async
+    # all_gather_into_tensor and the index_add_ on the RCCL stream
+    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev), ids_host=ids if sparse else None).item() for _ in range(2)]
     return ls, model.tower.params.clone()
 ref_l, ref_p = run("replicated")                      # no process group yet: plain single-GPU step
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1])
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-for mode in ("sharded", "replicated"):
-    l, p = run(mode)                                  # every collective now goes through RCCL
-    assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5, (mode, l, ref_l)
-    assert (p - ref_p).abs().max().item() < 1e-6, mode
+for mode, sparse in (("sharded", False), ("replicated", False), ("replicated", True)):
+    l, p = run(mode, sparse)                          # every collective now goes through RCCL
+    assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5, (mode, sparse, l, ref_l)
+    assert (p - ref_p).abs().max().item() < 1e-6, (mode, sparse)
 dist.barrier(); torch.cuda.synchronize()
 dist.destroy_process_group()
 print("NCCL_WORLD1_OK")

@@ -68,12 +68,17 @@ def child(rotate):
         L.spn_prof_disable()
         L.spn_prof_reset()
         tf, tb, tf_all, tb_all = kt[0], kt[1], tf, tb
+        # the whole loss step in one call (spn_bank_step: the pass + ONE tail launch), host-timed, where it is served
+        ts = None
+        if save is not None and ops.bank_step_ok(B, M, qb.shape[1], banks[0]):
+            ts = timed(lambda i: ops.bank_step(qb, banks[i % rotate], labels, 50.0, 1.0 / B, save))
         eb = 1 if dt == "fp8" else 2
         bytes_pass = M * D * eb
         out.append(dict(B=B, M=M, D=D, bank=dt, fwd_us=round(tf * 1e6, 1), bwd_us=round(tb * 1e6, 1),
                         fwd_call_us=round(tf_all * 1e6, 1), bwd_call_us=round(tb_all * 1e6, 1),
                         fwd_TBps=round(bytes_pass / tf / 1e12, 2), bwd_TBps=round(bytes_pass / tb / 1e12, 2),
-                        pair_frac_of_8TBps=round(2 * bytes_pass / (tf + tb) / 8e12, 3)))
+                        pair_frac_of_8TBps=round(2 * bytes_pass / (tf + tb) / 8e12, 3),
+                        step_call_us=None if ts is None else round(ts * 1e6, 1)))
     print(json.dumps(out))
 
 
@@ -108,7 +113,7 @@ def main():
         print(f"{o['B']:>4} {o['M']:>7} {o['D']:>5} {o['bank']:>5} | {o['fwd_us']:>11} {o['bwd_us']:>6} {o['fwd_us'] + o['bwd_us']:>6.1f} | "
               f"{n['fwd_us']:>8} {n['bwd_us']:>6} {n['fwd_us'] + n['bwd_us']:>6.1f} | {f['fwd_us']:>10} {f['bwd_us']:>6} "
               f"{f['fwd_us'] + f['bwd_us']:>6.1f} | {tbps:>20.2f} {tbps / 8:>5.2f}   call {o['fwd_call_us']}/{o['bwd_call_us']} -> "
-              f"{f['fwd_call_us']}/{f['bwd_call_us']}")
+              f"{f['fwd_call_us']}/{f['bwd_call_us']}   spn_bank_step (one call, host-timed back to back): {f.get('step_call_us')}")
 
 
 if __name__ == "__main__":
