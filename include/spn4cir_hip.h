@@ -170,7 +170,8 @@ size_t spn_bank_logits_bytes(int B, int M);
  * SPN_ERR_ARG for it. */
 int spn_bank_config(int mode);
 /* Process-wide kernel selection of the GEMMs, for A/B runs and tests (same results either way): key 0 = the persistent
- * multi-round NT kernel (value 1 on, 0 off, -1 back to the SPN_GEMM_PERSIST default).  SPN_ERR_ARG for an unknown key. */
+ * multi-round NT kernel (value 1 on, 0 off, -1 back to the SPN_GEMM_PERSIST default; measured slower in the step, so it exists
+ * only in the experiments build - the shipped library answers SPN_ERR_ARG to value 1).  SPN_ERR_ARG for an unknown key. */
 int spn_gemm_config(int key, int value);
 /* Every SPN_* environment variable is captured once, when the library is loaded; the kernels' A/B switches read that
  * snapshot only.  Writes a JSON object {"experiments_build": 0|1, "env": {"SPN_X": "value", ...}} (NUL-terminated, truncated

@@ -196,7 +196,7 @@ size_t spn_bank_logits_bytes(int B, int M) { return bank_saved_bytes_any(B, M); 
 int spn_bank_config(int mode) { return bank_config(mode); }
 
 int spn_gemm_config(int key, int value) {
-    if (key == 0) { gemm_nt_persist_set(value); return SPN_OK; }
+    if (key == 0) return gemm_nt_persist_set(value);
     return SPN_ERR_ARG;
 }
 

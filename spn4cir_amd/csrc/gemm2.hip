@@ -813,7 +813,12 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
     return SPN_OK;
 }
 
+#ifdef SPN_EXPERIMENTS
 // ----------------------------------------------------------------------------------- NT, persistent
+// (round 4; compiled only into the experiments build, like gemm_nt3 below: bit-identical to gemm_nt2 and faster per launch on
+// the 924-tile products in a rocprofv3 trace - fc + QuickGELU 124.4 -> 118.4 us - but the STEP is slower with it, 13.52 ->
+// 13.66 ms in two paired bench runs: the cycles it removes are the low-power ones (a workgroup waiting for its first operands),
+// and on a power-limited chip they come back as a lower clock on everything else.  profiles/r04_gemm_persist_ab.txt)
 // gemm_nt2p: the 8-slot staggered schedule of gemm_nt2_kernel<.., SCHED 2> as ONE workgroup per CU that walks several output
 // tiles, with the operand stream running ACROSS tile boundaries: the k tiles of a workgroup's tiles form one sequence g = 0,
 // 1, 2 ... (LDS stage g & 1), and the chunk issues "k tile + 1" / "k tile + 2" of the last k tiles of a tile already fetch
@@ -1082,11 +1087,10 @@ static int launch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K, in
 
 // SPN_GEMM_PERSIST=0 keeps every NT product on the one-tile-per-workgroup kernel (A/B switch)
 static int g_nt_persist = -1;                  // spn_gemm_config(0, v): -1 = the environment default, 0 = off, 1 = on
-void gemm_nt_persist_set(int v) { g_nt_persist = v < 0 ? -1 : (v ? 1 : 0); }
 static bool nt_persist_on() {
     static const bool v = [] {
         const char* e = spn_env("SPN_GEMM_PERSIST");
-        return !(e && e[0] == '0');
+        return e && e[0] == '1';                   // opt-in (experiments build): the step is slower with it
     }();
     return g_nt_persist < 0 ? v : g_nt_persist != 0;
 }
@@ -1096,6 +1100,9 @@ static bool dispatch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K,
                           hipStream_t st, int* rc) {
     if (!nt_persist_on() || M % 256 || N % 256 || K < 128 || ep.direct_store || ep.ldc % 8) return false;
     const int tiles = (M / 256) * (N / 256);
+    // Per launch (rocprofv3, profiles/r04_gemm_persist_ab.txt): 924 tiles (3.6 rounds) fc + QuickGELU 124.4 -> 118.4 us,
+    // d-activation 108.7 -> 107.1; 693 tiles (2.7 rounds, plain bf16 store) 69.4 -> 76.1 us - the four-pass epilogue (eight
+    // barriers instead of four) costs a plain store more than the two hidden prologues return.
     if (tiles <= device_cu_count()) return false;
     const bool b16 = ep.out_bf16 && !ep.out_f32, f32o = ep.out_f32 && !ep.out_bf16;
 #define SPN_NT2P(MODE_, ACT_, F_, B_, A_) (*rc = launch_nt2p<MODE_, ACT_, F_, B_, A_>(A, B, M, N, K, lda, ldb, ep, st), true)
@@ -1109,6 +1116,8 @@ static bool dispatch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K,
 #undef SPN_NT2P
     return false;
 }
+
+#endif  // SPN_EXPERIMENTS (persistent NT kernel)
 
 #ifdef SPN_EXPERIMENTS   // the hand-scheduled 4-wave kernel: measured slower in the step, not in the shipped library
 // Epilogue of gemm_nt3: FULL 256x256 tiles only (the launcher routes anything else to gemm_nt2), straight-line code, and
@@ -1388,6 +1397,12 @@ static int dispatch_nt3(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
 
 #endif  // SPN_EXPERIMENTS
 
+#ifdef SPN_EXPERIMENTS
+int gemm_nt_persist_set(int v) { g_nt_persist = v < 0 ? -1 : (v ? 1 : 0); return SPN_OK; }
+#else
+int gemm_nt_persist_set(int v) { return v > 0 ? SPN_ERR_ARG : SPN_OK; }     // the kernel is not part of this build
+#endif
+
 static bool nt_phased() {
     static const bool v = [] {
         const char* e = spn_env("SPN_GEMM_NT_PHASED");
@@ -1486,8 +1501,10 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
             if (nt_phased()) {
+#ifdef SPN_EXPERIMENTS
                 int rc = SPN_OK;
-                if (dispatch_nt2p(A, B, M, N, K, lda, ldb, mode, e2, st, &rc)) return rc;      // multi-round: persistent walk
+                if (dispatch_nt2p(A, B, M, N, K, lda, ldb, mode, e2, st, &rc)) return rc;      // multi-round: persistent walk (opt-in)
+#endif
                 return dispatch_nt2<256, 256, 2, 4, 2, 64, true>(A, B, M, N, K, lda, ldb, mode, e2, st);
             }
             return dispatch_nt2<256, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);

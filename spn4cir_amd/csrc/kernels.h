@@ -76,7 +76,7 @@ size_t gemm_tn_grouped_workspace_bytes(int Kr);
 int device_cu_count();   // compute units of the current device (256 on MI355X)
 int gemm_tn_grouped(const TnProblem* probs, int n, int Kr, float* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_tn2_workspace_bytes(int Kr, int N1, int N2);
-void gemm_nt_persist_set(int v);   // gemm2.hip: -1 = environment default, 0 / 1 = persistent multi-round NT kernel off / on
+int gemm_nt_persist_set(int v);    // gemm2.hip: -1 = environment default, 0 / 1 = persistent multi-round NT kernel off / on (experiments build)
 bool gemm_use_v1();
 int gemm_cfg();
 

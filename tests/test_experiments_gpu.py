@@ -1,5 +1,5 @@
 """The experiments build (make -C spn4cir_amd/csrc EXPERIMENTS=1 -> libspn4cir_hip_exp.so: the same C-ABI plus the kernels that
-were measured slower and left out of the shipped library - csrc/bank2.hip's streaming pair, the hand-scheduled 4-wave NT GEMM)
+were measured slower and left out of the shipped library - csrc/bank2.hip's streaming pair, the hand-scheduled 4-wave NT GEMM, the persistent multi-round NT GEMM)
 keeps passing its parity tests: the tests that need those kernels skip in the main run and run here, in a child pytest that
 loads the variant through SPN_LIB_PATH."""
 import os
@@ -31,7 +31,7 @@ def test_experiment_kernels_parity():
         pytest.skip("no GPU")
     assert os.path.exists(EXP_LIB), "experiments build absent: __graft_entry__.build() makes it"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-x", "-q", "-k",
-                        "saved_logits_pair or nt3_hand_scheduled"], env=dict(os.environ, SPN_LIB_PATH=EXP_LIB), cwd=ROOT,
+                        "saved_logits_pair or nt3_hand_scheduled or persistent_matches"], env=dict(os.environ, SPN_LIB_PATH=EXP_LIB), cwd=ROOT,
                        capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout and "skipped" not in p.stdout.splitlines()[-1], p.stdout[-500:]

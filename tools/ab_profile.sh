@@ -13,7 +13,7 @@ for E in "$2" "$3"; do
   export $E
   rocprofv3 --kernel-trace --stats -d $O/kt$i -o kt -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-packed --no-recall --no-extra-configs > $O/kt$i.log 2>&1
   python3 $R/tools/rocpd_stats.py $(ls $O/kt$i/*.db | head -1) $O/kernel_stats_$i.txt > /dev/null
-  tail -1 $O/kt$i.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$E', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
+  grep '^{"metric' $O/kt$i.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$E', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
   head -16 $O/kernel_stats_$i.txt | cut -c1-40,90-160
   unset ${E%%=*}
   rm -rf $O/kt$i
