@@ -725,6 +725,18 @@ __global__ __launch_bounds__(256) void bank_fused_combine_kernel(const float* __
     const float* st = sp + (size_t)b * 4;
     const size_t so = (size_t)B * D, ss = (size_t)B * 4;
     int r = rl;
+    for (; r + 112 < nch; r += 128) {                                // eight independent (weight, partial) loads in flight; the
+        f32x4 v[8];                                                  // accumulation order is that of the 4-deep loop below
+        float mm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = *(const f32x4*)(o + (size_t)(r + 16 * k) * so);
+            mm[k] = st[(size_t)(r + 16 * k) * ss];
+            zlab = fmaxf(zlab, st[(size_t)(r + 16 * k) * ss + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k] * __expf(mm[k] - ls);
+    }
     for (; r + 48 < nch; r += 64) {                                  // four independent (weight, partial) loads in flight
         const f32x4 v0 = *(const f32x4*)(o + (size_t)r * so), v1 = *(const f32x4*)(o + (size_t)(r + 16) * so);
         const f32x4 v2 = *(const f32x4*)(o + (size_t)(r + 32) * so), v3 = *(const f32x4*)(o + (size_t)(r + 48) * so);
@@ -814,6 +826,17 @@ __global__ __launch_bounds__(256) void bank_step_tail_kernel(const float* __rest
     const bool in = c < D;
     const float* o = Op + (size_t)b * D + (in ? c : 0);
     int r = rl;
+    for (; r + 112 < nch; r += 128) {                                // as bank_fused_combine_kernel: same order, eight loads in flight
+        f32x4 v[8];
+        float mm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = *(const f32x4*)(o + (size_t)(r + 16 * k) * so);
+            mm[k] = st[(size_t)(r + 16 * k) * ss];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k] * __expf(mm[k] - ls);
+    }
     for (; r + 48 < nch; r += 64) {
         const f32x4 v0 = *(const f32x4*)(o + (size_t)r * so), v1 = *(const f32x4*)(o + (size_t)(r + 16) * so);
         const f32x4 v2 = *(const f32x4*)(o + (size_t)(r + 32) * so), v3 = *(const f32x4*)(o + (size_t)(r + 48) * so);
@@ -1752,7 +1775,7 @@ __global__ void bank_loss_finalize_kernel(const float* __restrict__ stats, int n
 size_t bank_workspace_bytes(int B, int M, int D) {
     const BankChunking c = bank_chunking(B, M);
     size_t a = (size_t)c.nchunks * B * 4 * sizeof(float);
-    const size_t g = (size_t)gemm_bank_stats_tiles(M) * B * 4 * sizeof(float);   // GEMM-path statistics partials
+    const size_t g = (size_t)((M + 127) / 128) * B * 4 * sizeof(float);   // GEMM-path statistics partials (the finer of the two tilings)
     if (g > a) a = g;
     const size_t b = (size_t)c.nchunks * B * D * sizeof(float);
     if (b > a) a = b;
@@ -2027,12 +2050,12 @@ struct LargeSave {
     bf16_t* P; int ldp; bf16_t* Gt; int mpad; float* tmax; int nt;
 };
 static size_t large_save_bytes(int B, int M) {
-    const size_t ldp = (size_t)(M + 255) / 256 * 256, mpad = (size_t)(M + 63) / 64 * 64, nt = (size_t)(M + 255) / 256;
+    const size_t ldp = (size_t)(M + 255) / 256 * 256, mpad = (size_t)(M + 63) / 64 * 64, nt = (size_t)(M + 127) / 128;   // the finer tiling
     return (((size_t)B * ldp * 2 + 255) & ~(size_t)255) + ((mpad * B * 2 + 255) & ~(size_t)255) + nt * B * 4;
 }
 static LargeSave large_save_at(void* base, int B, int M) {
     LargeSave s;
-    s.ldp = (M + 255) / 256 * 256; s.mpad = (M + 63) / 64 * 64; s.nt = (M + 255) / 256;
+    s.ldp = (M + 255) / 256 * 256; s.mpad = (M + 63) / 64 * 64; s.nt = (M + 127) / 128;
     char* p = (char*)base;
     s.P = (bf16_t*)p; p += ((size_t)B * s.ldp * 2 + 255) & ~(size_t)255;
     s.Gt = (bf16_t*)p; p += ((size_t)s.mpad * B * 2 + 255) & ~(size_t)255;
@@ -2067,7 +2090,7 @@ size_t bank_saved_bytes_any(int B, int M) {
 __global__ __launch_bounds__(256) void bank_p_to_gt_kernel(const bf16_t* __restrict__ P, int ldp, const float* __restrict__ tmax,
                                                           const float* __restrict__ lse, const int64_t* __restrict__ labels,
                                                           int B, int M, int m_begin, float ls, float inv_m,
-                                                          bf16_t* __restrict__ Gt) {
+                                                          bf16_t* __restrict__ Gt, int tile_shift) {
     __shared__ float T[64][65];
     const int m0 = blockIdx.x * 64, b0 = blockIdx.y * 64, t = threadIdx.x;
 #pragma unroll
@@ -2076,7 +2099,7 @@ __global__ __launch_bounds__(256) void bank_p_to_gt_kernel(const bf16_t* __restr
         float g[8];
         if (b < B) {
             const bf16x8 p = *(const bf16x8*)(P + (size_t)b * ldp + m0 + m8);
-            const float tm = tmax[(size_t)((m0 + m8) >> 8) * B + b];          // 8 keys of one 256-key tile
+            const float tm = tmax[(size_t)((m0 + m8) >> tile_shift) * B + b];   // 8 keys of one statistics tile (128 / 256 keys)
             const float sc = __expf(tm - lse[b]);
             const int64_t lab = labels[b] - (int64_t)m_begin;
 #pragma unroll
@@ -2123,7 +2146,7 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     // right trade only while B is small (8-way data parallel: 32 per GPU).  SPN_BANK_GEMM=0 forces streaming.
     const bool use_gemm = bank_gemm_on();
     if (use_gemm && !a.bank_scale && !a.group && a.B >= 128 && a.D % 64 == 0) {
-        const int nt = gemm_bank_stats_tiles(a.M);
+        const int nt = gemm_bank_stats_tiles(a.M, a.D);
         if (ws_bytes < (size_t)nt * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
         {
             const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
@@ -2191,7 +2214,7 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
         const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 6 + (double)a.B * 16;
         ProfScope prof(PK_BANK_BWD, bytes, st);
         hipLaunchKernelGGL(bank_p_to_gt_kernel, dim3(sv.mpad / 64, (a.B + 63) / 64), dim3(256), 0, st, sv.P, sv.ldp, sv.tmax, row_lse,
-                           a.labels, a.B, a.M, a.m_begin, label_smoothing, 1.0f / (float)M_total, sv.Gt);
+                           a.labels, a.B, a.M, a.m_begin, label_smoothing, 1.0f / (float)M_total, sv.Gt, gemm_bank_stats_bn(a.D) == 128 ? 7 : 8);
         SPN_CHECK_LAUNCH();
         return gemm_tn(sv.Gt, a.bank, a.M, a.B, a.D, a.B, a.D, dq, a.D, grad_scale * a.inv_tau, 0, nullptr, ws, ws_bytes, st);
     }

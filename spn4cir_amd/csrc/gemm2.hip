@@ -1453,7 +1453,19 @@ static int dispatch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, i
     return SPN_ERR_ARG;
 }
 
-int gemm_bank_stats_tiles(int M) { return (M + 255) / 256; }
+// Bank-row width of a statistics tile: 256, or 128 for narrow banks (D <= 256: the BLIP / BLIP-2 heads).  Measured (round 4,
+// tools/bank_bench.py, kernel-only): B = 128, M = 30 000, D = 256: 21.2 -> 14.5 us with 128-row tiles (a 256-row tile of a
+// 256-wide bank is 118 tiles of little work each; 235 fill the chip) - but B = 256, M = 40 000, D = 768: 43.7 -> 48.9 us (the
+// 3-stage one-barrier loop of the 256 x 128 configuration loses more than the finer tiling gains).  SPN_BANK_GEMM_BN=128 / 256
+// forces one.  The tile count is what sizes the partial buffers: callers ask gemm_bank_stats_tiles(M, D).
+int gemm_bank_stats_bn(int D) {
+    static const int forced = [] {
+        const char* e = spn_env("SPN_BANK_GEMM_BN");
+        return !e ? 0 : (e[0] == '2' ? 256 : (e[0] == '1' ? 128 : 0));
+    }();
+    return forced ? forced : (D <= 256 ? 128 : 256);
+}
+int gemm_bank_stats_tiles(int M, int D) { const int bn = gemm_bank_stats_bn(D); return (M + bn - 1) / bn; }
 
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
                     float inv_tau, int m_begin, float* partial, hipStream_t st, bf16_t* p_out, int ldp, float* max_out) {
@@ -1465,6 +1477,8 @@ int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, in
     if (p_out && (ldp % 256 || ldp < M || !max_out)) return SPN_ERR_ARG;
     e.bs_p_out = p_out; e.bs_ldp = ldp; e.bs_max_out = max_out;
     e.ldc = 8;
+    if (gemm_bank_stats_bn(D) == 128)
+        return launch_nt2<256, 128, 4, 2, 3, GEMM_BANKSTATS, ACT_NONE, 1, 64>(q, bank, B, M, D, ldq, ldb, e, st);
     return launch_nt2<256, 256, 2, 4, 2, GEMM_BANKSTATS, ACT_NONE, 2, 64>(q, bank, B, M, D, ldq, ldb, e, st);
 }
 

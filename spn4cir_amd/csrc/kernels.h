@@ -55,7 +55,8 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
                     float inv_tau, int m_begin, float* partial, hipStream_t st, bf16_t* p_out = nullptr, int ldp = 0,
                     float* max_out = nullptr);
-int gemm_bank_stats_tiles(int M);
+int gemm_bank_stats_tiles(int M, int D);
+int gemm_bank_stats_bn(int D);      // bank rows per statistics tile (128 for D <= 256, else 256)
 bool gemm_tn2_pair_ok(int N1a, int N2a);
 size_t gemm_tn2_pair_workspace_bytes(int Kr, int N1a, int N2a, int N1b, int N2b);
 int gemm_tn2_pair(const bf16_t* A1, const bf16_t* B1, int N1a, int N2a, int lda1, int ldb1, float* C1, int ldc1, float* cs1,
