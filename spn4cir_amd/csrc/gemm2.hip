@@ -30,6 +30,7 @@ namespace spn {
 
 static constexpr int BK2 = 64;
 
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -122,14 +123,40 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
     }
     const float alpha = ep.alpha;
     const int row_l = wid * RPI + lane / LPR;                     // first row of this lane inside a chunk
+    // write-through stores (ep.store_wt, block-uniform): `buffer_store_dwordx4 ... sc1` through a descriptor over the whole
+    // output; the line is not kept in the XCD's L2 (MI355X_MICROARCH.md, stores of each flavour)
+    const bool wt = ep.store_wt != 0;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_o16, rs_o32, rs_aux;
+    if (wt) {
+        if constexpr (OUT_BF16) rs_o16 = make_rsrc(ep.out_bf16, 0xfffffff0u);
+        if constexpr (OUT_F32) rs_o32 = make_rsrc(ep.out_f32, 0xfffffff0u);
+        if constexpr (AUX_OUT) rs_aux = make_rsrc(ep.aux_out, 0xfffffff0u);
+    }
+    auto put16 = [&](void* base, const __amdgpu_buffer_rsrc_t& rs, size_t byte_off, u32x4 v) {
+        if (wt) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (uint32_t)byte_off, 0, 16);
+        else *(u32x4*)((char*)base + byte_off) = v;
+    };
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const size_t obase = (size_t)(m0 + ch * CHUNK + row_l) * ep.ldc + n;
         [[maybe_unused]] bf16x8 pf_aux[ITERS];
         [[maybe_unused]] f32x4 pf_r0[ITERS], pf_r1[ITERS];
         if constexpr (MODE == GEMM_DACT) {
+            if (ep.aux_ld) {                        // block-uniform: streaming loads (read once, no reuse: keep them out of the L2's way)
+                const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(ep.aux_in, 0xfffffff0u);
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it) pf_aux[it] = *(const bf16x8*)(ep.aux_in + obase + (size_t)it * NW * RPI * ep.ldc);
+                for (int it = 0; it < ITERS; ++it) {
+                    const uint32_t off = (uint32_t)((obase + (size_t)it * NW * RPI * ep.ldc) * 2);
+                    u32x4 v;
+                    if (ep.aux_ld == 2) v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 2);
+                    else if (ep.aux_ld == 16) v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 16);
+                    else v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 17);
+                    pf_aux[it] = __builtin_bit_cast(bf16x8, v);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) pf_aux[it] = *(const bf16x8*)(ep.aux_in + obase + (size_t)it * NW * RPI * ep.ldc);
+            }
         } else if constexpr (MODE == GEMM_RESID) {
             const float* rp = ep.resid + (size_t)(m0 + ch * CHUNK + row_l) * ep.ldr + n;
 #pragma unroll
@@ -186,9 +213,9 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
                             act_and_grad_into(ACT, v0[e], v0[e], g0[e]);
                             act_and_grad_into(ACT, v1[e], v1[e], g1[e]);
                         }
-                        *(bf16x8*)(ep.aux_out + o) = pack8(g0, g1);
+                        put16(ep.aux_out, rs_aux, o * 2, __builtin_bit_cast(u32x4, pack8(g0, g1)));
                     } else {
-                        *(bf16x8*)(ep.aux_out + o) = pack8(v0, v1);
+                        put16(ep.aux_out, rs_aux, o * 2, __builtin_bit_cast(u32x4, pack8(v0, v1)));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v0[e] = ACT == ACT_QUICKGELU ? quick_gelu_f(v0[e]) : gelu_erf_f(v0[e]);
@@ -220,10 +247,10 @@ __device__ __forceinline__ void nt_epilogue_full(f32x16 (&acc)[BM / WM / 32][BN 
                 }
             }
             if constexpr (OUT_F32) {
-                *(f32x4*)(ep.out_f32 + o) = v0;
-                *(f32x4*)(ep.out_f32 + o + 4) = v1;
+                put16(ep.out_f32, rs_o32, o * 4, __builtin_bit_cast(u32x4, v0));
+                put16(ep.out_f32, rs_o32, o * 4 + 16, __builtin_bit_cast(u32x4, v1));
             }
-            if constexpr (OUT_BF16) *(bf16x8*)(ep.out_bf16 + o) = pack8(v0, v1);
+            if constexpr (OUT_BF16) put16(ep.out_bf16, rs_o16, o * 2, __builtin_bit_cast(u32x4, pack8(v0, v1)));
         }
         }
         SPN_EPI_STAMP();
@@ -541,8 +568,24 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(co
         while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)ep.stag_ticks) __builtin_amdgcn_s_sleep(32);
     }
     const int tiles_n = (N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int m0, n0;
+    if (ep.col_group > 0 && ep.col_group < tiles_n) {
+        // column-group-major tile order (launch_nt2): logical ids sweep col_group column tiles for every row block, then the
+        // next group - the contiguous id range of an XCD then needs col_group B panels only, which stay in its L2
+        const int tiles_m = (M + BM - 1) / BM;
+        int c0 = 0, wg = ep.col_group;
+        while (bid >= tiles_m * wg) {              // <= tiles_n / col_group iterations, block-uniform
+            bid -= tiles_m * wg;
+            c0 += wg;
+            wg = min(ep.col_group, tiles_n - c0);
+        }
+        m0 = (bid / wg) * BM;
+        n0 = (c0 + bid % wg) * BN;
+    } else {
+        m0 = (bid / tiles_n) * BM;
+        n0 = (bid % tiles_n) * BN;
+    }
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (uint32_t)M * (uint32_t)lda * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (uint32_t)N * (uint32_t)ldb * 2u);
 
@@ -807,6 +850,37 @@ static int launch_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int
             e.stag_to = cus;
             e.stag_ticks = stag_us * 100 * (K / 768 > 0 ? K / 768 : 1);   // s_memrealtime ticks (100 MHz), scaled with the k loop
         }
+    }
+    // Tile order: row-major over the column tiles by default.  With many column tiles (fc / d-activation: 12 x 393 KB of weight
+    // panels = 4.7 MB) the panels of ONE row-major sweep no longer fit an XCD's 4 MB L2 next to the A panels and the output stream,
+    // and every round of 32 tiles re-fetches them: FETCH_SIZE x 2 = 194 MB per fc launch against 35 MB of operands
+    // (profiles/r04_bench_n1_pmc_fetch_size.txt).  In column groups of `cg` tiles an XCD's contiguous id range needs cg panels only
+    // (they stay resident), at the price of the A panels being fetched once per group: A x ceil(tiles_n / cg) + 8 x cg panels.
+    // cg = tiles_n split evenly into the fewest groups whose panels take <= 2.5 MB; SPN_GEMM_COL_GROUP=n forces n (0 = row-major).
+    if (MODE != GEMM_BANKSTATS) {
+        static const int forced = [] { const char* v = spn_env("SPN_GEMM_COL_GROUP"); return v ? atoi(v) : -1; }();
+        const int tiles_n = (N + BN - 1) / BN;
+        int cg = forced;
+        if (cg < 0) {
+            const int fit = (int)((2.5 * 1024 * 1024) / ((double)BN * K * 2));
+            cg = 0;
+            if (fit >= 1 && fit < tiles_n && tiles_n > 8) {
+                const int groups = (tiles_n + fit - 1) / fit;
+                cg = (tiles_n + groups - 1) / groups;
+            }
+        }
+        e.col_group = cg;
+        // write-through output stores for multi-round launches (their operand panels are re-read round after round): the
+        // outputs must be addressable through one 32-bit buffer descriptor.  SPN_GEMM_STORE_WT=0 / 1 forces off / on.
+        static const int wt = [] { const char* v = spn_env("SPN_GEMM_STORE_WT"); return v ? atoi(v) : -1; }();
+        const bool fits = (uint64_t)M * (uint64_t)(ep.ldc > 0 ? ep.ldc : N) * 4 < 0xfffffff0ull;
+        // measured (round 4, three paired bench runs): 13.75 -> 13.64 ms per step with every bf16 output written through; an fp32
+        // output (the one RESID launch left) loses (105.7 -> 124.5 us) and keeps plain stores
+        e.store_wt = (fits && (wt > 0 || (wt < 0 && !ep.out_f32))) ? 1 : 0;
+        // d-activation reads 121 MB of act'(pre) exactly once: non-temporal loads (aux = 2) keep that stream from displacing the
+        // operand panels (two paired runs: 13.12 / 13.07 -> 13.04 / 13.00 ms per step; sc1 / sc0 sc1: no change).  SPN_GEMM_AUX_LD=0 = plain
+        static const int ald = [] { const char* v = spn_env("SPN_GEMM_AUX_LD"); return v ? atoi(v) : 2; }();
+        e.aux_ld = fits ? ald : 0;
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), LDS, st, A, B, M, N, K, lda, ldb, e);
     SPN_CHECK_LAUNCH();

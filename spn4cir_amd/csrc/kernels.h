@@ -24,6 +24,10 @@ struct GemmEpilogue {
     float alpha = 1.0f;
     int direct_store = 0;            // gemm2 only: 1 = store from the MFMA layout (no LDS staging)
     int stag_from = 0, stag_to = 0, stag_ticks = 0;   // gemm2: first-round workgroups [stag_from, stag_to) start stag_ticks (100 MHz) late
+    int col_group = 0;               // gemm2: > 0 = tile order in column groups of this many 256-wide tiles (launch_nt2)
+    int aux_ld = 0;                  // gemm2, full tiles, GEMM_DACT: cache-policy bits of the aux_in loads (0 plain, 2 nt, 16 sc1, 17 sc0 sc1)
+    int store_wt = 0;                // gemm2, full tiles: 1 = outputs leave through write-through (sc1) buffer stores - the output
+                                     // stream then does not displace the operand panels from the XCD's L2 (launch_nt2)
     // GEMM_BANKSTATS (gemm2, 256x256 tile only): A = queries [B, D], B = bank rows [M, D]; nothing is stored but the
     // per-row softmax statistics of each 256-column tile: bs_out[(tile_n * B + row) * 4] = {max, sum exp, sum, label logit}
     // of logits * bs_inv_tau (the layout bank_stats_fold_kernel reduces)

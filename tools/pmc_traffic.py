@@ -24,9 +24,13 @@ def main(fetch, write, out, tag):
     T, W = 19712, 768
     def gemm(M, N, K, out_b, extra=0):
         return M * K * 2 + N * K * 2 + M * N * out_b + extra
-    per_layer = [gemm(T, 3 * W, W, 2), gemm(T, W, W, 4, T * W * 4), gemm(T, 4 * W, W, 4), gemm(T, W, 4 * W, 4, T * W * 4),
-                 gemm(T, 4 * W, W, 2, T * 4 * W * 2), gemm(T, W, 4 * W, 2), gemm(T, W, W, 2), gemm(T, W, 3 * W, 2)]
-    algo = sum(per_layer) / len(per_layer)
+    # round 4: the out-projection and c_proj store bf16 (the residual add moved into the following LayerNorm); only the last
+    # block's c_proj keeps the fp32 residual epilogue.  fc writes u + act'(pre) (2 x bf16), d-activation reads act'(pre).
+    layers = 12
+    per_layer = [gemm(T, 3 * W, W, 2), gemm(T, W, W, 2), gemm(T, 4 * W, W, 4), gemm(T, 4 * W, W, 2, T * 4 * W * 2),
+                 gemm(T, W, 4 * W, 2), gemm(T, W, W, 2), gemm(T, W, 3 * W, 2)]
+    cproj_bf16, cproj_resid = gemm(T, W, 4 * W, 2), gemm(T, W, 4 * W, 4, T * W * 4)
+    algo = (layers * sum(per_layer) + (layers - 1) * cproj_bf16 + cproj_resid) / (8 * layers)
     j = {"kernel": "gemm_nt2_kernel (all epilogue variants, launch-weighted)",
          "launches_fetch_pass": nf, "launches_write_pass": nw,
          "fetch_size_kb_raw_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
