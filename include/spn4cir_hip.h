@@ -195,6 +195,15 @@ int spn_bank_step_ok(int B, int M, int D, int fp8);
 int spn_bank_step(const void* q_bf16, int ldq, const void* bank, const float* bank_scale, const int64_t* labels, int B, int M,
                   int D, float inv_tau, float grad_scale, float* logits_save, float* row_lse, float* row_loss, float* loss_mean,
                   float* dq, void* stream);
+/* Negative-type ablation head, clip4cir/models_negtype.py:53-134 (text_neg_loss, refer_neg_loss, query_neg_loss, infonce_loss and
+ * forward()'s neg_type mask): refer / text / target = fp32 [B, D] raw reference-image, text and target-image features (D a
+ * multiple of 64, <= 1024).  With q_i = n(refer_i + text_i), t_i = n(target_i): target term L_ij = <q_i, t_j> (bit 4), query
+ * <t_i, q_j> (bit 8), text <n(refer_i + text_j), t_i> (bit 2), refer <n(refer_j + text_i), t_i> (bit 1), each / tau and CE over
+ * j with label i; loss [1] = mean of the selected terms, d_refer / d_text / d_target [B, D] = its gradient.  fp32 throughout,
+ * every sum in a fixed order.  ws: spn_negtype_workspace_bytes(B, D). */
+size_t spn_negtype_workspace_bytes(int B, int D);
+int spn_negtype_head(const float* refer, const float* text, const float* target, int B, int D, float inv_tau, int neg_type,
+                     float* loss, float* d_refer, float* d_text, float* d_target, void* ws, size_t ws_bytes, void* stream);
 /* fp8 bank (BASELINE config 5): the static bank stored as OCP e4m3 bytes [M, Dp] + one fp32 scale per row
  * (row max -> 448), halving the only HBM stream of the loss.  The kernels dequantise a tile into LDS (x scale,
  * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /

@@ -86,6 +86,8 @@ _SIGS = {
     "spn_config_dump": (i32, [C.c_char_p, i32]),
     "spn_gemm_config": (i32, [i32, i32]),
     "spn_bank_step_ok": (i32, [i32, i32, i32, i32]),
+    "spn_negtype_workspace_bytes": (sz, [i32, i32]),
+    "spn_negtype_head": (i32, [vp, vp, vp, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
     "spn_fusion_bwd_phase": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "spn_scale_cast_bf16": (i32, [vp, vp, i32, vp, i32, i32, i32, vp]),
     "spn_bank_step": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp]),

@@ -219,6 +219,14 @@ int spn_bank_grad_q_saved(const void* q_bf16, int ldq, const void* bank, const f
     return bank_grad_q(a, row_lse, label_smoothing, M_total, grad_scale, dq, (float*)ws, ws_bytes, ST(stream), logits_saved);
 }
 
+size_t spn_negtype_workspace_bytes(int B, int D) { return negtype_workspace_bytes(B, D); }
+
+int spn_negtype_head(const float* refer, const float* text, const float* target, int B, int D, float inv_tau, int neg_type,
+                     float* loss, float* d_refer, float* d_text, float* d_target, void* ws, size_t ws_bytes, void* stream) {
+    return negtype_head(refer, text, target, B, D, inv_tau, neg_type, loss, d_refer, d_text, d_target, (float*)ws, ws_bytes,
+                        ST(stream));
+}
+
 int spn_bank_step_ok(int B, int M, int D, int fp8) {
     BankArgs a = make_bank(nullptr, D, nullptr, nullptr, B, M, D, 0, 1.0f);
     static const float one = 1.0f;

@@ -80,6 +80,20 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_ba
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_base), 16, voffset_bytes, 0, 0, SPN_GLDS_AUX);
 }
 
+// Write-through (sc1) stores of streaming outputs through a buffer descriptor over [base, base + 4 GB): the line is not kept in
+// the XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"), so a kernel that only streams its result out neither displaces
+// what the next kernel will re-read from L2 nor leaves up to 32 MB of dirty lines to be written back at the kernel boundary.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) { return make_rsrc(base, 0xfffffff0u); }
+__device__ __forceinline__ void store_wt16(const __amdgpu_buffer_rsrc_t& rs, size_t byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, (uint32_t)byte_off, 0, 16);
+}
+__device__ __forceinline__ void store_wt8(const __amdgpu_buffer_rsrc_t& rs, size_t byte_off, u32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, (uint32_t)byte_off, 0, 16);
+}
+// process-wide default of the streaming kernels' store policy (config.hip): SPN_STREAM_WT=0 keeps plain stores
+int spn_stream_wt();
+
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

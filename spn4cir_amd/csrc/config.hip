@@ -35,6 +35,14 @@ const char* spn_env(const char* name) {
     return nullptr;
 }
 
+int spn_stream_wt() {
+    static const int v = [] {
+        const char* e = spn_env("SPN_STREAM_WT");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return v;
+}
+
 extern "C" int spn_config_dump(char* buf, int cap) {
     std::string s = "{\"experiments_build\": ";
 #ifdef SPN_EXPERIMENTS

@@ -85,6 +85,11 @@ int gemm_nt_persist_set(int v);    // gemm2.hip: -1 = environment default, 0 / 1
 bool gemm_use_v1();
 int gemm_cfg();
 
+// negtype.hip: the four in-batch InfoNCE terms of clip4cir/models_negtype.py (forward + feature gradients, fp32)
+size_t negtype_workspace_bytes(int B, int D);
+int negtype_head(const float* R, const float* T, const float* I, int B, int D, float inv_tau, int neg_type, float* loss,
+                 float* dR, float* dT, float* dI, float* ws, size_t ws_bytes, hipStream_t st);
+
 // elementwise.hip
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
 // y[b, :D] = bf16(x[b, :] * s), y[b, D:ldo] = 0; s = *scale_dev (device scalar) or its reciprocal

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             const float* __restrict__ beta, bf16_t* yb,
                                                             float* __restrict__ yf, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int rows, int W, float eps,
-                                                            const bf16_t* yin = nullptr, float* __restrict__ xo = nullptr) {
+                                                            const bf16_t* yin = nullptr, float* __restrict__ xo = nullptr, int wt = 0) {
+    const __amdgpu_buffer_rsrc_t rs_xo = wt_rsrc(xo), rs_yf = wt_rsrc(yf), rs_yb = wt_rsrc(yb);
     // persistent: wave w walks rows w, w + nwaves, ... with the next row's loads in flight under the current row's two
     // reductions and stores
     const int lane = threadIdx.x & 63;
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 const int c = lane + i * 64;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[i][e] += bf2f(ya[i][e]);
-                if (EXACT || c < nv) *(f32x4*)(xo + (size_t)row * W + c * 4) = v[i];
+                if (EXACT || c < nv) {
+                    if (wt) store_wt16(rs_xo, ((size_t)row * W + c * 4) * 4, __builtin_bit_cast(u32x4, v[i]));
+                    else *(f32x4*)(xo + (size_t)row * W + c * 4) = v[i];
+                }
             }
         }
         float s = 0.f;
@@ -83,10 +87,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * gm[i][e] + bt[i][e];
-                if (yf) *(f32x4*)(yf + (size_t)row * W + c * 4) = o;
+                if (yf) {
+                    if (wt) store_wt16(rs_yf, ((size_t)row * W + c * 4) * 4, __builtin_bit_cast(u32x4, o));
+                    else *(f32x4*)(yf + (size_t)row * W + c * 4) = o;
+                }
                 if (yb) {
                     bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                    *(bf16x4*)(yb + (size_t)row * W + c * 4) = ob;
+                    if (wt) store_wt8(rs_yb, ((size_t)row * W + c * 4) * 2, __builtin_bit_cast(u32x2, ob));
+                    else *(bf16x4*)(yb + (size_t)row * W + c * 4) = ob;
                 }
             }
         }
@@ -104,14 +112,15 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
     if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
     static const int cap = env_int_min1("SPN_LNF_BLOCKS", 768);
     const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
+    const int wt = (spn_stream_wt() && (uint64_t)rows * W * 4 < 0xfffffff0ull) ? 1 : 0;
 #define SPN_LN_FWD(V_)                                                                                          \
     do {                                                                                                        \
         if (W == 256 * V_)                                                                                      \
             hipLaunchKernelGGL((layernorm_fwd_kernel<V_, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, y_f32, \
-                               mean, rstd, rows, W, eps);                                                       \
+                               mean, rstd, rows, W, eps, (const bf16_t*)nullptr, (float*)nullptr, wt);          \
         else                                                                                                    \
             hipLaunchKernelGGL((layernorm_fwd_kernel<V_, false>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16,     \
-                               y_f32, mean, rstd, rows, W, eps);                                                \
+                               y_f32, mean, rstd, rows, W, eps, (const bf16_t*)nullptr, (float*)nullptr, wt);   \
     } while (0)
     if (W <= 256) SPN_LN_FWD(1);
     else if (W <= 512) SPN_LN_FWD(2);
@@ -132,14 +141,15 @@ int layernorm_fwd_add(const float* x, const bf16_t* y, const float* gamma, const
     if (W % 4 || W > 64 * 4 * LN_MAXV_LIMIT) return SPN_ERR_SHAPE;
     static const int cap = env_int_min1("SPN_LNF_BLOCKS", 768);
     const int blocks = (rows + 3) / 4 < cap ? (rows + 3) / 4 : cap;
+    const int wt = (spn_stream_wt() && (uint64_t)rows * W * 4 < 0xfffffff0ull) ? 1 : 0;
 #define SPN_LN_FWD_ADD(V_)                                                                                      \
     do {                                                                                                        \
         if (W == 256 * V_)                                                                                      \
             hipLaunchKernelGGL((layernorm_fwd_kernel<V_, true, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, \
-                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out);                            \
+                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out, wt);                        \
         else                                                                                                    \
             hipLaunchKernelGGL((layernorm_fwd_kernel<V_, false, true>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y_bf16, \
-                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out);                            \
+                               (float*)nullptr, mean, rstd, rows, W, eps, y, x_out, wt);                        \
     } while (0)
     if (W <= 256) SPN_LN_FWD_ADD(1);
     else if (W <= 512) SPN_LN_FWD_ADD(2);
@@ -163,7 +173,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             int accumulate_dx, bf16_t* __restrict__ dxb,
-                                                            float* __restrict__ ws, int rows, int W) {
+                                                            float* __restrict__ ws, int rows, int W, int wt = 0) {
+    const __amdgpu_buffer_rsrc_t rs_dx = wt_rsrc(dx), rs_dxb = wt_rsrc(dxb);
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
@@ -220,10 +231,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - s1 - xh[i][e] * s2);
                 float* dp = dx + (size_t)row * W + c * 4;
                 o += dprev[i];
-                *(f32x4*)dp = o;
+                if (wt) store_wt16(rs_dx, ((size_t)row * W + c * 4) * 4, __builtin_bit_cast(u32x4, o));
+                else *(f32x4*)dp = o;
                 if (dxb) {
                     bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                    *(bf16x4*)(dxb + (size_t)row * W + c * 4) = ob;
+                    if (wt) store_wt8(rs_dxb, ((size_t)row * W + c * 4) * 2, __builtin_bit_cast(u32x2, ob));
+                    else *(bf16x4*)(dxb + (size_t)row * W + c * 4) = ob;
                 }
             }
         }
@@ -269,22 +282,23 @@ int layernorm_bwd(const bf16_t* dy_bf16, const float* dy_f32, const float* x, co
     const bool want_param = dgamma && dbeta;
     if (want_param && ws_bytes < layernorm_bwd_workspace_bytes(rows, W)) return SPN_ERR_WORKSPACE;
     const int blocks = lnb_blocks(rows);
+    const int wt = (spn_stream_wt() && (uint64_t)rows * W * 4 < 0xfffffff0ull) ? 1 : 0;
     float* wsp = want_param ? ws : nullptr;
     const size_t lds = want_param ? (size_t)4 * 2 * W * sizeof(float) : 0;
 #define SPN_LN_BWD(V_)                                                                                           \
     do {                                                                                                         \
         if (dy_bf16 && W == 256 * V_)                                                                            \
             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_, true>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
-                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W, wt);                            \
         else if (dy_bf16)                                                                                        \
             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, V_, false>), dim3(blocks), dim3(256), lds, st, dy_bf16, x, gamma, \
-                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W, wt);                            \
         else if (W == 256 * V_)                                                                                  \
             hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_, true>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
-                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W, wt);                            \
         else                                                                                                     \
             hipLaunchKernelGGL((layernorm_bwd_kernel<float, V_, false>), dim3(blocks), dim3(256), lds, st, dy_f32, x, gamma,  \
-                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W);                            \
+                               mean, rstd, dx, accumulate_dx, dx_bf16, wsp, rows, W, wt);                            \
     } while (0)
     if (W <= 256) SPN_LN_BWD(1);
     else if (W <= 512) SPN_LN_BWD(2);

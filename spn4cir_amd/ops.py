@@ -413,6 +413,23 @@ def scale_cast_bf16(x, scale_dev, reciprocal=False, ldo=None):
     return out
 
 
+def negtype_head(refer, text, target, tau, neg_type):
+    """clip4cir/models_negtype.py's four in-batch terms at the feature level (spn_negtype_head): fp32 [B, D] raw reference,
+    text and target features -> (loss [1], d_refer, d_text, d_target)."""
+    for n, x in (("refer", refer), ("text", text), ("target", target)):
+        _req(x, torch.float32, n)
+    B, D = refer.shape
+    if text.shape != (B, D) or target.shape != (B, D):
+        raise ValueError("refer / text / target must share one [B, D] shape")
+    dev = refer.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dr, dt, di = (torch.empty(B, D, dtype=torch.float32, device=dev) for _ in range(3))
+    ws = workspace(lib().spn_negtype_workspace_bytes(B, D), dev, "negtype")
+    check(lib().spn_negtype_head(_p(refer), _p(text), _p(target), B, D, 1.0 / tau, int(neg_type), _p(loss), _p(dr), _p(dt), _p(di),
+                                 _p(ws), ws.numel(), _stream()), "negtype_head")
+    return loss, dr, dt, di
+
+
 def bank_step_ok(B, M, Dp, bank):
     """True when bank_step serves this shape (the single-pass kernels: see spn_bank_step_ok)."""
     return bool(lib().spn_bank_step_ok(B, M, Dp, 1 if isinstance(bank, Fp8Bank) else 0))

@@ -293,3 +293,24 @@ def test_tokmax_oracle_matches_reference(golden_dir):
         ref = torch.from_numpy(z[f"{tag}.d_fusion_feats"])
         assert (feats.grad - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item()), tag
         assert abs(temp.grad.item() - float(z[f"{tag}.d_temp"])) < 1e-4 * max(1.0, abs(float(z[f"{tag}.d_temp"]))), tag
+
+
+def test_negtype_oracle_matches_reference_capture(golden_dir):
+    """oracle/negtype.py against the reference's own text_neg_loss / refer_neg_loss / infonce_loss + forward()'s neg_type mask
+    (clip4cir/models_negtype.py:53-134; tests/golden/make_golden_negtype.py): loss and the three feature gradients."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import negtype
+    z = np.load(os.path.join(golden_dir, "negtype.npz"))
+    for tag in ("a", "b"):
+        r, t, i = (torch.from_numpy(z[f"{tag}::{k}"]) for k in ("refer", "text", "target"))
+        tau = float(z[f"{tag}::tau"])
+        for nt in (1, 2, 4, 8, 7, 15, 5, 10):
+            rr, tt, ii = (x.clone().requires_grad_(True) for x in (r, t, i))
+            loss = negtype.loss(rr, tt, ii, tau, nt)
+            loss.backward()
+            assert abs(loss.item() - float(z[f"{tag}::{nt}::loss"])) < 2e-6 * max(1.0, abs(loss.item()))
+            for g, k in ((rr, "refer"), (tt, "text"), (ii, "target")):
+                ref = torch.from_numpy(z[f"{tag}::{nt}::d_{k}"])
+                assert (g.grad - ref).abs().max() < 1e-6 * max(1.0, ref.abs().max().item()), (tag, nt, k)
