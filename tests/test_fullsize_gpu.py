@@ -4,7 +4,7 @@ mode against the dense one at B = 256, the BLIP fusion encoder at 12 layers x 76
 1024), and a trainer step over a 100 000-row fp8 bank.
 
 Gates (same as the small-fixture tests): features 1 - cos <= 1e-3 (north_star), loss within 1e-2, per-parameter gradient
-relative L2 <= 5e-2 against the fp32 CPU oracle (bf16 operands, fp32 accumulation)."""
+relative L2 against the fp32 CPU oracle (bf16 operands, fp32 accumulation) gated at 2 x the observed worst of each test (printed)."""
 import os
 
 import numpy as np
@@ -12,6 +12,9 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+GRAD_GATE_VITL14 = 2.5e-2    # per-parameter relative L2 of the ViT-L/14 text-tower gradients: 2 x the observed worst (1.17e-2 on the
+                             # bf16 bank in all three grouping modes, 1.23e-2 on the e4m3 bank; both on a LayerNorm weight of block 0)
 
 
 def _need_gpu():
@@ -69,7 +72,9 @@ def test_vitl14_every_gradient_matches_oracle(groups):
     for k, ref in g_ref.items():
         assert ref is not None and ref.norm() > 0, k
         worst[k] = _rel(views[k].cpu(), ref)
-    bad = {k: v for k, v in worst.items() if not v < 5e-2}
+    wk = max(worst, key=worst.get)
+    print(f"ViT-L/14 text step (groups {groups}): worst gradient error {worst[wk]:.3e} ({wk})")
+    bad = {k: v for k, v in worst.items() if not v < GRAD_GATE_VITL14}
     assert not bad, bad
     assert len(worst) == len(sd) == 2 + 12 * layers + 3
 
@@ -262,7 +267,10 @@ def test_fp8_bank_trainer_step_100k():
     f_ref, loss_ref, g_ref = _oracle_text_step(sd, ids, refer, ridx, deq, labels, tau)
     assert abs(loss.item() - loss_ref) < 1e-2 * max(1.0, abs(loss_ref))
     views = model.tower.named_views(grads)
-    bad = {k: _rel(views[k].cpu(), r) for k, r in g_ref.items() if not _rel(views[k].cpu(), r) < 5e-2}
+    errs = {k: _rel(views[k].cpu(), r) for k, r in g_ref.items()}
+    wk = max(errs, key=errs.get)
+    print(f"fp8 bank trainer step: worst gradient error {errs[wk]:.3e} ({wk})")
+    bad = {k: v for k, v in errs.items() if not v < GRAD_GATE_VITL14}
     assert not bad, bad
     # the update: torch.optim.AdamW semantics (train_negplus.py:77-83 hyper-parameters) applied to the step's own gradient
     # (a first Adam step is ~ lr * sign(g): comparing against the oracle's gradient would only re-test sign noise)

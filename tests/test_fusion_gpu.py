@@ -46,7 +46,7 @@ def test_blip_fusion_step_matches_reference(golden_dir):
         err = ((g.cpu() - ref).norm() / ref.norm()).item()
         if err > worst[1]:
             worst = (key, err)
-        assert err < 6e-2, (key, err)
+        assert err < 2e-2, (key, err)          # observed worst 8.0e-3
     print("worst relative L2 gradient error:", worst)
     # learnable temperature (blip4cir/models.py:29): dL/dtau against autograd on the reference's q
     qd = qref.double()

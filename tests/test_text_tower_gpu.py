@@ -3,7 +3,7 @@ captured from the reference (tests/golden/tiny_clip.npz, cirplus_step.npz).
 
 Tolerances: the HIP path runs its GEMMs on bf16 operands with fp32 accumulation while the
 reference CPU path is fp32; north_star's gate is 1e-3 cosine on the embeddings.  Gradients
-are compared per parameter tensor in relative L2 norm (5e-2; observed ~1e-2)."""
+are compared per parameter tensor in relative L2 norm (3.5e-2 = 2 x the observed worst, 1.6e-2)."""
 import os
 
 import numpy as np
@@ -69,7 +69,7 @@ def test_step_loss_and_grads_match_reference(golden_dir):
         ref = torch.from_numpy(s["grad_plus::" + key])
         err = ((g.cpu() - ref).norm() / ref.norm().clamp_min(1e-12)).item()
         worst = max(worst, err)
-        assert err < 5e-2, (key, err)
+        assert err < 3.5e-2, (key, err)        # observed worst 1.6e-2
     print("worst per-parameter relative L2 grad error:", worst)
 
 
