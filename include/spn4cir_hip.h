@@ -332,6 +332,16 @@ int spn_text_bwd_tokens(const spn_text_cfg* cfg, const float* params, const void
                         void* acts, const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd,
                         float* grads, void* ws, size_t ws_bytes, void* stream);
 
+/* spn_text_bwd_tokens in phases, for a data-parallel TG-CIR step (tgcir/train.py has no DDP): spn_text_bwd_tokens_head
+ * (the pooled feature's and every token's gradient into the residual gradient + ln_final's gradients), then
+ * spn_text_bwd_layer_deferred / spn_text_bwd_wgrad over layer groups as for spn_text_bwd, then spn_text_bwd_tail_tokens (the
+ * embedding gradients of EVERY position - the padding rows are live here).  Same ws in every phase. */
+int spn_text_bwd_tokens_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                             const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd,
+                             float* grads, void* ws, size_t ws_bytes, void* stream);
+int spn_text_bwd_tail_tokens(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* TG-CIR second-stage head (tgcir/models.py): the per-sample glue between spn_text_fwd_tokens and the
  * bank InfoNCE calls.  All buffers fp32 unless named *_bf16; S = 8 local tokens, G global tokens, NT = G + S <= 16,
  * L <= 640.  The two Linear layers with a GEMM shape (Backbone.text_fc, s_remain_map[0]) are spn_gemm_nt / spn_gemm_tn

@@ -121,6 +121,8 @@ _SIGS = {
     "spn_tg_gate_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "spn_tg_mod_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "spn_text_bwd_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_text_bwd_tokens_head": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "spn_text_bwd_tail_tokens": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),
     "spn_text_bwd_tail": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, sz, vp]),
     "spn_text_bwd_layer_deferred": (i32, [C.POINTER(TextCfg), vp, vp, vp, vp, i32, vp, sz, vp]),

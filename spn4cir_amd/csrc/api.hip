@@ -382,6 +382,21 @@ int spn_text_bwd_tokens(const spn_text_cfg* cfg, const float* params, const void
                            (char*)ws, ws_bytes, ST(stream));
 }
 
+int spn_text_bwd_tokens_head(const spn_text_cfg* cfg, const float* params, const void* weights_bf16, void* acts,
+                             const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd,
+                             float* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !acts || !dfeats || !dtokens || !tok_mean || !tok_rstd || !grads || !ws)
+        return SPN_ERR_ARG;
+    return text_bwd_tokens_head(tc(cfg), params, CBF(weights_bf16), (char*)acts, dfeats, dtokens, tok_mean, tok_rstd, grads,
+                                (char*)ws, ws_bytes, ST(stream));
+}
+
+int spn_text_bwd_tail_tokens(const spn_text_cfg* cfg, const int32_t* ids, void* acts, float* grads, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (!cfg || !ids || !acts || !grads || !ws) return SPN_ERR_ARG;
+    return text_bwd_tail_tokens(tc(cfg), ids, (char*)acts, grads, (char*)ws, ws_bytes, ST(stream));
+}
+
 size_t spn_tg_ws_bytes(int B, int C) { return tg_ws_bytes(B, C); }
 
 int spn_tg_tokenlearn_fwd(const float* z, const float* w, const float* bias, float* attn, float* mod_tokens, int B, int L,

@@ -172,6 +172,11 @@ int text_fwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, con
 int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
                     const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads,
                     char* ws, size_t ws_bytes, hipStream_t st);
+int text_bwd_tokens_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
+                         const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads, char* ws,
+                         size_t ws_bytes, hipStream_t st);
+int text_bwd_tail_tokens(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                         hipStream_t st);
 int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
                   float* grads, char* ws, size_t ws_bytes, hipStream_t st);
 int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l, char* ws,

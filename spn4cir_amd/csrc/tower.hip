@@ -778,19 +778,35 @@ int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads
 }
 
 // backward of text_fwd_tokens: dfeats [B, D] (pooled feature) and dtokens [B*L, W] (ln_final output of every row)
-int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
-                    const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads,
-                    char* ws, size_t ws_bytes, hipStream_t st) {
+// head of the token variant: text_bwd_head (dx = scatter of the EOT-row gradient) + ln_final backward of every row.  With
+// text_bwd_layer[_deferred] / text_bwd_wgrad and text_bwd_tail_tokens this is text_bwd_tokens in phases (TG-CIR under data
+// parallelism: a layer group's range goes to the all-reduce while the layers below still run).
+int text_bwd_tokens_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
+                         const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads, char* ws,
+                         size_t ws_bytes, hipStream_t st) {
     if (c.T > 0) return SPN_ERR_ARG;
-    SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));   // dx = scatter of the EOT-row gradient
+    SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));
     TextBwdWs w;
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));
     TextLayout t;
     text_layout(c, &t);
     TextActs A = text_acts_at(acts, c);
-    // + ln_final backward of every row, accumulated into dx (and its bf16 mirror) and into ln_final's gradients
-    SPN_TRY(layernorm_bwd(nullptr, dtokens, A.x_final, params + t.lnf_g, tok_mean, tok_rstd, w.dx, 1, w.dxb, grads + t.lnf_g,
-                          grads + t.lnf_b, 1, c.B * c.L, c.W, w.opws, w.opws_bytes, st));
+    return layernorm_bwd(nullptr, dtokens, A.x_final, params + t.lnf_g, tok_mean, tok_rstd, w.dx, 1, w.dxb, grads + t.lnf_g,
+                         grads + t.lnf_b, 1, c.B * c.L, c.W, w.opws, w.opws_bytes, st);
+}
+
+int text_bwd_tail_tokens(const TextCfg& c, const int32_t* ids, char* acts, float* grads, char* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    if (c.T > 0) return SPN_ERR_ARG;
+    return text_bwd_tail_impl(c, ids, acts, grads, ws, ws_bytes, true, st);
+}
+
+int text_bwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
+                    const float* dfeats, const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads,
+                    char* ws, size_t ws_bytes, hipStream_t st) {
+    if (c.T > 0) return SPN_ERR_ARG;
+    // dx = scatter of the EOT-row gradient + ln_final backward of every row, accumulated into dx (and its bf16 mirror)
+    SPN_TRY(text_bwd_tokens_head(c, params, wb, acts, dfeats, dtokens, tok_mean, tok_rstd, grads, ws, ws_bytes, st));
     if (!tn_group_on()) {
         for (int l = c.layers - 1; l >= 0; --l) SPN_TRY(text_bwd_layer(c, params, wb, acts, grads, l, ws, ws_bytes, st));
     } else {       // as text_bwd: data path of every block first, then the weight gradients in grouped launches

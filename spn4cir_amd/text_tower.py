@@ -230,6 +230,48 @@ class TextTower:
                                         _p(self._ws), self._ws.numel(), _stream()), "text_bwd_tokens")
         return self.grads
 
+    def backward_tokens_phased(self, dfeats, dtokens, on_span_ready, wgrad_groups=None):
+        """backward_tokens() in phases (TG-CIR under data parallelism): on_span_ready(start, end) right after the launches that
+        finish a flat-gradient range - head (ln_final + text_projection), then the blocks group by group (wgrad_groups: block
+        counts from the top, each group's weight gradients in one grouped launch behind its data path), then the embeddings."""
+        ids = self._last
+        if ids is None or getattr(self, "_tok_stats", None) is None:
+            raise RuntimeError("backward_tokens_phased() without a preceding forward_tokens()")
+        B, L = ids.shape
+        cfg = self._buffers(B, L, True, 0)
+        dfeats, dtokens = dfeats.contiguous(), dtokens.contiguous()
+        if dtokens.dtype != torch.float32 or dtokens.numel() != B * L * self.width:
+            raise ValueError("dtokens must be fp32 [B, L, W]")
+        ws, n = _p(self._ws), self._ws.numel()
+        spans = self.layer_spans()
+        check(lib().spn_text_bwd_tokens_head(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats), _p(dtokens),
+                                             _p(self._tok_stats[0]), _p(self._tok_stats[1]), _p(self.grads), ws, n, _stream()),
+              "text_bwd_tokens_head")
+        on_span_ready(*spans[0])
+        if os.environ.get("SPN_TN_GROUP", "1")[:1] == "0" or wgrad_groups is None:
+            for i, l in enumerate(reversed(range(self.layers))):
+                check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(self.grads), l,
+                                               ws, n, _stream()), "text_bwd_layer")
+                on_span_ready(*spans[1 + i])
+        else:
+            if sum(wgrad_groups) != self.layers or any(g <= 0 or g > 12 for g in wgrad_groups):
+                raise ValueError(f"wgrad_groups {wgrad_groups} must split {self.layers} layers into groups of 1..12")
+            hi = self.layers
+            for g in wgrad_groups:
+                lo = hi - g
+                for l in reversed(range(lo, hi)):
+                    check(lib().spn_text_bwd_layer_deferred(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts),
+                                                            _p(self.grads), l, ws, n, _stream()), "text_bwd_layer_deferred")
+                check(lib().spn_text_bwd_wgrad(C.byref(cfg), _p(self._acts), _p(self.grads), lo, hi, ws, n, _stream()),
+                      "text_bwd_wgrad")
+                for l in reversed(range(lo, hi)):
+                    on_span_ready(*spans[1 + (self.layers - 1 - l)])
+                hi = lo
+        check(lib().spn_text_bwd_tail_tokens(C.byref(cfg), _p(ids), _p(self._acts), _p(self.grads), ws, n, _stream()),
+              "text_bwd_tail_tokens")
+        on_span_ready(*spans[-1])
+        return self.grads
+
     def backward_phased(self, dfeats, on_span_ready, wgrad_groups=None, embed_early=False):
         """Same as backward(), but calls on_span_ready(start, end) right after the launches that
         finish the flat-gradient range [start, end) have been enqueued (tail+head params first, then

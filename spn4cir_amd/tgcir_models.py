@@ -472,8 +472,13 @@ class TgcirStage2Trainer:
         dq = self.loss_dp.backward(ctx)[:, :head.C].contiguous()
         dfeats, dtokens = head.backward(ops.combine_l2norm_bwd(q, inv, dq))
         self.red_head.on_span_ready(0, head.n_params)
-        text.backward_tokens(dfeats, dtokens)
-        self.red_text.on_span_ready(0, text.n_params)
+        if self.world > 1:
+            # layer groups (7 + 3 + 2 of 12): a group's gradient range is all-reduced while the blocks below still run
+            from .trainer import wgrad_groups
+            text.backward_tokens_phased(dfeats, dtokens, self.red_text.on_span_ready, wgrad_groups(text.layers, self.world))
+        else:
+            text.backward_tokens(dfeats, dtokens)
+            self.red_text.on_span_ready(0, text.n_params)
         self.red_head.finish()
         self.red_text.finish()
         self.step_count += 1

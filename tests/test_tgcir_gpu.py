@@ -87,9 +87,25 @@ def test_text_tower_token_output_and_backward():
     dtok = torch.randn(tok_ref.shape, generator=g) * 0.1
     dfe = torch.randn(feats_ref.shape, generator=g)
     ((tok_ref * dtok).sum() + (feats_ref * dfe).sum()).backward()
-    grads = t.named_views(t.backward_tokens(dfe.cuda(), dtok.cuda()))
+    flat = t.backward_tokens(dfe.cuda(), dtok.cuda()).clone()
+    grads = t.named_views(flat)
     for k, v in grads.items():
         assert rel(v, sdd[k].grad) < 5e-2, k           # the training path's per-parameter gate
+    # the same backward pass in phases (spn_text_bwd_tokens_head / layer groups / spn_text_bwd_tail_tokens): every span reported
+    # exactly once, and the gradients bit-identical when the grouping is the one-call form's
+    for groups in (None, [c["layers"]], [1] * c["layers"]):
+        t.forward_tokens(ids.cuda())
+        seen = []
+        flat2 = t.backward_tokens_phased(dfe.cuda(), dtok.cuda(), lambda a, b: seen.append((a, b)), groups)
+        assert sorted(seen) == sorted(t.layer_spans()) and len(seen) == c["layers"] + 2
+        if groups == [c["layers"]]:
+            # one group = what spn_text_bwd_tokens launches: same kernels, same order - bit-identical behind the embeddings (their
+            # gradient is accumulated with float atomics: last-bit run-to-run differences)
+            e0 = t.layer_spans()[-1][1]
+            assert torch.equal(flat2[e0:], flat[e0:]), groups
+            assert rel(flat2[:e0], flat[:e0]) < 1e-5
+        else:
+            assert rel(flat2, flat) < 2e-2, groups           # other groupings split the token reduction differently (fp32 order)
 
 
 def test_tgcir_step_matches_reference(golden_dir):
