@@ -2062,6 +2062,14 @@ static LargeSave large_save_at(void* base, int B, int M) {
     s.tmax = (float*)p;
     return s;
 }
+// SPN_BANK_S160=0: 128..256 queries stay on the 256 x 256-tile statistics GEMM (A/B switch)
+static bool bank_s160_on() {
+    static const bool on = [] {
+        const char* e = spn_env("SPN_BANK_S160");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 static bool bank_gemm_on() {
     static const bool use_gemm = [] {
         const char* e = spn_env("SPN_BANK_GEMM");
@@ -2148,6 +2156,25 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
     if (use_gemm && !a.bank_scale && !a.group && a.B >= 128 && a.D % 64 == 0) {
         const int nt = gemm_bank_stats_tiles(a.M, a.D);
         if (ws_bytes < (size_t)nt * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
+        if (bank_s160_on() && bank_stats160_ok(a.B, a.D, a.ldq)) {
+            // 128..256 queries: the 160-row-tile kernel (bank3.hip: every CU pulls, three bank k tiles in flight per CU); with a
+            // save buffer it keeps p TRANSPOSED ([bank row][query], the layout of the dq GEMM's G^T operand)
+            const int nt160 = bank_stats160_tiles(a.M);
+            {
+                const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
+                ProfScope prof(PK_BANK_FWD, bytes, st);
+                if (zsave && bank_saved_path_large(a)) {
+                    const LargeSave sv = large_save_at(zsave, a.B, a.M);
+                    rc = bank_stats160(a.q, a.ldq, a.bank, a.labels, a.B, a.M, a.D, a.m_begin, a.inv_tau, ws, sv.P, sv.tmax, st);   // p^T [M][B] in the P region
+                } else {
+                    rc = bank_stats160(a.q, a.ldq, a.bank, a.labels, a.B, a.M, a.D, a.m_begin, a.inv_tau, ws, nullptr, nullptr, st);
+                }
+            }
+            if (rc) return rc;
+            hipLaunchKernelGGL(bank_stats_fold_kernel, dim3((a.B + 3) / 4), dim3(256), 0, st, ws, nt160, a.B, stats);
+            SPN_CHECK_LAUNCH();
+            return SPN_OK;
+        }
         {
             const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
             ProfScope prof(PK_BANK_FWD, bytes, st);
@@ -2213,6 +2240,11 @@ int bank_grad_q(const BankArgs& a, const float* row_lse, float label_smoothing, 
         if (ws_bytes < gemm_tn_workspace_bytes(a.M, a.B, a.D)) return SPN_ERR_WORKSPACE;
         const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 6 + (double)a.B * 16;
         ProfScope prof(PK_BANK_BWD, bytes, st);
+        if (bank_s160_on() && bank_stats160_ok(a.B, a.D, a.ldq)) {      // the forward call kept p^T [M][B]: scale it into G^T, no transpose
+            rc = bank_gt_scale(sv.P, sv.Gt, sv.tmax, row_lse, a.labels, a.B, a.M, a.m_begin, label_smoothing, 1.0f / (float)M_total, st);
+            if (rc) return rc;
+            return gemm_tn(sv.Gt, a.bank, a.M, a.B, a.D, a.B, a.D, dq, a.D, grad_scale * a.inv_tau, 0, nullptr, ws, ws_bytes, st);
+        }
         hipLaunchKernelGGL(bank_p_to_gt_kernel, dim3(sv.mpad / 64, (a.B + 63) / 64), dim3(256), 0, st, sv.P, sv.ldp, sv.tmax, row_lse,
                            a.labels, a.B, a.M, a.m_begin, label_smoothing, 1.0f / (float)M_total, sv.Gt, gemm_bank_stats_bn(a.D) == 128 ? 7 : 8);
         SPN_CHECK_LAUNCH();

@@ -225,6 +225,13 @@ int bank2_grad_q(const BankArgs& a, const float* zsaved, const float* row_lse, f
 bool bank_step_ok(const BankArgs& a);
 int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean, float* dq,
               hipStream_t st);
+// bank3.hip: forward statistics for 128..256 queries in 160-row bank tiles (one workgroup per CU, deep bank prefetch)
+bool bank_stats160_ok(int B, int D, int ldq);
+int bank_stats160_tiles(int M);
+int bank_stats160(const bf16_t* q, int ldq, const bf16_t* bank, const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau,
+                  float* partial, bf16_t* Pt, float* tmax, hipStream_t st);
+int bank_gt_scale(const bf16_t* Pt, bf16_t* Gt, const float* tmax, const float* lse, const int64_t* labels, int B, int M, int m_begin,
+                  float ls, float inv_m, hipStream_t st);
 // finalize on the owner of all shards' stats: row_lse, row_loss and the mean loss
 int bank_loss_finalize(const float* stats, int nshards, int B, int64_t M_total, float label_smoothing,
                        float* row_lse, float* row_loss, float* loss_mean, hipStream_t st);
