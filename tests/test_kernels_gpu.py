@@ -247,7 +247,10 @@ def attn_ref(q, k, v, B, H, Lq, Lk, causal, key_bias, scale):
                                                    (2, 1, 64, 64, False, False), (1, 1, 65, 65, True, False),
                                                    (1, 2, 96, 96, False, True), (1, 2, 113, 113, False, True),
                                                    (1, 1, 128, 128, True, False), (2, 2, 16, 577, False, False),
-                                                   (1, 2, 64, 65, False, True), (1, 1, 33, 100, False, False)])
+                                                   (1, 2, 64, 65, False, True), (1, 1, 33, 100, False, False),
+                                                   # more (sequence, head) pairs than resident workgroups: the persistent backward
+                                                   # walk (two pairs per workgroup) loops; 513 pairs leave the last slot idle
+                                                   (70, 12, 77, 77, True, False), (171, 3, 40, 40, False, True)])
 def test_attention_fwd_bwd(ops, B, H, Lq, Lk, causal, bias):
     g = torch.Generator().manual_seed(B * 1000 + Lq)
     W = H * 64

@@ -8,7 +8,7 @@ extern "C" __global__ __launch_bounds__(320) void k(float* p) {
     p[threadIdx.x] = s[(threadIdx.x + 1) % 320];
 }
 int main() {
-    for (int lds : {30464, 32768, 40960, 52224, 53248, 53760, 54096, 54272, 54432, 54613, 54784, 65536, 77760, 81920}) {
+    for (int lds : {54613, 65536, 73728, 75000, 77760, 78848, 79872, 80352, 80896, 81920}) {
         int n = 0;
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 320, lds);
