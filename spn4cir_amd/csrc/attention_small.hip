@@ -334,12 +334,12 @@ __device__ __forceinline__ void attn_bwd_phase1_pick(int nkt, A&&... args) {
     else if constexpr (K > 0) attn_bwd_phase1_pick<NT, BIAS, K - 1>(nkt, args...);
 }
 
-// NH = (sequence, head) pairs a workgroup holds at once.  A 5-wave workgroup puts two waves on SIMD 0 and the dispatcher starts every
-// workgroup there, so a second resident workgroup needs four wave slots of SIMD 0: above 128 registers it does not fit and the CU
-// runs ONE workgroup (PMC: 4.9 resident waves per CU, whatever the occupancy query says), loads and phases strictly in turn.  Two pairs
-// in one 10-wave workgroup (NT <= 5: 2 x 78.5 KB of LDS) fill the SIMDs 3 | 3 | 2 | 2, the second pair takes its tiles in reverse so
-// that the causal triangle's costs add up evenly per SIMD, and the walk is persistent: the rows of the NEXT pair of pairs are fetched
-// into registers (2 x 16 B per matrix and thread) while this one is computed.
+// NH = (sequence, head) pairs a workgroup holds at once.  With one pair per 5-wave workgroup (78.5 KB of LDS) a CU held ONE
+// workgroup, not the two the occupancy query reports (SQ PMC: 4.9 resident waves per CU), so loads, phase 1 and phase 2 ran strictly
+// in turn on 5 waves over 4 SIMDs (59 us = 23 us of loads + the phases).  Two pairs in one 10-wave workgroup (NT <= 5: 2 x 78.5 KB
+// in one allocation) fill the SIMDs 3 | 3 | 2 | 2; the second pair takes its tiles in reverse so that the causal triangle's costs
+// add up evenly per SIMD; and the walk is persistent: the rows of the NEXT two pairs are fetched into registers (2 x 16 B per matrix
+// and thread) while these are computed.  9.5 resident waves per CU, 45 us.
 template <int NT, int NH, bool BIAS>
 __global__ __launch_bounds__(NT * NH * 64) void attention_small_bwd_kernel(AttnBwdArgs g) {
     const AttnArgs& a = g.f;
