@@ -654,7 +654,7 @@ def main():
             out["packed_eot"] = packed
         if alt:
             out["bank_mode_alt"] = alt
-        if not args.no_recall:
+        if world == 1 and not args.no_recall:     # checker legs run at N = 1 only: the other ranks would sit in the exit barrier
             rec = recall_block(args, sd, model, dev)
             if rec:
                 out["recall_at_10"] = rec["recall_at_10"]
