@@ -261,14 +261,26 @@ __device__ __forceinline__ void tn_stage(__amdgpu_buffer_rsrc_t rs, char* sT, in
 
 // fragment for the 16 columns [cb, cb+16) and the 32 k-rows [ks*32, ks*32+32): lane l gets
 // column cb + (l&15), k = ks*32 + (l>>4)*8 + 0..7
-__device__ __forceinline__ bf16x8 tn_frag(const char* sT, int cb, int ks, int lane) {
-    union { s16x4 h[2]; bf16x8 v; } u;
+// The reads are the asm form (common.h): in front of the builtin hipcc puts `s_waitcnt vmcnt(0)` while the NEXT k tile's LDS-DMA is
+// in flight (it cannot prove the read does not alias the DMA's destination), which serialised load and MFMA phases.  The caller
+// waits with wait_lgkm<0>() and converts with tn_tie().
+struct TnFrag { s16x4 h[2]; };
+__device__ __forceinline__ TnFrag tn_frag(const char* sT, int cb, int ks, int lane) {
+    TnFrag u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int krow = ks * 32 + (lane >> 4) * 8 + h * 4 + ((lane & 15) >> 2);
         const int p32 = (cb >> 4) ^ tn_f(krow);
-        u.h[h] = lds_tr16_b64(sT + krow * 256 + p32 * 32 + (lane & 3) * 8);
+        u.h[h] = lds_tr16_b64_asm(sT + krow * 256 + p32 * 32 + (lane & 3) * 8);
     }
+    return u;
+}
+__device__ __forceinline__ bf16x8 tn_tie(TnFrag& f) {
+    lds_tie(f.h[0]);
+    lds_tie(f.h[1]);
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = f.h[0];
+    u.h[1] = f.h[1];
     return u.v;
 }
 
@@ -327,11 +339,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_tn_kernel(const bf16_t* __re
         const char* sB = sA + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            TnFrag fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = tn_frag(sA, wr * 64 + i * 16, ks, lane);
+                fb[i] = tn_frag(sB, wc * 64 + i * 16, ks, lane);
+            }
+            wait_lgkm<0>();
             bf16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = tn_frag(sA, wr * 64 + i * 16, ks, lane);
-                b[i] = tn_frag(sB, wc * 64 + i * 16, ks, lane);
+                a[i] = tn_tie(fa[i]);
+                b[i] = tn_tie(fb[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
