@@ -209,6 +209,12 @@ int spn_negtype_head(const float* refer, const float* text, const float* target,
  * bf16) and run the same bf16 MFMA path with fp32 accumulation; q stays bf16.  Same statistics / finalize /
  * dq contract as the bf16 entry points above. */
 int spn_bank_quantize_fp8(const float* bank_f32, int M, int D, int Dp, void* bank_fp8, float* bank_scale, void* stream);
+/* bank_bf16 [M, D] = bf16(e4m3 x row scale): the image the fp8 calls expand into scratch once per pass at >= 128 queries.  A
+ * caller that scores >= 256 queries per call every step (config 5 at its per-GPU batch of 256: the pass is MFMA-bound there,
+ * not byte-bound) keeps this image next to the e4m3 bytes and passes it to the bf16 entry points: same values, no expansion
+ * per pass, and the saved-probabilities backward (spn_bank_stats_fwd_save / spn_bank_grad_q_saved) applies.  No reference
+ * counterpart (zscir/train_bank.py holds an fp32 bank). */
+int spn_bank_dequant_fp8(const void* bank_fp8, const float* bank_scale, int M, int D, void* bank_bf16, void* stream);
 /* workspace for the two fp8 calls: at B >= 128 it includes room for a bf16 expansion of the shard, made once per
  * pass (every bank tile then serves many query tiles; the per-tile dequantisation only pays at small batches).  With
  * only spn_bank_workspace_bytes() the calls still work and dequantise per tile. */

@@ -136,6 +136,7 @@ _SIGS = {
     "spn_vision_fwd_train": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, vp, vp]),
     "spn_vision_bwd": (i32, [C.POINTER(VisionCfg), vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_bank_quantize_fp8": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "spn_bank_dequant_fp8": (i32, [vp, vp, i32, i32, vp, vp]),
     "spn_bank_stats_fwd_fp8": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "spn_bank_grad_q_fp8": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, f32, i64, f32, vp, vp, sz, vp]),
     "spn_preprocess_image": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

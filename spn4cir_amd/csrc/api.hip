@@ -249,6 +249,10 @@ int spn_bank_quantize_fp8(const float* bank, int M, int D, int Dp, void* bank_fp
     return bank_quantize_fp8(bank, M, D, Dp, (uint8_t*)bank_fp8, scale, ST(stream));
 }
 
+int spn_bank_dequant_fp8(const void* bank_fp8, const float* bank_scale, int M, int D, void* bank_bf16, void* stream) {
+    return bank_dequant_fp8((const uint8_t*)bank_fp8, bank_scale, M, D, (bf16_t*)bank_bf16, ST(stream));
+}
+
 int spn_bank_stats_fwd_fp8(const void* q_bf16, int ldq, const void* bank_fp8, const float* bank_scale,
                            const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau, float* stats, void* ws,
                            size_t ws_bytes, void* stream) {

@@ -2015,6 +2015,16 @@ __global__ void bank_dequant_fp8_kernel(const uint8_t* __restrict__ src, const f
     }
 }
 
+// the bf16 image of an e4m3 bank (exactly what the kernels' per-pass expansion holds): for callers that keep it across steps
+int bank_dequant_fp8(const uint8_t* data, const float* scale, int M, int D, bf16_t* out, hipStream_t st) {
+    if (!data || !scale || !out || M <= 0 || D <= 0 || D % 16) return SPN_ERR_ARG;
+    const size_t n16 = (size_t)M * D / 16;
+    const int blocks = (int)((n16 + 255) / 256 > 4096 ? 4096 : (n16 + 255) / 256);
+    hipLaunchKernelGGL(bank_dequant_fp8_kernel, dim3(blocks), dim3(256), 0, st, data, scale, out, n16, D);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 static constexpr int FP8_EXPAND_MIN_B = 128;
 
 size_t bank_workspace_bytes_fp8(int B, int M, int D) {

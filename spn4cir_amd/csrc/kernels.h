@@ -202,6 +202,7 @@ struct BankArgs {
 };
 // fp32 [M, D] -> OCP e4m3 [M, Dp] (zero padded) with one fp32 scale per row (row max -> 448)
 int bank_quantize_fp8(const float* bank, int M, int D, int Dp, uint8_t* out, float* scale, hipStream_t st);
+int bank_dequant_fp8(const uint8_t* data, const float* scale, int M, int D, bf16_t* out, hipStream_t st);
 // forward: per-row partial softmax statistics over this shard
 //   stats[b] = {max, sum exp(l - max), sum l, label logit (or -inf if the label is not in the shard)}
 // zsave (optional, bank_saved_bytes()): receives the logits when bank_saved_path(a) - hand it to bank_grad_q as zsaved

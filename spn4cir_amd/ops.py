@@ -263,6 +263,28 @@ class Fp8Bank:
         """fp32 [M, Dp] exactly as the kernels see it before the bf16 rounding."""
         return self.data.view(torch.float8_e4m3fn).float() * self.scale[:, None]
 
+    def bf16_image(self):
+        """bf16 [M, Dp] = the expansion the fp8 kernels make per pass at large batches, made ONCE and kept
+        (spn_bank_dequant_fp8).  Used by the bank calls from FP8_IMAGE_MIN_B queries per call on."""
+        if getattr(self, "_image", None) is None:
+            M, Dp = self.data.shape
+            img = torch.empty(M, Dp, dtype=torch.bfloat16, device=self.data.device)
+            check(lib().spn_bank_dequant_fp8(_p(self.data), _p(self.scale), M, Dp, _p(img), _stream()), "bank_dequant_fp8")
+            self._image = img
+        return self._image
+
+
+# From this many queries per call on the bank pass is bound by MFMA issue, not by the bank's bytes: an e4m3 bank is used through
+# its kept bf16 image (same values as the kernels' per-pass expansion; +2 B per element of HBM) and the saved-probabilities
+# backward applies.  Below it the e4m3 bytes are streamed (half the bytes of the one HBM stream of the loss).
+FP8_IMAGE_MIN_B = 256
+
+
+def _bank_operand(bank, B):
+    if isinstance(bank, Fp8Bank) and B >= FP8_IMAGE_MIN_B:
+        return bank.bf16_image()
+    return bank
+
 
 def prepare_bank(bank_f32, dtype="bf16"):
     """fp32 [M, D] (L2-normalised rows) -> device bf16 [M, bank_dim(D)], zero padded; dtype="fp8" -> Fp8Bank."""
@@ -338,6 +360,7 @@ def bank_stats_fwd(q_bf16, bank_bf16, labels, inv_tau, m_begin=0, save=None):
     backward pass (spn_bank_stats_fwd_save)."""
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
+    bank_bf16 = _bank_operand(bank_bf16, B)
     stats = torch.empty(B, 4, dtype=torch.float32, device=q_bf16.device)
     fp8 = isinstance(bank_bf16, Fp8Bank)
     ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
@@ -377,6 +400,7 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
     """saved: the buffer the matching bank_stats_fwd(..., save=...) call filled (spn_bank_grad_q_saved)."""
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
+    bank_bf16 = _bank_operand(bank_bf16, B)
     dq = torch.empty(B, Dp, dtype=torch.float32, device=q_bf16.device)
     fp8 = isinstance(bank_bf16, Fp8Bank)
     ws = workspace((lib().spn_bank_workspace_bytes_fp8 if fp8 else lib().spn_bank_workspace_bytes)(B, M, Dp), q_bf16.device,
@@ -432,7 +456,7 @@ def negtype_head(refer, text, target, tau, neg_type):
 
 def bank_step_ok(B, M, Dp, bank):
     """True when bank_step serves this shape (the single-pass kernels: see spn_bank_step_ok)."""
-    return bool(lib().spn_bank_step_ok(B, M, Dp, 1 if isinstance(bank, Fp8Bank) else 0))
+    return bool(lib().spn_bank_step_ok(B, M, Dp, 1 if isinstance(_bank_operand(bank, B), Fp8Bank) else 0))
 
 
 def bank_step(q_bf16, bank_bf16, labels, inv_tau, grad_scale, save):
@@ -441,6 +465,7 @@ def bank_step(q_bf16, bank_bf16, labels, inv_tau, grad_scale, save):
     B, Dp = q_bf16.shape
     M = bank_bf16.shape[0]
     dev = q_bf16.device
+    bank_bf16 = _bank_operand(bank_bf16, B)
     fp8 = isinstance(bank_bf16, Fp8Bank)
     data, scale = (bank_bf16.data, bank_bf16.scale) if fp8 else (bank_bf16, None)
     if save is None or not save.is_cuda or save.numel() * save.element_size() < lib().spn_bank_logits_bytes(B, M):

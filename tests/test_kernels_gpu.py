@@ -366,6 +366,36 @@ def test_bank_fused_single_pass(ops, B, M, D, tau, fp8):
     _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=False)
 
 
+def test_bank_fp8_large_batch_uses_kept_image(ops):
+    """From ops.FP8_IMAGE_MIN_B queries per call on an e4m3 bank is scored through its bf16 image, expanded once and kept
+    (spn_bank_dequant_fp8): the image is bf16(e4m3 x row scale) bit for bit, the pair of calls gives exactly what the bf16
+    entry points give on that image (saved-probabilities backward included), and both match the oracle on the dequantised
+    bank."""
+    from oracle import bank_loss
+    B, M, D, tau = 256, 5000, 768, 0.02
+    text, refer, bank, ridx, labels = _bank_case(B, M, D, 11)
+    fb = ops.prepare_bank(dev(bank), "fp8")
+    img = fb.bf16_image()
+    assert img is fb.bf16_image()                                  # kept
+    assert torch.equal(img.cpu(), fb.dequantize().to(torch.bfloat16).cpu())
+    assert B >= ops.FP8_IMAGE_MIN_B
+    _, qb, _ = ops.combine_l2norm_fwd(dev(refer), dev(ridx), dev(text))
+    out = []
+    for bk in (fb, img):
+        save = ops.bank_logits_buffer(B, M, "cuda")
+        stats = ops.bank_stats_fwd(qb, bk, dev(labels), 1.0 / tau, save=save)
+        lse, row, mean = ops.bank_loss_finalize(stats, M)
+        dq = ops.bank_grad_q(qb, bk, dev(labels), 1.0 / tau, lse, 1.0 / B, saved=save)
+        out.append((mean.cpu(), dq.cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    qr = qb[:, :D].float().cpu()
+    br = fb.dequantize()[:, :D].cpu()
+    loss_ref = float(bank_loss.infonce_stats(qr, br, labels, tau)[2].mean())
+    dq_ref = bank_loss.infonce_grad_q(qr, br, labels, tau)
+    assert abs(float(out[0][0]) - loss_ref) < 2e-3 * max(1.0, abs(loss_ref))
+    assert rel_err(out[0][1][:, :D], dq_ref) < 1.5e-2
+
+
 @pytest.mark.parametrize("noise", [3.0, 3.5, 5.0])        # smallest 1 - p_label of the batch ~ 1e-4, 1e-3, 4e-2
 def test_bank_confident_rows(ops, noise):
     """Queries that (nearly) coincide with their target row, p_label -> 1: the gradient is the small difference
