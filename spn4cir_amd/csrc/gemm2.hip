@@ -546,7 +546,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN 
 #endif
 #define SPN_SLOT_BAR(LVL) do { if (SPN_EXP_NOBAR < LVL) { __builtin_amdgcn_s_barrier(); for (int xb__ = 0; xb__ < SPN_EXP_XBAR; ++xb__) __builtin_amdgcn_s_barrier(); } } while (0)
 template <int BM, int BN, int WM, int WN, int STAGES, int MODE, int ACT, int SCHED, int BKT>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
+__global__ __launch_bounds__(WM* WN * 64, (STAGES * (BM + BN) * BKT * 2 <= 80 * 1024 ? 2 : 1) * (WM * WN) / 4) void gemm_nt2_kernel(const bf16_t* __restrict__ A,
                                                                             const bf16_t* __restrict__ B, int M,
                                                                             int N, int K, int lda, int ldb,
                                                                             GemmEpilogue ep) {
@@ -1588,6 +1588,18 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
 #endif
         case 1: return dispatch_nt2<256, 128, 4, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
         case 3:   // default: 256x256x64, 8 waves; SPN_GEMM_NT_PHASED=0 selects the one-barrier-per-k-tile loop
+#ifdef SPN_EXPERIMENTS
+            {
+                // SPN_GEMM_TWO_WG=1 (experiments build): the short-k, wide products (qkv / fc / d-activation: K <= 768, N >= 2048) on
+                // 128 x 256 x 32 tiles with three 24 KB stages - 72 KB of LDS and <= 128 registers per wave, so that TWO workgroups
+                // share a CU and one's epilogue runs under the other's k loop.  Measured in the step (rocprofv3, round 4): fc +
+                // QuickGELU 119.6 -> 147.2 us, d-activation 108.6 -> 131.4, qkv 70 -> 87.8, step 13.28 -> 14.09 ms: the one-barrier
+                // loop on a tile with 1.5x the LDS-DMA bytes per flop loses more than the hidden epilogue returns.
+                static const int two_wg = [] { const char* v = spn_env("SPN_GEMM_TWO_WG"); return v ? atoi(v) : 0; }();
+                if (two_wg && K <= 768 && N >= 2048 && M % 128 == 0 && N % 256 == 0 && K % 32 == 0)
+                    return dispatch_nt2<128, 256, 2, 4, 3, 32>(A, B, M, N, K, lda, ldb, mode, e2, st);
+            }
+#endif
             if (nt_phased()) {
 #ifdef SPN_EXPERIMENTS
                 int rc = SPN_OK;
