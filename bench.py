@@ -65,9 +65,9 @@ def parse():
                    help="N > 1: skip the short extra measurement of the OTHER bank mode reported as bank_mode_alt")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
-    p.add_argument("--prof-every", type=int, default=5,
+    p.add_argument("--prof-every", type=int, default=17,
                    help="HIP-event pairs go around every n-th launch of the dominant kernel inside the timed region "
-                        "(a stride coprime to the 8-GEMM period of a layer samples every shape evenly; 1 = all launches)")
+                        "(a stride coprime to the 392 gemm_nt launches of a step - 2^3 x 7^2 - samples every shape evenly; 1 = all launches)")
     p.add_argument("--kernel-pass-steps", type=int, default=3,
                    help="extra steps AFTER the timed region with every kernel class timed, for the kernels[] breakdown")
     p.add_argument("--no-packed", action="store_true", help="skip the extra (not headline) packed-EOT measurement")
@@ -483,9 +483,9 @@ def main():
     lib = _lib.lib()
     prof = not args.no_prof
     # Live roofline measurement: HIP-event pairs around the launches of the DOMINANT kernel (gemm_nt, checked
-    # below against the all-kernel pass) inside the timed region, around every --prof-every-th launch (default 5:
-    # ~390 samples in 20 steps, every GEMM shape hit evenly).  An event pair keeps a launch from overlapping its
-    # neighbours: bracketing every kernel class costs 7 % of the step, every gemm_nt launch 2.5 %, every 5th 0.7 %.
+    # below against the all-kernel pass) inside the timed region, around every --prof-every-th launch (default 17:
+    # ~460 samples in 20 steps, every GEMM shape hit evenly).  An event pair keeps a launch from overlapping its
+    # neighbours: bracketing every kernel class costs 7 % of the step, every gemm_nt launch 2.5 %, every 5th 0.7 %, every 17th 0.2 %.
     # The full per-class breakdown comes from a few extra steps after the timed region.
     DOM = 0
     if prof:
