@@ -44,8 +44,8 @@ FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 
 # priced on its algorithmic bytes (fwd: read qkv, write o = 8 W B per token; bwd: read qkv, o, dO, write dqkv = 16 W B)
 KERNELS = {0: ("gemm_nt_kernel", "mfma"), 1: ("gemm_tn (grouped weight gradients, no split-K, + tail reduce)", "mfma"),
            2: ("attention_small_fwd_kernel", "hbm"), 3: ("attention_small_bwd_kernel", "hbm"),
-           4: ("bank forward pass (GEMM path at B >= 128, keeps p for the backward pass)", "hbm"),
-           5: ("bank backward pass (G^T transpose + dq GEMM from the saved p at B >= 128)", "hbm")}
+           4: ("bank forward pass (160-row-tile kernel at 128 <= B <= 256, keeps p^T for the backward pass)", "hbm"),
+           5: ("bank backward pass (G^T scale + dq GEMM + split-k fold from the saved p^T at B >= 128)", "hbm")}
 
 
 def parse():
