@@ -98,6 +98,7 @@ def self_launch(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.pop("MASTER_PORT", None)          # the default set above belongs to single-process runs
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's peer mappings need it on this driver
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = p.stdout.splitlines()
     result = [l for l in lines if l.startswith('{"metric"')]
