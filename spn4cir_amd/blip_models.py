@@ -1,14 +1,21 @@
 """blip4cir `CIRPlus` protocol (blip4cir/models.py:16-121) over the MI355X path: fusion encoder (med.py BertModel
 + text_proj), BLIP ViT image side, static token / target banks, learnable temperature.
 
-    model = CIRPlus(blip_state_dict_or_path, tau=0.03, tokenizer=my_bert_tokenizer)
+    model = CIRPlus(blip_state_dict_or_path, tau=0.03, vocab_file="bert-base-uncased/vocab.txt")
     loss = model.forward(text, indexs, target_indexs, refer_indexs)['bank_loss']; loss.backward()
+    extract_index_features(classic_val_dataset, model.blip); compute_fiq_val_metrics(rel_ds, model.blip, ...)
 
-`text` is a list of strings when a tokenizer is given (any callable `texts -> (ids [B,L], attention_mask [B,L])`;
-the reference's `BertTokenizer('bert-base-uncased')` + `[ENC]` first token needs a vocabulary download that this
-repository cannot vendor), or an already tokenised `(ids, mask)` pair.  State-dict keys follow BLIP_Retrieval:
-`visual_encoder.*`, `vision_proj.*`, `text_encoder.*`, `text_proj.*` (under `blip.` in CIRPlus.state_dict())."""
+`text` is a list of strings: tokenised as blip_cir.py:87-88 does (WordPiece, padding='longest', first id <- [ENC]) by
+`bert_tokenizer.BertWordPieceTokenizer` built from `vocab_file` (or $SPN_BERT_VOCAB; the bert-base-uncased vocab.txt
+is a download this repository cannot vendor), or by `tokenizer=` - an object with the transformers call shape
+(`tok(texts, padding='longest', return_tensors='pt')` + `.enc_token_id`, e.g. the reference's own `init_tokenizer()`)
+or a plain callable `texts -> (ids [B,L], attention_mask [B,L])`.  An already tokenised `(ids, mask)` pair is taken as
+is.  `model.blip` is the object the reference's loop hands to `extract_index_features` / `compute_*_val_metrics`
+(blip4cir/train.py:59,70,134,167): it answers `img_embed`, `img_embed_p`, `img_txt_fusion`, `tokenizer`, `eval()` /
+`train()` and holds the parameters under BLIP_Retrieval's names: `visual_encoder.*`, `vision_proj.*`,
+`text_encoder.*`, `text_proj.*`, `temp` (under `blip.` in CIRPlus.state_dict())."""
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -48,9 +55,59 @@ class _FusionBankStep(torch.autograd.Function):
         return torch.zeros((), device=grad_out.device), dtau, None, None, None, None, None
 
 
+class BlipRetrievalFacade(nn.Module):
+    """`model.blip`: BLIP_Retrieval's inference surface (blip_cir.py:54-103) over the owning CIRPlus' kernels, and the
+    parameter container whose names equal BLIP_Retrieval.state_dict()'s.  The owner is held weakly (it registers this
+    module as a child; a strong reference back would make the module tree cyclic)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner_ref", weakref.ref(owner))
+        self.temp = nn.Parameter(0.07 * torch.ones([], device=owner.device), requires_grad=False)   # blip_cir.py:47; stage 1 only
+
+    def _owner(self):
+        owner = self._owner_ref()
+        if owner is None:
+            raise RuntimeError("the CIRPlus that owns this BLIP module is gone")
+        return owner
+
+    @property
+    def tokenizer(self):
+        return self._owner().tokenizer
+
+    def init_stage2(self):                           # blip_cir.py:48-52: the image side is frozen here from the start
+        for name, p in self.named_parameters():
+            if name.startswith(("visual_encoder.", "vision_proj.")):
+                p.requires_grad = False
+
+    def img_embed(self, image, atts=False, return_pool_and_normalized=False):
+        """blip_cir.py:54-70: tokens [B, S, W] (+ normalised vision_proj of token 0) (+ all-ones attention mask)."""
+        owner = self._owner()
+        tokens, pooled = owner._img_embed(image)
+        out = (tokens,)
+        if return_pool_and_normalized:
+            out += (pooled,)
+        if atts:
+            out += (torch.ones(tokens.shape[:-1], dtype=torch.long, device=tokens.device),)
+        return out[0] if len(out) == 1 else out
+
+    def img_embed_p(self, image):
+        """blip_cir.py:72-80."""
+        return self._owner()._img_embed(image)[1]
+
+    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=False, return_raw=False):
+        """blip_cir.py:82-103, inference form.  `train=True` (B x B logits against in-batch targets over `temp`) is the
+        first-stage loss of the candidate-reranking code this file was taken from; the second stage never calls it."""
+        if train or return_raw:
+            raise NotImplementedError("img_txt_fusion(train=True / return_raw=True) is not on the second-stage path "
+                                      "(blip4cir/models.py:101 calls it with the defaults)")
+        return self._owner()._fuse(r_image_embeds, text)
+
+
 class CIRPlus(nn.Module):
     def __init__(self, blip_model_name, tau=0.01, transform="targetpad", target_ratio=1.25, encoder="both",
-                 device=torch.device("cuda"), plus=False, tokenizer=None, image_size=384, patch=16, enc_token_id=None):
+                 device=torch.device("cuda"), plus=False, tokenizer=None, image_size=384, patch=16, enc_token_id=None,
+                 vocab_file=None):
         super().__init__()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -61,6 +118,12 @@ class CIRPlus(nn.Module):
                 raise RuntimeError(f"BLIP checkpoint {sd} not found")
             sd = torch.load(sd, map_location="cpu")
             sd = sd.get("model", sd.get("BLIP_Retrieval", sd))
+        vocab_file = vocab_file or os.environ.get("SPN_BERT_VOCAB")
+        if tokenizer is None and vocab_file:
+            from .bert_tokenizer import init_tokenizer
+            tokenizer = init_tokenizer(vocab_file)                       # blip.py:189-194 from a local vocab.txt
+        if enc_token_id is None:
+            enc_token_id = getattr(tokenizer, "enc_token_id", None)
         self.plus, self.encoder, self.tokenizer, self.enc_token_id = plus, encoder, tokenizer, enc_token_id
         c = fusion_cfg_from_state_dict(sd, "text_encoder.")
         self.output_dim = sd["text_proj.weight"].shape[0]
@@ -80,7 +143,7 @@ class CIRPlus(nn.Module):
             self.vision.load_blip_state_dict(sd)
         self.input_dim = image_size
         self.tau = nn.Parameter(tau * torch.ones([], device=self.device))
-        self.blip = nn.Module()                      # parameter container: names as in BLIP_Retrieval.state_dict()
+        self.blip = BlipRetrievalFacade(self)        # names as in BLIP_Retrieval.state_dict() + its inference methods
         self._params = {}
         for key, view in self.fusion.named_views().items():
             name = key if key.startswith("text_proj.") else "text_encoder." + key
@@ -173,15 +236,17 @@ class CIRPlus(nn.Module):
         if bank_path:
             torch.save(refer, bank_path)
 
-    def img_embed(self, image, return_pool_and_normalized=False):
-        """BLIP_Retrieval.img_embed (blip_cir.py:54-70): token sequence [B, S, W] (and normalised vision_proj of token 0)."""
+    def _img_embed(self, image):
         if self.vision is None:
             raise RuntimeError("this checkpoint has no visual_encoder")
         with torch.no_grad():
-            feats, tokens = self.vision.forward(image, return_tokens=True)
-        if return_pool_and_normalized:
-            return tokens, torch.nn.functional.normalize(feats, dim=-1)
-        return tokens
+            feats, tokens = self.vision.forward(image.to(self.device, torch.float32), return_tokens=True)
+            return tokens, ops.combine_l2norm_fwd(None, None, feats.contiguous())[0]
+
+    def img_embed(self, image, return_pool_and_normalized=False):
+        """BLIP_Retrieval.img_embed (blip_cir.py:54-70): token sequence [B, S, W] (and normalised vision_proj of token 0)."""
+        tokens, pooled = self._img_embed(image)
+        return (tokens, pooled) if return_pool_and_normalized else tokens
 
     # -------------------------------------------------------------------------------- step
     def tokenize(self, text):
@@ -189,20 +254,26 @@ class CIRPlus(nn.Module):
             ids, mask = text
         else:
             if self.tokenizer is None:
-                raise RuntimeError("no tokenizer: pass tokenizer=callable(texts) -> (ids, mask) or feed (ids, mask) "
-                                   "(blip_cir.py:87-88 uses BertTokenizer('bert-base-uncased') + the [ENC] id)")
-            ids, mask = self.tokenizer(list(text))
+                raise RuntimeError("no tokenizer: construct CIRPlus with vocab_file=<bert-base-uncased vocab.txt> (or set "
+                                   "SPN_BERT_VOCAB), pass tokenizer=, or feed (ids, mask)  (blip_cir.py:87-88)")
+            texts = [text] if isinstance(text, str) else list(text)
+            out = self.tokenizer(texts, padding="longest", return_tensors="pt") if hasattr(self.tokenizer, "enc_token_id") \
+                else self.tokenizer(texts)
+            ids, mask = (out["input_ids"], out["attention_mask"]) if hasattr(out, "keys") else out
         ids = ids.to(self.device, torch.int32).clone()
         if self.enc_token_id is not None:
             ids[:, 0] = self.enc_token_id              # blip_cir.py:88
         return ids.contiguous(), mask.to(self.device, torch.int32).contiguous()
 
-    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text):
-        """Inference form (blip_cir.py:82-103, train=False): normalised text_proj of the fused [ENC] token."""
+    def _fuse(self, r_image_embeds, text):
         ids, mask = self.tokenize(text)
         with torch.no_grad():
             proj = self.fusion.forward(ids, mask, r_image_embeds.to(self.device, torch.float32))
-        return torch.nn.functional.normalize(proj, dim=-1)
+            return ops.combine_l2norm_fwd(None, None, proj)[0]
+
+    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text):
+        """Inference form (blip_cir.py:82-103, train=False): normalised text_proj of the fused [ENC] token."""
+        return self._fuse(r_image_embeds, text)
 
     def forward(self, text, indexs, target_indexs, refer_indexs, reference_image=None, target_image=None):
         """blip4cir/models.py:95-110 -> {'bank_loss': 0-dim tensor}; backward() fills .grad of the fusion encoder's

@@ -2170,6 +2170,8 @@ int bank_stats_fwd(const BankArgs& a, float* stats, float* ws, size_t ws_bytes, 
             // 128..256 queries: the 160-row-tile kernel (bank3.hip: every CU pulls, three bank k tiles in flight per CU); with a
             // save buffer it keeps p TRANSPOSED ([bank row][query], the layout of the dq GEMM's G^T operand)
             const int nt160 = bank_stats160_tiles(a.M);
+            // this tiling writes more partial blocks than the 256-row GEMM tiling checked above: guard it by its own count
+            if (ws_bytes < (size_t)nt160 * a.B * 4 * sizeof(float)) return SPN_ERR_WORKSPACE;
             {
                 const double bytes = (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16;
                 ProfScope prof(PK_BANK_FWD, bytes, st);

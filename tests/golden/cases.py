@@ -118,3 +118,91 @@ def blip2_target_feats(tag):
         t[3, 5] = t[3, 17]
         t[7, :] = t[7, 0]
     return t
+
+
+# ------------------------------------------------- blip4cir end to end: strings in, metrics out (blip_val.npz)
+# Sizes the reference hard-codes (blip4cir/utils.py:36-37, validate.py:83): 577 image tokens x 768, 256-wide pooled features.
+BLIPVAL = dict(W=768, VLAYERS=1, PATCH=16, RES=384, PROJ=256, HID=128, LAYERS=2, INTER=512, MAXPOS=128, NG=20, NQ=24, B=6, M=20,
+               TAU=0.03)
+_BLIP_WORDS = ("is are has with and more less very dress shirt top skirt sleeve sleeves collar floral print striped solid red blue "
+               "green black white pink dark light long short longer shorter loose fitted plain casual same different color style "
+               "the a dog dogs cat people remove add change instead facing left right two").split()
+
+
+def blipval_vocab():
+    """The synthetic WordPiece vocabulary of make_golden_bert_tokenizer.py (stored in bert_tokenizer.json)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bert_tokenizer.json"), encoding="utf-8") as f:
+        return json.load(f)["vocab"]
+
+
+def blipval_state_dict():
+    """BLIP_Retrieval state dict (blip_cir.py:34-47 names) from seeds: 1-block ViT at the full token shape, 2-layer
+    cross-attention BERT 128 wide over 768-wide image tokens, vocab = synthetic vocabulary + [DEC] + [ENC]."""
+    from oracle import blip_vit
+    c = BLIPVAL
+    sd = blip_vit.synthetic_state_dict(c["W"], c["VLAYERS"], c["PATCH"], c["RES"], c["PROJ"], seed=41)
+    for k in list(sd):                       # 768-wide products: keep the block's activations O(1)
+        if k.endswith(("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")):
+            sd[k] = sd[k] * 0.4
+    g = torch.Generator().manual_seed(43)
+    r = lambda *s, std=0.02: torch.randn(*s, generator=g) * std
+    H, E, I, V = c["HID"], c["W"], c["INTER"], len(blipval_vocab()) + 2
+    t = {"embeddings.word_embeddings.weight": r(V, H, std=0.5), "embeddings.position_embeddings.weight": r(c["MAXPOS"], H, std=0.1),
+         "embeddings.LayerNorm.weight": 1 + r(H, std=0.1), "embeddings.LayerNorm.bias": r(H, std=0.05)}
+    for l in range(c["LAYERS"]):
+        p = f"encoder.layer.{l}."
+        for a, kw in (("attention", H), ("crossattention", E)):
+            for n in ("query", "key", "value"):
+                w_in = H if n == "query" else kw
+                t[p + f"{a}.self.{n}.weight"] = r(H, w_in, std=0.6 / w_in ** 0.5)
+                t[p + f"{a}.self.{n}.bias"] = r(H, std=0.05)
+            t[p + a + ".output.dense.weight"] = r(H, H, std=0.06)
+            t[p + a + ".output.dense.bias"] = r(H, std=0.05)
+            t[p + a + ".output.LayerNorm.weight"] = 1 + r(H, std=0.1)
+            t[p + a + ".output.LayerNorm.bias"] = r(H, std=0.05)
+        t[p + "intermediate.dense.weight"] = r(I, H, std=0.06); t[p + "intermediate.dense.bias"] = r(I, std=0.05)
+        t[p + "output.dense.weight"] = r(H, I, std=0.04); t[p + "output.dense.bias"] = r(H, std=0.05)
+        t[p + "output.LayerNorm.weight"] = 1 + r(H, std=0.1); t[p + "output.LayerNorm.bias"] = r(H, std=0.05)
+    sd.update({"text_encoder." + k: v for k, v in t.items()})
+    sd["text_proj.weight"], sd["text_proj.bias"] = r(c["PROJ"], H, std=0.08), r(c["PROJ"], std=0.05)
+    return sd
+
+
+def blipval_inputs():
+    """-> dict(images [NG,3,384,384], names, fiq_rows, cirr_rows, train = (captions, indexs, target_ids, refer_ids))."""
+    import random
+    c = BLIPVAL
+    g = torch.Generator().manual_seed(47)
+    rng = random.Random(53)
+    images = torch.randn(c["NG"], 3, c["RES"], c["RES"], generator=g)
+    names = [f"B{i:05d}" for i in range(c["NG"])]
+    cap = lambda lo, hi: " ".join(rng.choice(_BLIP_WORDS) for _ in range(rng.randint(lo, hi)))
+    ref_i = [rng.randrange(c["NG"]) for _ in range(c["NQ"])]
+    tgt_i = [(r + 1 + rng.randrange(c["NG"] - 1)) % c["NG"] for r in ref_i]
+    fiq_rows = [(names[r], names[t], [cap(2, 7) + rng.choice(["", ".", "?", " ,"]), cap(2, 6) + rng.choice(["", ".", "!"])])
+                for r, t in zip(ref_i, tgt_i)]
+    cirr_rows = []
+    for r, t in zip(ref_i, tgt_i):
+        others = [j for j in rng.sample(range(c["NG"]), 9) if j not in (r, t)][:5]
+        cirr_rows.append((names[r], names[t], cap(3, 12).capitalize() + rng.choice(["", ".", ", too"]), [names[j] for j in others + [t]]))
+    caps = [cap(3, 10).capitalize() + " and " + cap(2, 6) for _ in range(c["B"])]
+    refer = [rng.randrange(c["NG"]) for _ in range(c["B"])]
+    target = [rng.randrange(c["M"]) for _ in range(c["B"])]
+    train = (caps, torch.arange(c["B"]), torch.tensor(target), torch.tensor(refer))
+    return dict(images=images, names=names, fiq_rows=fiq_rows, cirr_rows=cirr_rows, train=train)
+
+
+class ClassicRows(torch.utils.data.Dataset):
+    """'classic' dataset items (name, preprocessed image) as data_utils.py returns them."""
+    data_name, split, dress_types = "fiq", "val", ["dress"]
+
+    def __init__(self, names, images):
+        self.names, self.images = names, images
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, i):
+        return self.names[i], self.images[i]

@@ -272,3 +272,85 @@ def test_blip_bank_builders(golden_dir, tmp_path):
     assert (1 - cos).max() < 1e-3
     m2.load_refer_bank(p2)
     assert torch.equal(m2.refer_bank, model.refer_bank)
+
+
+def test_blip_reference_call_pattern_strings_to_metrics(golden_dir, tmp_path):
+    """The calls blip4cir/train.py makes, on the object it makes them on (`model.blip`, train.py:59,70,134,167), with caption
+    STRINGS: extract_index_features(classic_ds, model.blip) -> compute_fiq/cirr_val_metrics(rel_ds, model.blip, ...) and
+    model.forward(captions, ...) + backward, against blip_val.npz (captured from the reference's own chain, tokenizer
+    included).  The vocabulary travels as a vocab.txt file, as the real one would."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cases import BLIPVAL, ClassicRows, blipval_inputs, blipval_state_dict, blipval_vocab
+    from spn4cir_amd import validate_fusion as vf
+    from spn4cir_amd.blip_models import CIRPlus
+    from spn4cir_amd.utils import extract_index_features_fusion as extract_index_features
+    z = np.load(os.path.join(golden_dir, "blip_val.npz"))
+    c, inp = BLIPVAL, blipval_inputs()
+    vocab_file = tmp_path / "vocab.txt"
+    vocab_file.write_text("\n".join(blipval_vocab()) + "\n", encoding="utf-8")
+    model = CIRPlus(blipval_state_dict(), tau=c["TAU"], device=torch.device("cuda"), plus=True, vocab_file=str(vocab_file))
+    assert model.input_dim == c["RES"] and model.output_dim == c["PROJ"]
+    assert model.blip.tokenizer is model.tokenizer and model.tokenizer.enc_token_id == len(blipval_vocab()) + 1
+    model.blip.eval()                                                           # train.py:111
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a.double().cpu(), b.double(), dim=-1)
+    # train.py:57-60
+    feats, feats_p, names = extract_index_features(ClassicRows(inp["names"], inp["images"]), model.blip)
+    assert names == inp["names"] and tuple(feats.shape) == (c["NG"], 577, 768) and tuple(feats_p.shape) == (c["NG"], 256)
+    assert (1 - cos(feats_p, torch.from_numpy(z["index_features_p"]))).max() < 1e-3
+    assert (1 - cos(feats[:, ::48, ::16], torch.from_numpy(z["index_tokens_sample"]))).max() < 2e-3
+    # the BLIP_Retrieval methods themselves (blip_cir.py:54-80)
+    one = model.blip.img_embed(inp["images"][:2].cuda())
+    assert torch.is_tensor(one) and tuple(one.shape) == (2, 577, 768)
+    t3 = model.blip.img_embed(inp["images"][:2].cuda(), atts=True, return_pool_and_normalized=True)
+    assert len(t3) == 3 and t3[2].dtype == torch.long and tuple(t3[2].shape) == (2, 577) and bool(t3[2].all())
+    assert torch.equal(model.blip.img_embed_p(inp["images"][:2].cuda()), t3[1])
+    with pytest.raises(NotImplementedError):
+        model.blip.img_txt_fusion(one, t3[1], ["a dress"] * 2, train=True)
+    # train.py:134-136, 167-168: five positional arguments, model.blip
+    from make_golden import FakeCirrDataset, FakeFiqDataset
+    pred_fiq, _ = vf.generate_fiq_val_predictions(model.blip, FakeFiqDataset(inp["fiq_rows"]), names, feats)
+    pred_cirr = vf.generate_cirr_val_predictions(model.blip, FakeCirrDataset(inp["cirr_rows"]), names, feats)[0]
+    assert (1 - cos(pred_fiq, torch.from_numpy(z["pred_fiq"]))).max() < 1e-3          # north_star gate on the embeddings
+    assert (1 - cos(pred_cirr, torch.from_numpy(z["pred_cirr"]))).max() < 1e-3
+    fiq = vf.compute_fiq_val_metrics(FakeFiqDataset(inp["fiq_rows"]), model.blip, feats, feats_p, names)
+    cirr = vf.compute_cirr_val_metrics(FakeCirrDataset(inp["cirr_rows"]), model.blip, feats, feats_p, names)
+    one_query = 100.0 / c["NQ"] + 1e-6       # bf16 towers on a random-weight model: a near-tie at a cut-off may move one query
+    print("fiq", fiq, "reference", z["fiq"], "cirr", cirr, "reference", z["cirr"])
+    assert all(abs(a - b) <= one_query for a, b in zip(fiq, z["fiq"]))
+    assert all(abs(a - b) <= one_query for a, b in zip(cirr, z["cirr"]))
+
+    class Replay:                           # the ranking itself is exact: the captured queries give the captured metrics
+        def __init__(self, q):
+            self.q, self.pos = q.cuda(), 0
+
+        def img_txt_fusion(self, r, t, text, train=False):
+            out = self.q[self.pos:self.pos + len(text)]
+            self.pos += len(text)
+            return out
+    ref_p = torch.from_numpy(z["index_features_p"]).cuda()
+    fiq_x = vf.compute_fiq_val_metrics(FakeFiqDataset(inp["fiq_rows"]), Replay(torch.from_numpy(z["pred_fiq"])), feats, ref_p, names)
+    cirr_x = vf.compute_cirr_val_metrics(FakeCirrDataset(inp["cirr_rows"]), Replay(torch.from_numpy(z["pred_cirr"])), feats, ref_p, names)
+    assert np.allclose(fiq_x, z["fiq"], atol=1e-4) and np.allclose(cirr_x, z["cirr"], atol=1e-4)
+    # train.py:113-125 on strings (plus=True: token rows per image id)
+    caps, indexs, target_ids, refer_ids = inp["train"]
+    model.refer_bank, model.target_bank = feats.clone(), feats_p.clone().cpu()
+    loss = model.forward(caps, indexs, target_ids, refer_ids)["bank_loss"]
+    assert "{:05.3f}".format(loss) and abs(loss.item() - float(z["loss"])) < 2e-2 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    assert abs(model.tau.grad.item() - float(z["dtau"])) < 5e-2 * abs(float(z["dtau"]))
+    named = dict(model.blip.named_parameters())
+    worst = ("", 0.0)
+    for k in z.files:
+        if k.startswith("grad::"):
+            ref = torch.from_numpy(z[k])
+            got = named[k[6:]].grad.cpu()
+            if k.endswith("self.key.bias"):     # mathematically zero (softmax shift invariance): round-off on both sides
+                scale = torch.from_numpy(z[k.replace("key.bias", "query.bias")]).norm()
+                assert got.norm() < 3e-2 * scale, (k, got.norm().item(), scale.item())
+                continue
+            err = ((got - ref).norm() / ref.norm()).item()
+            worst = max(worst, (k[6:], err), key=lambda t: t[1])
+            assert err < 4e-2, (k, err)
+    print("worst relative L2 gradient error:", worst)
+    assert "blip.temp" in model.state_dict() and named["visual_encoder.blocks.0.attn.qkv.weight"].grad is None

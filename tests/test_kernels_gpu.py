@@ -1036,6 +1036,18 @@ def test_c_abi_error_codes(ops):
     bank2 = torch.zeros(8, 128, dtype=torch.bfloat16, device="cuda")
     assert L.spn_bank_stats_fwd(p(q2), 128, p(bank2), p(lab), 0, 8, 128, 0, 50.0, p(st), p(ws), ws.numel(), None) == -1
     assert L.spn_bank_stats_fwd(p(q2), 128, p(bank2), p(lab), 4, 8, 128, 0, 50.0, None, p(ws), ws.numel(), None) == -1
+    # 160-row-tile statistics pass (128..256 queries): a workspace sized for the 256-row tiling only (ceil(M/256) blocks of
+    # B*16 bytes) is too small for its ceil(M/160) partial blocks -> SPN_ERR_WORKSPACE before anything is launched
+    Bq, Mq, Dq = 256, 4000, 256
+    q3 = torch.zeros(Bq, Dq, dtype=torch.bfloat16, device="cuda")
+    bank3 = torch.zeros(Mq, Dq, dtype=torch.bfloat16, device="cuda")
+    lab3 = torch.zeros(Bq, dtype=torch.int64, device="cuda")
+    st3 = torch.zeros(Bq, 4, device="cuda")
+    small = ((Mq + 255) // 256) * Bq * 16
+    if os.environ.get("SPN_BANK_S160", "1") != "0" and os.environ.get("SPN_BANK_GEMM", "1") != "0":
+        assert L.spn_bank_stats_fwd(p(q3), Dq, p(bank3), p(lab3), Bq, Mq, Dq, 0, 50.0, p(st3), p(ws), small, None) == -3
+    assert L.spn_bank_stats_fwd(p(q3), Dq, p(bank3), p(lab3), Bq, Mq, Dq, 0, 50.0, p(st3), p(ws),
+                                L.spn_bank_workspace_bytes(Bq, Mq, Dq), None) == 0
     # token-max bank: rows must come in groups of 32 per target, widths as the plain bank
     assert L.spn_bank_stats_fwd_tokmax(p(q2), 128, p(bank2), p(lab), 4, 0, 128, 0, 14.0, p(st), p(ws), ws.numel(), None) == -1
     # TG-CIR head: more than 640 positions / 8 local tokens only

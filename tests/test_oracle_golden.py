@@ -314,3 +314,56 @@ def test_negtype_oracle_matches_reference_capture(golden_dir):
             for g, k in ((rr, "refer"), (tt, "text"), (ii, "target")):
                 ref = torch.from_numpy(z[f"{tag}::{nt}::d_{k}"])
                 assert (g.grad - ref).abs().max() < 1e-6 * max(1.0, ref.abs().max().item()), (tag, nt, k)
+
+
+def test_blip_val_chain_oracle_matches_reference(golden_dir):
+    """blip_val.npz = the reference's own blip4cir chain on caption STRINGS (utils.extract_index_features ->
+    BLIP_Retrieval.img_embed incl. blip_cir.py:62, validate.generate_*_val_predictions -> img_txt_fusion incl. the tokenizer
+    call of blip_cir.py:87-88, models.CIRPlus.forward + backward).  The oracle pieces (blip_vit.img_embed, the WordPiece
+    restatement, bert_fusion.fusion_query, cross-entropy) must reproduce it in fp32."""
+    from cases import BLIPVAL, blipval_inputs, blipval_state_dict, blipval_vocab
+    from oracle import bert_fusion, blip_vit
+    from spn4cir_amd.bert_tokenizer import BertWordPieceTokenizer
+    z = _load(golden_dir, "blip_val.npz")
+    c, sd, inp = BLIPVAL, blipval_state_dict(), blipval_inputs()
+    tok = BertWordPieceTokenizer(vocab=blipval_vocab())
+    with torch.no_grad():
+        tokens, pooled = blip_vit.img_embed(sd, inp["images"], c["W"] // 64)
+    assert torch.allclose(pooled, torch.from_numpy(z["index_features_p"]), atol=2e-5)           # blip_cir.py:62 pinned
+    assert torch.allclose(tokens[:, ::48, ::16], torch.from_numpy(z["index_tokens_sample"]), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(tokens.norm(dim=-1), torch.from_numpy(z["index_tokens_norm"]), rtol=1e-4)
+    fsd = {k[len("text_encoder."):]: v for k, v in sd.items() if k.startswith("text_encoder.")}
+    fsd.update({k: v for k, v in sd.items() if k.startswith("text_proj.")})
+    name2i = {n: i for i, n in enumerate(inp["names"])}
+
+    def fuse(rows_ref, caps, params=fsd):
+        ids, mask = tok.enc_batch(caps)
+        ref = tokens[torch.tensor([name2i[r] for r in rows_ref])]
+        return bert_fusion.fusion_query(params, ids.to(torch.int32), mask.to(torch.int32), ref)
+
+    caps = [f"{r[2][0].strip('.?, ').capitalize()} and {r[2][1].strip('.?, ')}" for r in inp["fiq_rows"]]
+    with torch.no_grad():
+        pf = fuse([r[0] for r in inp["fiq_rows"]], caps)
+        pc = fuse([r[0] for r in inp["cirr_rows"]], [r[2] for r in inp["cirr_rows"]])
+    assert torch.allclose(pf, torch.from_numpy(z["pred_fiq"]), atol=2e-5)
+    assert torch.allclose(pc, torch.from_numpy(z["pred_cirr"]), atol=2e-5)
+    # training step on strings
+    caps, _, target_ids, refer_ids = inp["train"]
+    params = {k: v.clone().requires_grad_(True) for k, v in fsd.items()}
+    tau = torch.tensor(c["TAU"], requires_grad=True)
+    ids, mask = tok.enc_batch(caps)
+    assert ids.shape[1] == int(z["train_ids_longest"])
+    q = bert_fusion.fusion_query(params, ids.to(torch.int32), mask.to(torch.int32), tokens[refer_ids])
+    loss = torch.nn.functional.cross_entropy((q @ pooled.T) / tau, target_ids)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    assert abs(tau.grad.item() - float(z["dtau"])) < 1e-3 * abs(float(z["dtau"]))
+    n = 0
+    for k in z.files:
+        if k.startswith("grad::"):
+            name = k[6:]
+            name = name[len("text_encoder."):] if name.startswith("text_encoder.") else name
+            ref = torch.from_numpy(z[k])
+            assert (params[name].grad - ref).abs().max() <= 5e-4 * ref.abs().max().clamp_min(1e-6) + 1e-7, name
+            n += 1
+    assert n >= 10
