@@ -247,6 +247,11 @@ def blip_config4_block(args, dev):
     return out
 
 
+def _fp8_min_b():
+    from spn4cir_amd import ops
+    return ops.fp8_image_min_b()
+
+
 def fp8_config5_block(args, sd, model_cls, dev):
     """BASELINE config 5's bank on ONE GPU: M = 100 000 rows x 768 stored e4m3 + per-row scale, the fp8-MFMA similarity pass,
     beside the same step on the bf16 bank, at the per-GPU batches of the 8-GPU run (32 = strong scaling, 256 = weak)."""
@@ -289,8 +294,11 @@ def fp8_config5_block(args, sd, model_cls, dev):
                 lib.spn_prof_collect(kid, C.byref(ms), C.byref(work), C.byref(nl))
                 pair += ms.value / max(1, nl.value) * 1e3
             lib.spn_prof_reset()
-            nbytes = M * D * (1 if dt_name == "fp8" else 2)
+            from spn4cir_amd import ops as _ops
+            operand = _ops.bank_operand_kind(tr._bank, B)          # what the kernels READ: e4m3 bytes, bf16, or the kept bf16 image
+            nbytes = M * D * (1 if operand == "e4m3" else 2)
             ent[dt_name] = {"triplets_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "bank_pair_us": round(pair, 1),
+                            "operand": operand,
                             "bank_GBps_one_read": round(nbytes / (pair * 1e-6) / 1e9, 1) if pair > 0 else None,
                             "loss_first_step": round(float(first.item()), 5), "loss_last": round(float(loss.item()), 5)}
             del tr
@@ -298,7 +306,10 @@ def fp8_config5_block(args, sd, model_cls, dev):
         ent["loss_abs_diff_first_step"] = round(abs(ent["fp8"]["loss_first_step"] - ent["bf16"]["loss_first_step"]), 6)
         out[f"B{B}"] = ent
     out["workload"] = (f"config-2 step (ViT-L/14 text tower) over a {M} x {D} bank stored e4m3 + fp32 row scale vs bf16; "
-                       f"bank_pair_us = HIP-event time of the bank forward + backward kernels; 8 steps after 3 warm-up; 1 GPU")
+                       f"bank_pair_us = HIP-event time of the bank forward + backward kernels; `operand` = what those kernels read "
+                       f"(from {_fp8_min_b()} queries per call an e4m3 bank is served through its kept bf16 image - "
+                       f"SPN_FP8_IMAGE_MIN_B - so the B256 'fp8' entry is NOT an fp8-MFMA pass); bank_GBps_one_read prices the "
+                       f"operand's bytes; 8 steps after 3 warm-up; 1 GPU")
     del model
     torch.cuda.empty_cache()
     return out

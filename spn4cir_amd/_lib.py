@@ -200,6 +200,19 @@ def check(rc, what=""):
         raise RuntimeError(f"spn4cir_hip {what} failed: {msg} (code {rc})")
 
 
+_ENV_SNAPSHOT = None
+
+
+def env(name, default=None):
+    """SPN_* switch as the LIBRARY saw it when it was loaded (csrc/config.hip freezes the environment then and the kernels read
+    only that snapshot).  The host side must route by the same value: a variable set after the load would otherwise make Python
+    choose one call sequence (e.g. deferred / grouped weight gradients) while the library's own switch says the other."""
+    global _ENV_SNAPSHOT
+    if _ENV_SNAPSHOT is None:
+        _ENV_SNAPSHOT = dict(config_dump().get("env", {}))
+    return _ENV_SNAPSHOT.get(name, default)
+
+
 def config_dump():
     """The library's run-time configuration as a dict: {"experiments_build": 0|1, "env": {every SPN_* variable present when
     the library was loaded}} - the kernels' A/B switches read that snapshot only (csrc/config.hip)."""

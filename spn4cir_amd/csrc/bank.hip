@@ -1929,7 +1929,28 @@ static int bank_fused_bwd(const BankArgs& a, const float* save, const float* row
 // One shard holding the whole bank, no label smoothing: the step's forward AND backward w.r.t. the queries in two launches
 // (the single pass over the bank + bank_step_tail_kernel) instead of four (pass, statistics fold, finalize, combine).
 static int bank_check(const BankArgs& a);
+// 192..256 queries (the GEMM-shaped pair): the five launches of the saved-probability path behind ONE call - statistics pass (keeps
+// p^T), fold + finalize + mean in one tail launch, G^T scaling, dq GEMM, split-k fold.  Scratch behind the LargeSave image of `save`:
+// the statistics partials, the tail's arrival counter, the dq GEMM's split-k slabs (sized for the widest bank: the C-ABI sizes the
+// scratch from (B, M) alone).
+static bool bank_s160_on();
+static bool bank_step_large_ok(const BankArgs& a) {
+    return bank_saved_path_large(a) && !bank_fused_large() && bank_s160_on() && bank_stats160_ok(a.B, a.D, a.ldq) && a.D <= 1024 &&
+           (uint64_t)a.M * a.D * 2 < (1ull << 32);
+}
+static size_t large_save_bytes(int B, int M);
+static size_t large_step_extra_bytes(int B, int M) {
+    size_t tn = 0;                                     // the split count depends on the width: take the largest need
+    for (int D = 512; D <= 1024; D += 64) {
+        const size_t t = gemm_tn_workspace_bytes(M, B, D);
+        if (t > tn) tn = t;
+    }
+    return (((size_t)bank_stats160_tiles(M) * B * 16 + 255) & ~(size_t)255) + 256 + tn;
+}
+static int bank_step_large(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean,
+                           float* dq, hipStream_t st);
 bool bank_step_ok(const BankArgs& a) {
+    if (bank_step_large_ok(a)) return true;
     return bank_fused_ok(a) && !bank_saved_path(a) && !(bank_saved_path_large(a) && !bank_fused_large());
 }
 int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean, float* dq,
@@ -1938,6 +1959,7 @@ int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, 
     if (rc) return rc;
     if (!save || !row_lse || !row_loss || !loss_mean || !dq || a.m_begin != 0) return SPN_ERR_ARG;
     if (!bank_step_ok(a)) return SPN_ERR_SHAPE;
+    if (bank_step_large_ok(a)) return bank_step_large(a, save, grad_scale, row_lse, row_loss, loss_mean, dq, st);
     const BankChunking c = bank_chunking(a.B, a.M, fused_blocks(a.B, a.M, a.bank_scale != nullptr, a.D));
     float* Op = save;
     float* sp = save + (size_t)c.nchunks * a.B * a.D;
@@ -2098,8 +2120,36 @@ bool bank_saved_path_large(const BankArgs& a) {
     return bank_gemm_on() && !a.bank_scale && !a.group && a.B >= min_b && a.B % 8 == 0 && a.D >= 512 && a.D % 64 == 0;
 }
 static size_t fused_save_bytes(int B, int M, int D);
+static int bank_step_large(const BankArgs& a, float* save, float grad_scale, float* row_lse, float* row_loss, float* loss_mean,
+                           float* dq, hipStream_t st) {
+    const LargeSave sv = large_save_at(save, a.B, a.M);
+    char* p = (char*)save + large_save_bytes(a.B, a.M);
+    p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+    float* partial = (float*)p;
+    const int nt160 = bank_stats160_tiles(a.M);
+    p += ((size_t)nt160 * a.B * 16 + 255) & ~(size_t)255;
+    int* counter = (int*)p;
+    p += 256;
+    float* ws = (float*)p;
+    const size_t ws_bytes = gemm_tn_workspace_bytes(a.M, a.B, a.D);
+    int rc;
+    {
+        ProfScope prof(PK_BANK_FWD, (double)a.M * a.D * 2 + (double)a.B * a.D * 2 + (double)a.B * 16, st);
+        rc = bank_stats160(a.q, a.ldq, a.bank, a.labels, a.B, a.M, a.D, 0, a.inv_tau, partial, sv.P, sv.tmax, st, counter);
+        if (rc) return rc;
+        rc = bank_stats_tail(partial, nt160, a.B, row_lse, row_loss, loss_mean, counter, st);
+        if (rc) return rc;
+    }
+    ProfScope prof(PK_BANK_BWD, (double)a.M * a.D * 2 + (double)a.B * a.D * 6 + (double)a.B * 16, st);
+    rc = bank_gt_scale(sv.P, sv.Gt, sv.tmax, row_lse, a.labels, a.B, a.M, 0, 0.f, 1.0f / (float)a.M, st);
+    if (rc) return rc;
+    return gemm_tn(sv.Gt, a.bank, a.M, a.B, a.D, a.B, a.D, dq, a.D, grad_scale * a.inv_tau, 0, nullptr, ws, ws_bytes, st);
+}
+
 size_t bank_saved_bytes_any(int B, int M) {
-    const size_t small = bank_saved_bytes(B, M), large = B >= 128 ? large_save_bytes(B, M) : 0;
+    const size_t small = bank_saved_bytes(B, M);
+    size_t large = B >= 128 ? large_save_bytes(B, M) : 0;
+    if (B >= 128 && B <= 256) large += 256 + large_step_extra_bytes(B, M);        // bank_step_large's scratch behind the image
     const size_t fused = fused_save_bytes(B, M, 1024);      // the widest bank: the C-ABI sizes the scratch from (B, M) alone
     const size_t a = small > large ? small : large;
     return a > fused ? a : fused;

@@ -37,8 +37,10 @@ template <bool SAVE>
 __global__ __launch_bounds__(512, 2) void bank_stats160_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ bank,
                                                               const int64_t* __restrict__ labels, int B, int M, int D, int m_begin,
                                                               float inv_tau, float* __restrict__ partial, bf16_t* __restrict__ Pt,
-                                                              float* __restrict__ tmax) {
+                                                              float* __restrict__ tmax, int* __restrict__ tail_counter) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // arrival counter of bank_stats_tail_kernel (bank_step at 192..256 queries): reset by this launch, in front of it
+    if (tail_counter && blockIdx.x == 0 && threadIdx.x == 0) *tail_counter = 0;
     char* sBank = smem;
     char* sQ = smem + S160_NB * S160_BANK_STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,10 +194,70 @@ __global__ __launch_bounds__(256) void bank_gt_scale_kernel(const bf16_t* __rest
     }
 }
 
+// Fold + finalize of a single-shard step in ONE launch (bank_step at 192..256 queries): wave = one query, the arithmetic of
+// bank_stats_fold_kernel (lanes stride 64 over the tiles, the same merge order) followed by bank_loss_finalize_kernel's
+// single-shard row (lse = m + log l, loss = lse - label logit), so that lse - hence G and dq - is BIT-identical to the three-call
+// path.  The mean is summed by the block that arrives last (ticket; release / acquire at agent scope) with the finalize kernel's
+// own 256-leaf tree: bit-identical too.
+__global__ __launch_bounds__(256) void bank_stats_tail_kernel(const float* __restrict__ ws, int n, int B, float* __restrict__ row_lse,
+                                                             float* row_loss, float* __restrict__ loss_mean, int* counter) {
+    __shared__ float red[256];
+    __shared__ int last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = blockIdx.x * 4 + (tid >> 6);
+    if (q < B) {
+        float m = -INFINITY, l = 0.f, lab = -INFINITY;
+        for (int i = lane; i < n; i += 64) {
+            const f32x4 p = *(const f32x4*)(ws + ((size_t)i * B + q) * 4);
+            const float mn = fmaxf(m, p[0]);
+            if (mn > -INFINITY) l = l * __expf(m - mn) + p[1] * __expf(p[0] - mn);
+            m = mn;
+            lab = fmaxf(lab, p[3]);
+        }
+        const float mw = wave_max(m);
+        l = (m > -INFINITY) ? l * __expf(m - mw) : 0.f;
+        l = wave_sum(l);
+        lab = wave_max(lab);
+        if (lane == 0) {
+            // the finalize kernel re-merges the ONE folded shard: l * exp(m - m) + ... from (m, l) = (-inf, 0): l * 1 exactly
+            const float lse = mw + logf(l);
+            row_lse[q] = lse;
+            row_loss[q] = lse - lab;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    float acc = 0.f;
+    for (int i = tid; i < B; i += 256) acc += __hip_atomic_load(row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) *loss_mean = red[0] / (float)B;
+}
+
+int bank_stats_tail(const float* partial, int ntiles, int B, float* row_lse, float* row_loss, float* loss_mean, int* counter,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(bank_stats_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, st, partial, ntiles, B, row_lse, row_loss, loss_mean,
+                       counter);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 bool bank_stats160_ok(int B, int D, int ldq) { return B >= 128 && B <= 256 && B % 8 == 0 && D % 64 == 0 && D >= 192 && ldq % 8 == 0; }
 
 int bank_stats160(const bf16_t* q, int ldq, const bf16_t* bank, const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau,
-                  float* partial, bf16_t* Pt, float* tmax, hipStream_t st) {
+                  float* partial, bf16_t* Pt, float* tmax, hipStream_t st, int* tail_counter) {
     if (!bank_stats160_ok(B, D, ldq)) return SPN_ERR_SHAPE;
     if ((uint64_t)M * D * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
     static bool attr_set = false;
@@ -208,10 +270,10 @@ int bank_stats160(const bf16_t* q, int ldq, const bf16_t* bank, const int64_t* l
     const int tiles = bank_stats160_tiles(M);
     if (Pt)
         hipLaunchKernelGGL(bank_stats160_kernel<true>, dim3(tiles), dim3(512), S160_LDS, st, q, ldq, bank, labels, B, M, D, m_begin, inv_tau,
-                           partial, Pt, tmax);
+                           partial, Pt, tmax, tail_counter);
     else
         hipLaunchKernelGGL(bank_stats160_kernel<false>, dim3(tiles), dim3(512), S160_LDS, st, q, ldq, bank, labels, B, M, D, m_begin, inv_tau,
-                           partial, (bf16_t*)nullptr, (float*)nullptr);
+                           partial, (bf16_t*)nullptr, (float*)nullptr, tail_counter);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

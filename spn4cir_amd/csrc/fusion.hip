@@ -481,12 +481,10 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
     // embeddings: x0 = LN(word[ids] + pos)
     SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
                            grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));
-    hipError_t he = hipMemsetAsync(grads + t.word, 0, (size_t)c.vocab * W * sizeof(float), st);
-    if (he != hipSuccess) return (int)he;
+    SPN_TRYF(zero_fill_f32(grads + t.word, (size_t)c.vocab * W, st));
     SPN_TRYF(embed_bwd(ids, A.last, dy, grads + t.word, grads + t.pos, c.B, c.L, W, c.vocab, st));
     if (c.L < c.max_pos) {
-        he = hipMemsetAsync(grads + t.pos + (size_t)c.L * W, 0, (size_t)(c.max_pos - c.L) * W * sizeof(float), st);
-        if (he != hipSuccess) return (int)he;
+        SPN_TRYF(zero_fill_f32(grads + t.pos + (size_t)c.L * W, (size_t)(c.max_pos - c.L) * W, st));
     }
     return SPN_OK;
 }

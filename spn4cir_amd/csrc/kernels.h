@@ -107,6 +107,7 @@ int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int acc
                 hipStream_t st);
 size_t colsum_workspace_bytes(int rows, int cols);
 int fold_rows(const float* ws, size_t stride, int n, size_t C, float* out, float alpha, int accumulate, hipStream_t st);
+int zero_fill_f32(float* p, size_t n, hipStream_t st);     // elementwise.hip: the library's own zero fill (no hipMemsetAsync on the step)
 constexpr int FOLD_BATCH_MAX = 32;
 struct FoldBatch {            // out[i][c] = sum_{r < n} ws[i][r * stride + c], c < C, for i < items
     const float* ws[FOLD_BATCH_MAX];
@@ -230,7 +231,9 @@ int bank_step(const BankArgs& a, float* save, float grad_scale, float* row_lse, 
 bool bank_stats160_ok(int B, int D, int ldq);
 int bank_stats160_tiles(int M);
 int bank_stats160(const bf16_t* q, int ldq, const bf16_t* bank, const int64_t* labels, int B, int M, int D, int m_begin, float inv_tau,
-                  float* partial, bf16_t* Pt, float* tmax, hipStream_t st);
+                  float* partial, bf16_t* Pt, float* tmax, hipStream_t st, int* tail_counter = nullptr);
+int bank_stats_tail(const float* partial, int ntiles, int B, float* row_lse, float* row_loss, float* loss_mean, int* counter,
+                    hipStream_t st);
 int bank_gt_scale(const bf16_t* Pt, bf16_t* Gt, const float* tmax, const float* lse, const int64_t* labels, int B, int M, int m_begin,
                   float ls, float inv_m, hipStream_t st);
 // finalize on the owner of all shards' stats: row_lse, row_loss and the mean loss

@@ -757,8 +757,7 @@ static int text_bwd_tail_impl(const TextCfg& c, const int32_t* ids, char* acts, 
     TextLayout t;
     text_layout(c, &t);
     TextActs A = text_acts_at(acts, c);
-    hipError_t he = hipMemsetAsync(grads + t.tok, 0, (size_t)c.vocab * c.W * sizeof(float), st);
-    if (he != hipSuccess) return (int)he;
+    SPN_TRY(zero_fill_f32(grads + t.tok, (size_t)c.vocab * c.W, st));
     if (c.T > 0)
         SPN_TRY(embed_bwd_packed(ids, A.row_b, A.row_l, A.cu, w.dx, grads + t.tok, grads + t.pos, c.T, c.B, c.L, c.W, c.vocab,
                                  w.opws, w.opws_bytes, st));
@@ -766,8 +765,7 @@ static int text_bwd_tail_impl(const TextCfg& c, const int32_t* ids, char* acts, 
         SPN_TRY(embed_bwd_all(ids, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, 0, w.opws, w.opws_bytes, st));
     else SPN_TRY(embed_bwd(ids, A.eot, w.dx, grads + t.tok, grads + t.pos, c.B, c.L, c.W, c.vocab, st));
     if (c.L < c.L_ctx) {
-        he = hipMemsetAsync(grads + t.pos + (size_t)c.L * c.W, 0, (size_t)(c.L_ctx - c.L) * c.W * sizeof(float), st);
-        if (he != hipSuccess) return (int)he;
+        SPN_TRY(zero_fill_f32(grads + t.pos + (size_t)c.L * c.W, (size_t)(c.L_ctx - c.L) * c.W, st));
     }
     return SPN_OK;
 }

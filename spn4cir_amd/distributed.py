@@ -16,6 +16,7 @@ The math is backend-agnostic: `ops` is any object with bank_stats_fwd / bank_los
 bank_grad_q (the HIP ops in production; tests inject a CPU implementation over gloo).
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -62,6 +63,18 @@ def all_gather_cat(x, group=None, cache=None):
     return out
 
 
+def _mean_over_ranks(mean_local, group=None):
+    """Global mean loss from the ranks' local means (equal local batch sizes): ONE collective and no elementwise kernel on the
+    device path - RCCL averages in the all-reduce itself (ReduceOp.AVG); gloo (CPU tests, two ranks sharing a GPU) sums and
+    divides.  The local mean is a kernel output (spn_bank_loss_finalize / spn_bank_step), never a torch reduction."""
+    out = mean_local                                   # a fresh kernel output of this call: reduced in place
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(out, op=dist.ReduceOp.AVG, group=group)
+        return out
+    dist.all_reduce(out, group=group)
+    return out / dist.get_world_size(group)
+
+
 def reduce_scatter_rows(x, group=None):
     """x [world * B_local, ...] summed over ranks; this rank keeps its B_local rows."""
     world, rank = _world(group)
@@ -77,6 +90,10 @@ def reduce_scatter_rows(x, group=None):
     return out
 
 
+class _CacheToken:
+    """Ownership marker of BankLossDP's gather buffers (weak-referenced: a dropped ctx releases them by itself)."""
+
+
 class BankLossDP:
     def __init__(self, ops, group=None, mode="sharded"):
         if mode not in ("replicated", "sharded"):
@@ -87,12 +104,14 @@ class BankLossDP:
         # ctx['labels'] until backward(ctx) has run: a second forward before that (gradient accumulation, an eval forward
         # between forward and backward) gets fresh buffers instead of overwriting the pending step's queries.
         self._bufs = {}
-        self._pending_ctx = 0
+        self._cache_owner = None          # weak reference to the token of the ctx that currently holds self._bufs
 
-    def forward(self, qb_local, labels_local, bank, m_begin, M_total, inv_tau, label_smoothing=0.0):
+    def forward(self, qb_local, labels_local, bank, m_begin, M_total, inv_tau, label_smoothing=0.0, need_grad=True):
         """qb_local [B_local, Dp] bf16 L2-normalised queries, labels_local [B_local] int64 GLOBAL bank
         rows, `bank` = full bank (replicated) or this rank's shard starting at global row m_begin.
-        Returns a ctx dict; ctx['loss'] is the GLOBAL mean loss (identical on every rank)."""
+        Returns a ctx dict; ctx['loss'] is the GLOBAL mean loss (identical on every rank).
+        need_grad=False (evaluation, loss reporting): no backward call will follow - the one-call step, which also forms dq and
+        allocates its scratch, is not taken."""
         ops = self.ops
 
         def stats_fwd(q, labels):
@@ -106,37 +125,37 @@ class BankLossDP:
         if self.mode == "replicated" or _skip(self.world):
             # the whole bank on this rank, no label smoothing: forward and backward w.r.t. q in two launches (spn_bank_step)
             step_ok = getattr(ops, "bank_step_ok", None)
-            if (step_ok is not None and label_smoothing == 0.0 and m_begin == 0 and bank.shape[0] == M_total
+            if (need_grad and step_ok is not None and label_smoothing == 0.0 and m_begin == 0 and bank.shape[0] == M_total
                     and step_ok(qb_local.shape[0], M_total, qb_local.shape[1], bank)):
                 save = ops.bank_logits_buffer(qb_local.shape[0], M_total, qb_local.device)
                 if save is not None:
                     B_global = qb_local.shape[0] * self.world
                     lse, row, mean, dq = ops.bank_step(qb_local, bank, labels_local, inv_tau, 1.0 / B_global, save)
-                    loss = mean
-                    if not _skip(self.world):
-                        loss = row.sum().reshape(1)
-                        dist.all_reduce(loss, group=self.group)      # reporting only
-                        loss = loss / B_global
+                    loss = mean if _skip(self.world) else _mean_over_ranks(mean, self.group)      # reporting only
                     return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss, bank=bank, m_begin=m_begin,
                                 M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False,
                                 saved=None, dq=dq)
             stats, saved = stats_fwd(qb_local, labels_local)
             lse, row, mean = ops.bank_loss_finalize(stats, M_total, label_smoothing)
-            loss = row.sum().reshape(1)
-            if not _skip(self.world):
-                dist.all_reduce(loss, group=self.group)          # reporting only
+            loss = mean if _skip(self.world) else _mean_over_ranks(mean, self.group)              # reporting only
             B_global = qb_local.shape[0] * self.world
-            return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss / B_global, bank=bank, m_begin=m_begin,
+            return dict(q=qb_local, labels=labels_local, lse=lse, loss=loss, bank=bank, m_begin=m_begin,
                         M_total=M_total, inv_tau=inv_tau, ls=label_smoothing, B_global=B_global, gathered=False, saved=saved)
-        cache = self._bufs if self._pending_ctx == 0 else None
-        self._pending_ctx += 1
+        # the cached gather buffers belong to ONE ctx at a time: free again when that ctx's backward has run or the ctx was
+        # dropped without one (an evaluation forward, an exception) - its token is then gone and the weak reference dead
+        token = None
+        cache = None
+        if self._cache_owner is None or self._cache_owner() is None:
+            token = _CacheToken()
+            self._cache_owner = weakref.ref(token)
+            cache = self._bufs
         q_all = all_gather_cat(qb_local, self.group, cache)
         labels_all = all_gather_cat(labels_local, self.group, cache)
         stats, saved = stats_fwd(q_all, labels_all)                                     # [B, 4] over my shard
         stats_all = all_gather_cat(stats.unsqueeze(0), self.group, cache)               # [G, B, 4]
         lse, row, mean = ops.bank_loss_finalize(stats_all, M_total, label_smoothing)    # identical everywhere
         return dict(q=q_all, labels=labels_all, lse=lse, loss=mean, bank=bank, m_begin=m_begin, M_total=M_total,
-                    inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True, saved=saved)
+                    inv_tau=inv_tau, ls=label_smoothing, B_global=q_all.shape[0], gathered=True, saved=saved, cache_token=token)
 
     def backward(self, ctx, loss_scale=1.0):
         """-> d(loss_scale * global mean loss)/d(q_local)  [B_local, Dp] fp32"""
@@ -148,7 +167,9 @@ class BankLossDP:
                                   M_total=ctx["M_total"], label_smoothing=ctx["ls"], m_begin=ctx["m_begin"], **kw)
         if ctx["gathered"]:
             dq = reduce_scatter_rows(dq, self.group)
-            self._pending_ctx = max(0, self._pending_ctx - 1)
+            if ctx.get("cache_token") is not None and self._cache_owner is not None and self._cache_owner() is ctx["cache_token"]:
+                self._cache_owner = None                 # this step is done with the gather buffers
+            ctx["cache_token"] = None
         return dq
 
 

@@ -280,8 +280,27 @@ class Fp8Bank:
 FP8_IMAGE_MIN_B = 256
 
 
+def fp8_image_min_b():
+    """Query count from which an e4m3 bank is served through its kept bf16 image.  SPN_FP8_IMAGE_MIN_B overrides the default
+    (256): 0 = never build the image (memory-bound deployments: +2 bytes per bank element stay unspent; large batches then
+    expand the shard per pass inside the library), any other value = the threshold."""
+    v = os.environ.get("SPN_FP8_IMAGE_MIN_B")
+    if v is None or v.strip() == "":
+        return FP8_IMAGE_MIN_B
+    n = int(v)
+    return (1 << 62) if n <= 0 else n
+
+
+def bank_operand_kind(bank, B):
+    """What the bank calls actually read for `B` queries per call: "bf16", "e4m3" (raw bytes on the fp8 MFMA) or "bf16_image"
+    (an e4m3 bank through its kept expansion) - reported by bench.py next to every fp8 number."""
+    if isinstance(bank, Fp8Bank):
+        return "bf16_image" if B >= fp8_image_min_b() else "e4m3"
+    return "bf16"
+
+
 def _bank_operand(bank, B):
-    if isinstance(bank, Fp8Bank) and B >= FP8_IMAGE_MIN_B:
+    if isinstance(bank, Fp8Bank) and B >= fp8_image_min_b():
         return bank.bf16_image()
     return bank
 

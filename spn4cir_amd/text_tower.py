@@ -13,6 +13,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check, lib
+from ._lib import env as _lib_env
 from .ops import _p, _stream
 
 _BLOCK_KEYS = ["ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
@@ -248,7 +249,7 @@ class TextTower:
                                              _p(self._tok_stats[0]), _p(self._tok_stats[1]), _p(self.grads), ws, n, _stream()),
               "text_bwd_tokens_head")
         on_span_ready(*spans[0])
-        if os.environ.get("SPN_TN_GROUP", "1")[:1] == "0" or wgrad_groups is None:
+        if (_lib_env("SPN_TN_GROUP", "1") or "1")[:1] == "0" or wgrad_groups is None:
             for i, l in enumerate(reversed(range(self.layers))):
                 check(lib().spn_text_bwd_layer(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(self.grads), l,
                                                ws, n, _stream()), "text_bwd_layer")
@@ -294,7 +295,7 @@ class TextTower:
         check(lib().spn_text_bwd_head(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(self._acts), _p(dfeats),
                                       _p(self.grads), ws, n, _stream()), "text_bwd_head")
         on_span_ready(*spans[0])
-        if os.environ.get("SPN_TN_GROUP", "1")[:1] == "0":
+        if (_lib_env("SPN_TN_GROUP", "1") or "1")[:1] == "0":
             wgrad_groups = None                     # the library's workspace then holds no deferred buffers
         if wgrad_groups is None:
             for i, l in enumerate(reversed(range(self.layers))):

@@ -20,8 +20,8 @@ def wgrad_groups(layers, world):
     blocks), so that each group's gradient all-reduce runs under the backward of the following ones (partial rounds of
     256 CUs are split over the reduction by the kernel).
     SPN_WGRAD_GROUPS="a,b,.." overrides; "0" = no deferral (one grouped launch per block)."""
-    import os
-    env = os.environ.get("SPN_WGRAD_GROUPS")
+    from ._lib import env as lib_env          # the library's own snapshot of the environment (one source for both sides)
+    env = lib_env("SPN_WGRAD_GROUPS")
     if env is not None:
         return None if env.strip() in ("", "0") else [int(x) for x in env.split(",")]
     if world > 1 and 4 <= layers <= 24:

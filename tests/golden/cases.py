@@ -206,3 +206,36 @@ class ClassicRows(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         return self.names[i], self.images[i]
+
+
+# ------------------------------------------------------------- BLIP fusion encoder at config 4's full shape
+def fusion_sd(layers, W, I, E, Dp, vocab, max_pos, seed, init="small_residual"):
+    """BertModel(add_cross_attention) + text_proj state-dict with med.py's key names: BertPreTrainedModel's normal init scaled
+    up on the query / key / value / intermediate matrices so that attention is not uniform, non-trivial LayerNorm affine, and
+    SMALL residual-branch outputs (attention / cross-attention / FFN output.dense at std 0.01).  The last point keeps the
+    12-layer post-LN stack from rank-collapsing: with all matrices at std 0.04 the mean pairwise cosine between the positions'
+    hidden states grows 0.20, 0.45, 0.67, ... 0.9996, 0.9998 over the layers (every position carries the same vector at the
+    top: the near-uniform cross-attention over 577 random image tokens adds one common vector per layer), the query / key
+    gradients of the top layers are then the remainder of a cancelling sum and no bf16 attention backward reproduces them to
+    better than ~0.2; with this init it ends at 0.47 and every tensor is held to the same gate.
+    init="reference": BertPreTrainedModel._init_weights' own scale on every matrix (normal std 0.02, med.py / HF initializer_range;
+    LayerNorm affine and biases as above so that they matter) - the rank-collapsing regime, kept so that the noise floor of BOTH
+    inits is on record (noise_floor.json: blip_*_refinit)."""
+    g = torch.Generator().manual_seed(seed)
+    ref_init = init == "reference"
+    r = lambda *s, std=0.02: torch.randn(*s, generator=g) * (0.02 if (ref_init and len(s) == 2) else std)
+    sd = {"embeddings.word_embeddings.weight": r(vocab, W), "embeddings.position_embeddings.weight": r(max_pos, W),
+          "embeddings.LayerNorm.weight": 1 + r(W, std=0.1), "embeddings.LayerNorm.bias": r(W, std=0.05)}
+    for l in range(layers):
+        p = f"encoder.layer.{l}."
+        for a, kw in (("attention", W), ("crossattention", E)):
+            sd[p + a + ".self.query.weight"] = r(W, W, std=0.04); sd[p + a + ".self.query.bias"] = r(W, std=0.05)
+            sd[p + a + ".self.key.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.key.bias"] = r(W, std=0.05)
+            sd[p + a + ".self.value.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.value.bias"] = r(W, std=0.05)
+            sd[p + a + ".output.dense.weight"] = r(W, W, std=0.01); sd[p + a + ".output.dense.bias"] = r(W, std=0.05)
+            sd[p + a + ".output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + a + ".output.LayerNorm.bias"] = r(W, std=0.05)
+        sd[p + "intermediate.dense.weight"] = r(I, W, std=0.04); sd[p + "intermediate.dense.bias"] = r(I, std=0.05)
+        sd[p + "output.dense.weight"] = r(W, I, std=0.01); sd[p + "output.dense.bias"] = r(W, std=0.05)
+        sd[p + "output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + "output.LayerNorm.bias"] = r(W, std=0.05)
+    sd["text_proj.weight"] = r(Dp, W, std=0.05); sd["text_proj.bias"] = r(Dp, std=0.05)
+    return sd

@@ -78,12 +78,27 @@ def _worker(rank, world, port, mode, out):
         else:
             ctx = dp.forward(ql, ll, bank, 0, M, 1.0 / tau, eps)
         dq = dp.backward(ctx)
+        ok_cache = True
+        if mode == "sharded":
+            # gather-buffer ownership: a forward whose ctx is dropped without backward (evaluation) must not disable the
+            # cache for good, and a second forward while a step is pending must not overwrite that step's queries
+            qbuf = ctx["q"]
+            args = (ql, ll, bank[b:e].contiguous(), b, M, 1.0 / tau, eps)
+            c1 = dp.forward(*args)                                   # backward done above: the cached buffers are free again
+            ok_cache = c1["q"].data_ptr() == qbuf.data_ptr()
+            c2 = dp.forward(*args)                                   # c1 still pending: fresh buffers
+            ok_cache = ok_cache and c2["q"].data_ptr() != qbuf.data_ptr() and torch.equal(c1["q"], c2["q"])
+            del c1, c2                                               # both dropped without backward
+            c3 = dp.forward(*args, need_grad=False)
+            ok_cache = ok_cache and c3["q"].data_ptr() == qbuf.data_ptr()
+            dq3 = dp.backward(c3)
+            ok_cache = ok_cache and torch.equal(dq3, dq) and abs(c3["loss"].item() - ctx["loss"].item()) < 1e-7
         # single-process reference
         qd = q.double().requires_grad_(True)
         ref = torch.nn.functional.cross_entropy((qd @ bank.double().t()) / tau, labels, label_smoothing=eps)
         ref.backward()
         ok_loss = abs(ctx["loss"].item() - ref.item()) < 1e-5
-        ok_grad = torch.allclose(dq.double(), qd.grad[rank * bl:(rank + 1) * bl], atol=1e-6, rtol=1e-4)
+        ok_grad = torch.allclose(dq.double(), qd.grad[rank * bl:(rank + 1) * bl], atol=1e-6, rtol=1e-4) and ok_cache
         # bucketed gradient all-reduce
         flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
         red = GradBucketReducer(flat, None, bucket_elems=300)

@@ -3,8 +3,11 @@ not reach - ViT-L/14's text tower with every parameter gradient against the orac
 mode against the dense one at B = 256, the BLIP fusion encoder at 12 layers x 768 x 577 image tokens (enc_width 768 and
 1024), and a trainer step over a 100 000-row fp8 bank.
 
-Gates (same as the small-fixture tests): features 1 - cos <= 1e-3 (north_star), loss within 1e-2, per-parameter gradient
-relative L2 against the fp32 CPU oracle (bf16 operands, fp32 accumulation) gated at 2 x the observed worst of each test (printed)."""
+Gates: features 1 - cos <= 1e-3 (north_star), loss within 1e-2.  Per-parameter gradients: relative L2 against the fp32 CPU oracle,
+gated PER TENSOR at FLOOR_FACTOR x the bf16 noise floor of that tensor - what rounding every matrix-product operand to bf16 (fp32
+accumulation) costs the ORACLE ITSELF on the same model, batch and seed (oracle/noise.py; tests/golden/make_noise_floor.py ->
+noise_floor.json).  A kernel bug moves a tensor by far more than the 50 % head-room; bf16 arithmetic cannot be held to less than its
+own floor.  The worst ratio of each test is printed."""
 import os
 
 import numpy as np
@@ -13,8 +16,23 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-GRAD_GATE_VITL14 = 2.5e-2    # per-parameter relative L2 of the ViT-L/14 text-tower gradients: 2 x the observed worst (1.17e-2 on the
-                             # bf16 bank in all three grouping modes, 1.23e-2 on the e4m3 bank; both on a LayerNorm weight of block 0)
+FLOOR_FACTOR = 1.5           # HIP-vs-oracle error of a tensor <= FLOOR_FACTOR x its bf16 operand-rounding floor
+
+
+def _floor_gate(case, errs, what):
+    """errs {tensor: relative L2 vs the fp32 oracle}.  Asserts err <= FLOOR_FACTOR x noise_floor.json[case]['operands'][tensor] for
+    every tensor and prints the worst ratios."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise_floor.json")) as f:
+        floor = json.load(f)[case]["operands"]
+    missing = [k for k in errs if k not in floor]
+    assert not missing, (case, missing[:5])
+    ratio = {k: e / floor[k] for k, e in errs.items()}
+    top = sorted(ratio.items(), key=lambda t: -t[1])[:3]
+    print(f"{what}: {len(errs)} tensors, worst error / bf16-floor ratios " +
+          ", ".join(f"{r:.2f} ({k}: {errs[k]:.3e} vs floor {floor[k]:.3e})" for k, r in top))
+    bad = {k: (errs[k], floor[k]) for k, r in ratio.items() if not r <= FLOOR_FACTOR}
+    assert not bad, (case, bad)
 
 
 def _need_gpu():
@@ -72,10 +90,7 @@ def test_vitl14_every_gradient_matches_oracle(groups):
     for k, ref in g_ref.items():
         assert ref is not None and ref.norm() > 0, k
         worst[k] = _rel(views[k].cpu(), ref)
-    wk = max(worst, key=worst.get)
-    print(f"ViT-L/14 text step (groups {groups}): worst gradient error {worst[wk]:.3e} ({wk})")
-    bad = {k: v for k, v in worst.items() if not v < GRAD_GATE_VITL14}
-    assert not bad, bad
+    _floor_gate("vitl14_b8", worst, f"ViT-L/14 text step (groups {groups})")
     assert len(worst) == len(sd) == 2 + 12 * layers + 3
 
 
@@ -105,32 +120,7 @@ def test_packed_matches_dense_at_full_size():
     assert not bad, bad
 
 
-def _fusion_sd(layers, W, I, E, Dp, vocab, max_pos, seed):
-    """BertModel(add_cross_attention) + text_proj state-dict with med.py's key names: BertPreTrainedModel's normal init scaled
-    up on the query / key / value / intermediate matrices so that attention is not uniform, non-trivial LayerNorm affine, and
-    SMALL residual-branch outputs (attention / cross-attention / FFN output.dense at std 0.01).  The last point keeps the
-    12-layer post-LN stack from rank-collapsing: with all matrices at std 0.04 the mean pairwise cosine between the positions'
-    hidden states grows 0.20, 0.45, 0.67, ... 0.9996, 0.9998 over the layers (every position carries the same vector at the
-    top: the near-uniform cross-attention over 577 random image tokens adds one common vector per layer), the query / key
-    gradients of the top layers are then the remainder of a cancelling sum and no bf16 attention backward reproduces them to
-    better than ~0.2; with this init it ends at 0.47 and every tensor is held to the same gate."""
-    g = torch.Generator().manual_seed(seed)
-    r = lambda *s, std=0.02: torch.randn(*s, generator=g) * std
-    sd = {"embeddings.word_embeddings.weight": r(vocab, W), "embeddings.position_embeddings.weight": r(max_pos, W),
-          "embeddings.LayerNorm.weight": 1 + r(W, std=0.1), "embeddings.LayerNorm.bias": r(W, std=0.05)}
-    for l in range(layers):
-        p = f"encoder.layer.{l}."
-        for a, kw in (("attention", W), ("crossattention", E)):
-            sd[p + a + ".self.query.weight"] = r(W, W, std=0.04); sd[p + a + ".self.query.bias"] = r(W, std=0.05)
-            sd[p + a + ".self.key.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.key.bias"] = r(W, std=0.05)
-            sd[p + a + ".self.value.weight"] = r(W, kw, std=0.04); sd[p + a + ".self.value.bias"] = r(W, std=0.05)
-            sd[p + a + ".output.dense.weight"] = r(W, W, std=0.01); sd[p + a + ".output.dense.bias"] = r(W, std=0.05)
-            sd[p + a + ".output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + a + ".output.LayerNorm.bias"] = r(W, std=0.05)
-        sd[p + "intermediate.dense.weight"] = r(I, W, std=0.04); sd[p + "intermediate.dense.bias"] = r(I, std=0.05)
-        sd[p + "output.dense.weight"] = r(W, I, std=0.01); sd[p + "output.dense.bias"] = r(W, std=0.05)
-        sd[p + "output.LayerNorm.weight"] = 1 + r(W, std=0.1); sd[p + "output.LayerNorm.bias"] = r(W, std=0.05)
-    sd["text_proj.weight"] = r(Dp, W, std=0.05); sd["text_proj.bias"] = r(Dp, std=0.05)
-    return sd
+from cases import fusion_sd as _fusion_sd  # noqa: E402  (shared with tests/golden/make_noise_floor.py)
 
 
 def test_fusion_init_is_not_rank_collapsed():
@@ -149,8 +139,9 @@ def test_fusion_init_is_not_rank_collapsed():
     assert mean_cos < 0.7, mean_cos
 
 
+@pytest.mark.parametrize("init", ["small_residual", "reference"])
 @pytest.mark.parametrize("enc_width", [768, 1024])
-def test_blip_fusion_full_shape(enc_width):
+def test_blip_fusion_full_shape(enc_width, init):
     """BASELINE config 4 at the shape it names: med_config.json's BERT-base (12 layers, 768 wide, 12 heads, FFN 3072) with
     cross-attention over 577 image tokens of width `enc_width` (768 = ViT-B, 1024 = create_vit('large'),
     blip4cir/blip.py:206-212), B = 128, 32-token captions, 30 000 x 256 bank, tau 0.03.
@@ -165,7 +156,7 @@ def test_blip_fusion_full_shape(enc_width):
     from spn4cir_amd.fusion import FusionEncoder
     W, layers, heads, I, Dp, vocab, max_pos = 768, 12, 12, 3072, 256, 30524, 512
     B, L, S, M, tau = 128, 32, 577, 30000, 0.03
-    sd = _fusion_sd(layers, W, I, enc_width, Dp, vocab, max_pos, seed=0)
+    sd = _fusion_sd(layers, W, I, enc_width, Dp, vocab, max_pos, seed=0, init=init)
     enc_model = FusionEncoder(W, layers, heads, I, enc_width, Dp, vocab, max_pos, "cuda")
     enc_model.load_state_dict(sd)
     g = torch.Generator().manual_seed(1)
@@ -218,7 +209,7 @@ def test_blip_fusion_full_shape(enc_width):
     dq = ops.bank_grad_q(qb, bank_b, labels[:b].cuda(), 1.0 / tau, lse, 1.0 / b)[:, :Dp].contiguous()
     grads = enc_model.backward(ops.combine_l2norm_bwd(q, inv, dq))
     views = enc_model.named_views(grads)
-    bad, worst = {}, (0.0, None)
+    errs = {}
     for k, p in params.items():
         ref = p.grad
         if k == "embeddings.position_embeddings.weight":
@@ -231,12 +222,8 @@ def test_blip_fusion_full_shape(enc_width):
             vref = params[k.replace(".key.bias", ".value.bias")].grad.norm()
             assert got.norm() < 1e-2 * vref and ref.norm() < 1e-2 * vref, k
             continue
-        e = _rel(got, ref)
-        worst = max(worst, (e, k))
-        if not e < 3e-2:            # observed worst 1.4e-2 / 1.5e-2 (enc_width 768 / 1024, query weights of layers 10 / 11): gate 2 x
-            bad[k] = e
-    print(f"blip fusion enc_width {enc_width}: worst gradient error {worst[0]:.3e} ({worst[1]})")
-    assert not bad, bad
+        errs[k] = _rel(got, ref)
+    _floor_gate(f"blip_{enc_width}" + ("_refinit" if init == "reference" else ""), errs, f"blip fusion enc_width {enc_width} ({init} init)")
 
 
 def test_fp8_bank_trainer_step_100k():
@@ -268,10 +255,7 @@ def test_fp8_bank_trainer_step_100k():
     assert abs(loss.item() - loss_ref) < 1e-2 * max(1.0, abs(loss_ref))
     views = model.tower.named_views(grads)
     errs = {k: _rel(views[k].cpu(), r) for k, r in g_ref.items()}
-    wk = max(errs, key=errs.get)
-    print(f"fp8 bank trainer step: worst gradient error {errs[wk]:.3e} ({wk})")
-    bad = {k: v for k, v in errs.items() if not v < GRAD_GATE_VITL14}
-    assert not bad, bad
+    _floor_gate("vitl14_b8_e4m3", errs, "fp8 bank trainer step")
     # the update: torch.optim.AdamW semantics (train_negplus.py:77-83 hyper-parameters) applied to the step's own gradient
     # (a first Adam step is ~ lr * sign(g): comparing against the oracle's gradient would only re-test sign noise)
     for k in ("text_projection", "transformer.resblocks.5.mlp.c_fc.weight", "positional_embedding"):
@@ -308,8 +292,7 @@ def test_config1_vitb32_inbatch_step_every_gradient():
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-2 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
     named = dict(model.clip.named_parameters())
-    worst = {"matrix": (0.0, None), "vector": (0.0, None)}
-    n = 0
+    errs = {}
     for k, p in params.items():
         if p.grad is None or float(p.grad.abs().max()) == 0.0:
             continue                                        # logit_scale-like entries the step does not touch
@@ -317,19 +300,72 @@ def test_config1_vitb32_inbatch_step_every_gradient():
         assert gk is not None, k
         if k == "token_embedding.weight":                   # only the rows of the batch's ids carry gradient
             rows = torch.unique(ids.long())
-            err = _rel(gk.cpu()[rows], p.grad[rows])
+            errs[k] = _rel(gk.cpu()[rows], p.grad[rows])
         else:
-            err = _rel(gk.cpu(), p.grad)
-        kind = "matrix" if p.dim() >= 2 else "vector"
-        if err > worst[kind][0]:
-            worst[kind] = (err, k)
-        # Weight matrices: the usual 5e-2.  Bias / LayerNorm vectors at B = 4: such a gradient is a sum over the rows that reach the
-        # loss - 4 [EOS] rows, 2 x 4 class tokens - of terms that largely cancel between the reference and the target side of the
-        # in-batch loss (d/dq and d/dt pull in opposite directions), so the bf16 operand rounding is measured against a small
-        # remainder: observed worst 0.130 (a c_proj bias of the visual tower; 0.113 on visual.ln_post.bias: 8 rows), gate 2 x that; the
-        # matrices do not cancel that way (observed worst 3.6e-2).
-        assert err < (5e-2 if kind == "matrix" else 0.26), (k, err)
-        n += 1
-    assert n >= 12 * 12 * 2 + 8
-    print(f"config 1 (ViT-B/32, B=4): loss {loss.item():.5f} oracle {ref.item():.5f}; worst gradient error over {n} tensors: "
-          f"matrices {worst['matrix'][0]:.3e} ({worst['matrix'][1]}), vectors {worst['vector'][0]:.3e} ({worst['vector'][1]})")
+            errs[k] = _rel(gk.cpu(), p.grad)
+    # Bias / LayerNorm vectors at B = 4 are sums over the few rows that reach the loss (4 [EOS] rows, 2 x 4 class tokens) of terms
+    # that largely cancel between the reference and the target side of the in-batch loss: their bf16 FLOOR is itself 5-8e-2 (the
+    # oracle with bf16 operands against its fp32 self), which is what the per-tensor gate prices instead of a blanket constant.
+    assert len(errs) >= 12 * 12 * 2 + 8
+    print(f"config 1 (ViT-B/32, B=4): loss {loss.item():.5f} oracle {ref.item():.5f}")
+    _floor_gate("config1_vitb32_b4", errs, "config 1 (ViT-B/32, B=4)")
+
+
+_FUSE_RESID_CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, %r)
+from spn4cir_amd import _lib, ops, synthetic
+from spn4cir_amd.text_tower import TextTower
+W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
+B, M, tau = 8, 40000, 0.02
+sd = synthetic.text_state_dict(W, layers, D, seed=0)
+ids = synthetic.token_ids(B, seed=1)
+target, refer = synthetic.banks(M, D, seed=2)
+ridx, labels = synthetic.triplet_indices(B, M, seed=4)
+t = TextTower(W, layers, heads, D, device="cuda")
+t.load_clip_state_dict(sd)
+feats = t.forward(ids.cuda())
+q, qb, inv = ops.combine_l2norm_fwd(refer.cuda(), ridx.cuda(), feats)
+stats = ops.bank_stats_fwd(qb, ops.prepare_bank(target.cuda()), labels.cuda(), 1.0 / tau)
+lse, row, mean = ops.bank_loss_finalize(stats, M)
+torch.save({"feats": feats.cpu(), "loss": mean.cpu(), "env": _lib.config_dump()["env"]}, sys.argv[1])
+"""
+
+
+def test_deferred_residual_adds_on_and_off_against_oracle(tmp_path):
+    """The text tower's default keeps the out-projection / c_proj results in bf16 (8-bit mantissa) until the next LayerNorm adds them
+    to the fp32 residual stream; SPN_FUSE_RESID=0 adds them in the GEMM's fp32 epilogue.  The reference's autocast path rounds the
+    same results to fp16 (11 bits): bf16 is 8 x coarser per product, so the claim to check is not equivalence but that BOTH settings
+    stay inside the gates at ViT-L/14 depth - features 1 - cos <= 1e-3 and loss within 1e-2 of the fp32 oracle - and by how much
+    they differ (printed).  Each setting runs in its own process: the library freezes SPN_* when it is loaded."""
+    _need_gpu()
+    import subprocess
+    import sys
+    from spn4cir_amd import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"fr{flag}.pt")
+        p = subprocess.run([sys.executable, "-c", _FUSE_RESID_CHILD % root, out], env=dict(os.environ, SPN_FUSE_RESID=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = torch.load(out)
+        assert res[flag]["env"].get("SPN_FUSE_RESID") == flag
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
+    B, M, tau = 8, 40000, 0.02
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    ids = synthetic.token_ids(B, seed=1)
+    target, refer = synthetic.banks(M, D, seed=2)
+    ridx, labels = synthetic.triplet_indices(B, M, seed=4)
+    from oracle import bank_loss, clip_text
+    with torch.no_grad():
+        f_ref = clip_text.encode_text(sd, ids.long())
+        loss_ref = bank_loss.bank_large_step(refer, ridx, f_ref, target, labels, tau).item()
+    rep = {}
+    for flag, r in res.items():
+        cos = torch.nn.functional.cosine_similarity(r["feats"].double(), f_ref.double(), dim=-1)
+        rep[flag] = ((1 - cos).max().item(), abs(r["loss"].item() - loss_ref))
+        assert rep[flag][0] < 1e-3 and rep[flag][1] < 1e-2 * max(1.0, abs(loss_ref)), (flag, rep[flag])
+    print(f"deferred residual adds ON : max 1-cos {rep['1'][0]:.2e}, |dloss| {rep['1'][1]:.2e};  OFF: max 1-cos {rep['0'][0]:.2e}, "
+          f"|dloss| {rep['0'][1]:.2e}  (oracle loss {loss_ref:.5f})")
+    assert not torch.equal(res["1"]["feats"], res["0"]["feats"])              # the switch really selects two code paths

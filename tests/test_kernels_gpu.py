@@ -530,7 +530,10 @@ def _saved_pair_case(ops, bank_loss, B, M, D, tau, fp8, check_z=True, split_q=Tr
 @pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "e4m3"])
 @pytest.mark.parametrize("B,M,D,tau", [(32, 40000, 768, 0.02), (4, 500, 128, 0.01), (33, 1500, 640, 0.02), (1, 7, 128, 0.02),
                                         (127, 9001, 1024, 0.05), (160, 40000, 768, 0.02), (32, 100000, 768, 0.02),
-                                        (128, 30000, 256, 0.03)])
+                                        (128, 30000, 256, 0.03),
+                                        # 192..256 queries: the GEMM-shaped pair behind one call (statistics pass + ONE tail launch for
+                                        # fold / finalize / mean, G^T scaling, dq GEMM); ragged bank sizes, a width other than 768
+                                        (256, 40000, 768, 0.02), (192, 5000, 768, 0.02), (200, 4001, 512, 0.02), (256, 3000, 1024, 0.05)])
 def test_bank_step_single_call(ops, B, M, D, tau, fp8):
     """spn_bank_step (one pass over the bank + ONE tail launch) against the three-call path it replaces
     (spn_bank_stats_fwd_save + spn_bank_loss_finalize + spn_bank_grad_q_saved): lse and dq BIT-identical (a bank-sharded
@@ -551,6 +554,8 @@ def test_bank_step_single_call(ops, B, M, D, tau, fp8):
     lse3, row3, mean3 = ops.bank_loss_finalize(stats, M)
     dq3 = ops.bank_grad_q(qb, bank_b, lab, 1.0 / tau, lse3, 1.0 / B, saved=save2)
     assert torch.equal(lse, lse3) and torch.equal(dq, dq3)           # the same arithmetic in the same order
+    if B >= 192 and not fp8:                                         # the large path repeats the finalize kernel's tree: bit-identical
+        assert torch.equal(row, row3) and torch.equal(mean, mean3)
     assert (row - row3).abs().max() < 2e-5
     assert abs(mean.item() - mean3.item()) < 2e-5 * max(1.0, abs(mean3.item()))
     if not fp8:      # oracle on the operands the kernels see (the e4m3 kernels' operand model: test_bank_fused_single_pass)
