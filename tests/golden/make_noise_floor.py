@@ -2,9 +2,13 @@
 oracle); no /root/reference.      python tests/golden/make_noise_floor.py [case ...]   -> noise_floor.json
 
 For every full-size case the oracle step runs twice on the CPU: in fp32, and with every matrix-product operand rounded to
-bf16 with fp32 accumulation (oracle/noise.py - forward AND backward products; the arithmetic class of the MI355X kernels and,
-with fp16, of the reference's own autocast path).  The per-tensor relative L2 distance between the two gradient sets is what
-operand rounding alone costs on THIS model, batch and seed: the floor.  The GPU tests then assert
+bf16 with fp32 accumulation (oracle/noise.py - forward AND backward products, bias gradients summed from the rounded output
+gradient; the arithmetic class of the MI355X kernels and, with fp16, of the reference's own autocast path).  The per-tensor
+relative L2 distance between the two gradient sets is what operand rounding alone costs on THIS model, batch and seed.  It is a
+random variable of the rounding pattern - gradients that are remainders of cancelling sums (bias / LayerNorm vectors at B = 4)
+move by up to 1.7x between equally legitimate patterns - so it is sampled on four rounding grids (x -> bf16(x s) / s,
+s = 2^(r/4)) and the floor of a tensor is the RMS over the samples (`operands`; the largest sample is kept as `operands_max`).
+The GPU tests then assert
     HIP-vs-oracle error  <=  1.5 x floor     (per tensor; the ratio is printed)
 instead of an absolute constant.  `autocast` = the same with every product's OUTPUT rounded too (the reference's storage
 class under torch.cuda.amp.autocast) - recorded beside it for information.
@@ -39,13 +43,18 @@ def _grads(step, sd):
     return out, {k: p.grad for k, p in params.items() if p.grad is not None and float(p.grad.abs().max()) > 0}
 
 
+REALISATIONS = 4
+
+
 def floors(step, sd, row_subset=None):
-    """-> dict(loss_fp32, loss_abs_diff, feat_max_1_minus_cos, operands={tensor: floor}, autocast={tensor: floor})"""
+    """-> dict(loss_fp32, operands={tensor: RMS floor over REALISATIONS rounding grids}, operands_max={tensor: largest sample},
+    autocast={tensor: floor with outputs rounded too, one sample}, feature / loss deviations of the first sample)"""
     torch.manual_seed(0)
     o32, g32 = _grads(step, sd)
-    res = {"loss_fp32": float(o32["loss"].detach())}
-    for tag, outputs in (("operands", False), ("autocast", True)):
-        with noise.bf16_gemm_operands(outputs=outputs) as m:
+    res = {"loss_fp32": float(o32["loss"].detach()), "realisations": REALISATIONS}
+
+    def sample(outputs, r):
+        with noise.bf16_gemm_operands(outputs=outputs, realisation=r) as m:
             ob, gb = _grads(step, sd)
         assert m.products > 0
         fl = {}
@@ -54,10 +63,18 @@ def floors(step, sd, row_subset=None):
             if row_subset and k in row_subset:
                 got, ref = got[row_subset[k]], ref[row_subset[k]]
             fl[k] = noise.rel_l2(got, ref)
-        res[tag] = fl
         cos = torch.nn.functional.cosine_similarity(ob["feats"].double(), o32["feats"].double(), dim=-1)
-        res[f"{tag}_loss_abs_diff"] = abs(float(ob["loss"].detach()) - float(o32["loss"].detach()))
-        res[f"{tag}_feat_max_1_minus_cos"] = float((1 - cos).max())
+        return fl, abs(float(ob["loss"].detach()) - float(o32["loss"].detach())), float((1 - cos).max())
+
+    samples = []
+    for r in range(REALISATIONS):
+        fl, dl, dc = sample(False, r)
+        samples.append(fl)
+        if r == 0:
+            res["operands_loss_abs_diff"], res["operands_feat_max_1_minus_cos"] = dl, dc
+    res["operands"] = {k: (sum(s_[k] ** 2 for s_ in samples) / len(samples)) ** 0.5 for k in samples[0]}
+    res["operands_max"] = {k: max(s_[k] for s_ in samples) for k in samples[0]}
+    res["autocast"], res["autocast_loss_abs_diff"], res["autocast_feat_max_1_minus_cos"] = sample(True, 0)
     return res
 
 
@@ -134,7 +151,7 @@ def main():
     for name in (sys.argv[1:] or list(CASES)):
         t0 = time.time()
         r = CASES[name]()
-        for tag in ("operands", "autocast"):
+        for tag in ("operands", "operands_max", "autocast"):
             r[tag] = {k: float(f"{v:.4e}") for k, v in r[tag].items()}
         data[name] = r
         ops_ = r["operands"]

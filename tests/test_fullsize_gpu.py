@@ -27,6 +27,11 @@ def _floor_gate(case, errs, what):
         floor = json.load(f)[case]["operands"]
     missing = [k for k in errs if k not in floor]
     assert not missing, (case, missing[:5])
+    dump = os.environ.get("SPN_DUMP_ERRS")          # analysis aid: the raw per-tensor errors of this run as JSON under that directory
+    if dump:
+        os.makedirs(dump, exist_ok=True)
+        with open(os.path.join(dump, "errs_" + "".join(c if c.isalnum() else "_" for c in f"{case}_{what}")[:120] + ".json"), "w") as f:
+            json.dump(errs, f)
     ratio = {k: e / floor[k] for k, e in errs.items()}
     top = sorted(ratio.items(), key=lambda t: -t[1])[:3]
     print(f"{what}: {len(errs)} tensors, worst error / bf16-floor ratios " +
