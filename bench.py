@@ -471,7 +471,9 @@ def main():
     target, refer = synthetic.banks(args.bank, D, seed=2)
     if args.bank_mode == "auto":
         args.bank_mode = "replicated" if args.bank < 1000000 else "sharded"
-    trainer = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode)
+    # pack=False: `value` is the dense 77-token computation the reference performs (the drop-in's DEFAULT is the packed mode,
+    # reported separately below as `packed_eot`)
+    trainer = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False)
     trainer.set_banks(refer, target)
 
     B = args.batch_per_gpu
@@ -537,15 +539,18 @@ def main():
     # computation the reference performs; this only reports what the optional mode buys on these caption lengths.
     packed = None
     if not args.no_packed:
-        cu, total = trainer.tower.cu_seqlens(ids_all[sl])
-        cu = cu.to(dev)
-        ids_p = ids[:, :trainer.tower.live_length(ids_all[sl])].contiguous()     # padding columns only beyond the longest caption
+        # as a training loop runs it: the ids also on the host every step (they come from the tokenizer there), the trainer
+        # derives the prefix sums and uploads them through its pinned staging buffer - no stream synchronisation
+        ids_host_p = ids_all[sl]
+        _, total = trainer.tower.cu_seqlens(ids_host_p)
+        ids_p = ids[:, :trainer.tower.live_length(ids_host_p)].contiguous()     # padding columns only beyond the longest caption
+        trainer.pack = True
         for _ in range(max(2, args.warmup)):
-            lp = trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
+            lp = trainer.step(ids_p, ridx, labels, ids_host=ids_host_p)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            lp = trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
+            lp = trainer.step(ids_p, ridx, labels, ids_host=ids_host_p)
         barrier()
         dtp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
@@ -553,24 +558,26 @@ def main():
         packed = {"value": round(B_global * args.steps / dtp.item(), 1), "unit": "triplets/sec",
                   "ms_per_step": round(dtp.item() / args.steps * 1e3, 3), "live_rows_rank0": total,
                   "dense_rows_per_rank": B * ids.shape[1], "loss_last": round(float(lp.item()), 5),
-                  "note": "optional TextTower packed mode (pack_eot); not the headline value"}
+                  "note": "TextTower packed mode = the DEFAULT of CIRPlus (pack_eot) and Stage2Trainer (pack) since round 5: "
+                          "bit-identical features; per-step host prefix sums + pinned upload included; not the headline value"}
         if prof:
             # the same per-class breakdown for the packed step (rocprofv3 table: profiles/r03_packed_kernel_stats.txt);
             # every rank runs the steps (they contain collectives), rank 0 reports its records
             lib.spn_prof_enable(max(64, 200 * args.kernel_pass_steps))
             lib.spn_prof_select(0xFFFFFFFF, 1)
             for _ in range(args.kernel_pass_steps):
-                trainer.step(ids_p, ridx, labels, cu, total, ids_host=ids_host)
+                trainer.step(ids_p, ridx, labels, ids_host=ids_host_p)
             torch.cuda.synchronize()
             lib.spn_prof_disable()
             packed["kernels"] = collect_kernels(lib, args.kernel_pass_steps, total, W)
             lib.spn_prof_reset()
 
+    trainer.pack = False
     # N > 1: the other bank mode, measured briefly with the same barrier / max-over-ranks protocol (not the headline)
     alt = None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
         other = "sharded" if args.bank_mode == "replicated" else "replicated"
-        tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other)
+        tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other, pack=False)
         tr2.set_banks(refer, target)
         for _ in range(max(2, args.warmup)):
             tr2.step(ids, ridx, labels, ids_host=ids_host)

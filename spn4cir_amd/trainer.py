@@ -42,8 +42,13 @@ def wgrad_groups(layers, world):
 
 class Stage2Trainer:
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="replicated", check_finite=False):
+                 bank_mode="replicated", check_finite=False, pack=True):
         self.model, self.tower = model, model.tower
+        # pack (default): when step() gets the ids on the host too (ids_host=), the text tower computes only the rows up to each
+        # caption's EOT token - same features bit for bit, same loss and gradients.  The prefix sums are built on the host and go
+        # up through a pinned staging buffer without synchronising the stream.
+        self.pack = bool(pack)
+        self._cu_pinned = None
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.group = group
         self.world, self.rank = _world(group)
@@ -80,10 +85,24 @@ class Stage2Trainer:
     def step(self, ids, refer_idx, labels, cu_seqlens=None, total_rows=0, ids_host=None):
         """ids int32 [B_local, L], refer_idx / labels int64 [B_local] (device). Returns the global mean
         loss as a 1-element device tensor.  cu_seqlens / total_rows (TextTower.cu_seqlens of the host ids,
-        uploaded) switch the text tower to its packed mode: same result, only live rows computed.
+        uploaded) switch the text tower to its packed mode: same result, only live rows computed; with `ids_host` and the
+        trainer's pack=True (default) they are derived here.
         ids_host (data parallel only): the same ids as a CPU tensor - the token-embedding gradient is then summed over the
         ranks as touched rows (SparseRowReducer) instead of as a dense 152 MB all-reduce."""
         t = self.tower
+        if cu_seqlens is None and self.pack and ids_host is not None:
+            cu_host, total_rows = t.cu_seqlens(ids_host)
+            if self._cu_pinned is None or self._cu_pinned.numel() != cu_host.numel():
+                self._cu_pinned = torch.empty(cu_host.numel(), dtype=torch.int32).pin_memory()
+                self._cu_dev = torch.empty(cu_host.numel(), dtype=torch.int32, device=t.device)
+                self._cu_free = None
+            if self._cu_free is not None:
+                self._cu_free.synchronize()               # the previous step's upload has left the staging buffer (long ago)
+            self._cu_pinned.copy_(cu_host)
+            self._cu_dev.copy_(self._cu_pinned, non_blocking=True)
+            self._cu_free = torch.cuda.Event()
+            self._cu_free.record()
+            cu_seqlens = self._cu_dev
         sparse = self.sparse_embed is not None and ids_host is not None and not self.check_finite
         if sparse:
             self.sparse_embed.plan(ids_host)              # host-side collectives only; before any device work of the step

@@ -59,6 +59,19 @@ def test_cirplus_reference_style_loop(golden_dir):
     loss2 = model.forward(ids, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]),
                           torch.from_numpy(s["ref_img_ids"]))["bank_loss"]
     assert loss2.item() < loss.item()                                  # one step on the same batch lowers the loss
+    # the packed text tower is the DEFAULT of the drop-in (ids on the host, as the DataLoader hands them over): same features bit
+    # for bit and the same loss as the dense 77-position run
+    assert model.pack_eot and model._pack[0] is not None and model._pack[1] < ids.numel()
+    dense = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=True, pack_eot=False)
+    dense.refer_bank, dense.target_bank = model.refer_bank, torch.from_numpy(s["target_bank"])
+    fresh = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=True)
+    fresh.refer_bank, fresh.target_bank = model.refer_bank, torch.from_numpy(s["target_bank"])
+    args = (ids, torch.arange(B), torch.from_numpy(s["tgt_img_ids"]), torch.from_numpy(s["ref_img_ids"]))
+    lp, ld = fresh.forward(*args)["bank_loss"], dense.forward(*args)["bank_loss"]
+    assert dense._pack[0] is None and abs(lp.item() - ld.item()) < 1e-6 * max(1.0, abs(ld.item()))
+    with torch.enable_grad():
+        fp, fd = fresh.tower.forward(fresh.tokenize(ids), *fresh._pack).clone(), dense.tower.forward(dense.tokenize(ids)).clone()
+    assert torch.equal(fp, fd)
     # per-triplet reference rows (plus=False, models_negplus.py:135)
     model2 = CIRPlus(sd, tau=float(s["tau"]), device=torch.device("cuda"), plus=False)
     model2.refer_bank = torch.from_numpy(s["trip_bank"])

@@ -10,7 +10,7 @@ dev = torch.device("cuda")
 W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
 model = CIRPlus(synthetic.text_state_dict(W, layers, D, seed=0), tau=0.02, device=dev, plus=True)
 target, refer = synthetic.banks(40000, D, seed=2)
-tr = Stage2Trainer(model, lr=2e-5)
+tr = Stage2Trainer(model, lr=2e-5, pack=False)      # this tool passes cu_seqlens itself
 tr.set_banks(refer, target)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256          # triplets per step (second argument)
 ids_h = synthetic.token_ids(B, seed=1)
