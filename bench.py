@@ -75,6 +75,8 @@ def parse():
     p.add_argument("--recall-queries", type=int, default=2000,
                    help="queries of the synthetic retrieval check (SURVEY 8d: 2 000; the CPU oracle encodes every one of "
                         "them in fp32, ~0.05 s each on 32 threads)")
+    p.add_argument("--blip-images", type=int, default=30000,
+                   help="images in the blip_config4 block's device-resident token bank (config 4: 30 000 = 26.6 / 35.4 GB bf16)")
     p.add_argument("--no-extra-configs", action="store_true",
                    help="skip the blip_config4 / fp8_config5 blocks (BASELINE configs 4 and 5 on one GPU, after the timed region)")
     p.add_argument("--recall-gallery", type=int, default=6000)
@@ -203,7 +205,7 @@ def blip_config4_block(args, dev):
     for the reference's encoder width (768) and BASELINE's ViT-L (1024).  Not the headline."""
     from spn4cir_amd.fusion import BlipStage2Trainer, FusionEncoder
     out = {}
-    B, L, S, M, images = 128, 32, 577, 30000, 1000
+    B, L, S, M, images = 128, 32, 577, 30000, args.blip_images
     for E in (768, 1024):
         g = torch.Generator().manual_seed(0)
         enc = FusionEncoder(768, 12, 12, 3072, E, 256, 30524, 512, dev)
@@ -219,17 +221,24 @@ def blip_config4_block(args, dev):
         lens = torch.randint(6, L + 1, (B,), generator=g)
         mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int32)
         ids, mask = (ids * mask).to(dev), mask.to(dev)
-        ref_bank = torch.randn(images, S, E, device=dev)
+        # the reference-token bank of ALL 30 000 images, bf16, resident on the device (26.6 GB at enc_width 768,
+        # 35.4 GB at 1024; the reference keeps it fp32 in host RAM and uploads 227 MB per step); filled in chunks (set-up, untimed)
+        ref_bank = torch.empty(images, S, E, dtype=torch.bfloat16, device=dev)
+        dgen = torch.Generator(device=dev).manual_seed(5)
+        for s0 in range(0, images, 1000):
+            n = min(1000, images - s0)
+            ref_bank[s0:s0 + n].copy_(torch.randn(n, S, E, generator=dgen, device=dev, dtype=torch.float32))
         ridx = torch.randint(0, images, (B,), generator=g).to(dev)
         labels = torch.randint(0, M, (B,), generator=g).to(dev)
         tr = BlipStage2Trainer(enc, tau=0.03, lr=5e-6, bank_mode="replicated")
         tr.set_bank(torch.nn.functional.normalize(torch.randn(M, 256, generator=g)))
+        tr.set_token_bank(ref_bank)
         for _ in range(3):
-            loss = tr.step(ids, mask, ref_bank[ridx], labels)
+            loss = tr.step(ids, mask, None, labels, token_idx=ridx)
         torch.cuda.synchronize()
         n, t0 = 10, time.perf_counter()
         for _ in range(n):
-            loss = tr.step(ids, mask, ref_bank[ridx], labels)
+            loss = tr.step(ids, mask, None, labels, token_idx=ridx)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         T, TS, W, I = B * L, B * S, 768, 3072
@@ -242,8 +251,9 @@ def blip_config4_block(args, dev):
         del tr, enc, ref_bank
         torch.cuda.empty_cache()
     out["workload"] = (f"blip4cir stage-2 step: BERT-base fusion (12 x 768, cross-attention over {S} image tokens), B={B}, "
-                       f"L={L}, bank {M}x256, tau 0.03 learnable, AdamW; reference tokens gathered from a device-resident "
-                       f"[{images}, {S}, E] fp32 bank; 10 steps after 3 warm-up; 1 GPU")
+                       f"L={L}, bank {M}x256, tau 0.03 learnable, AdamW; reference tokens gathered by the library "
+                       f"(spn_fusion_fwd_bank) from a device-resident [{images}, {S}, E] bf16 token bank "
+                       f"({images * S * 768 * 2 / 1e9:.1f} / {images * S * 1024 * 2 / 1e9:.1f} GB); 10 steps after 3 warm-up; 1 GPU")
     return out
 
 

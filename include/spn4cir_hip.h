@@ -494,6 +494,23 @@ size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg);
 int spn_fusion_refresh_bf16(const spn_fusion_cfg* cfg, const float* params, void* weights_bf16, void* stream);
 int spn_fusion_fwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                    const int32_t* mask, const float* enc, void* acts, float* proj_out, void* stream);
+/* spn_fusion_fwd with the reference image tokens taken from a DEVICE-RESIDENT bf16 token bank [bank_rows][S][enc_width]
+ * (row = one image's token sequence) through token_idx int64 [B]: replaces `self.refer_bank[refer_indexs].detach().to(self.device)`
+ * (blip4cir/models.py:97-100: a host gather + a 227 MB upload per B = 128 step; the bank is [N, 577, 768] fp32 in host RAM there,
+ * 26.6 GB as bf16 on the device here).  The rows land directly in the bf16 A operand of the cross-attention K/V projections
+ * (med.py:178-181).  An index outside [0, bank_rows) yields zero tokens (never dereferenced). */
+int spn_fusion_fwd_bank(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        const int32_t* mask, const void* token_bank_bf16, int64_t bank_rows, const int64_t* token_idx, void* acts,
+                        float* proj_out, void* stream);
+/* The gather alone: out[b, :] = bank[idx[b], :], rows of row_elems bf16 (multiple of 8, 16-byte aligned buffers). */
+int spn_gather_bank_rows_bf16(const void* bank_bf16, int64_t bank_rows, const int64_t* idx, void* out_bf16, int B, int64_t row_elems,
+                              void* stream);
+/* Learnable temperature (blip4cir/models.py:29 `self.tau = nn.Parameter`, :118 `logits = ... / tau`): with dqk = d loss / d (q / tau)
+ * [B][lddq] and q fp32 [B][D], writes dtau[0] = -alpha * s * (sum_b <q_b, dqk_b>) / tau^2 (s = scale_dev[0], 1 when NULL: autograd's
+ * incoming d(loss); a caller holding d loss / d q instead of d loss / d (q / tau) passes alpha = tau) and inv_tau[0] = 1 / tau
+ * (either output may be NULL); tau is read on the device - no host synchronisation; one workgroup, fixed summation order. */
+int spn_tau_grad(const float* q, const float* dqk, int lddq, const float* tau_dev, int B, int D, float alpha, const float* scale_dev,
+                 float* dtau, float* inv_tau, void* stream);
 int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                    void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream);
 

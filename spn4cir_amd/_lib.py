@@ -159,6 +159,9 @@ _SIGS = {
     "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_refresh_bf16": (i32, [C.POINTER(FusionCfg), vp, vp, vp]),
     "spn_fusion_fwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "spn_fusion_fwd_bank": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]),
+    "spn_gather_bank_rows_bf16": (i32, [vp, C.c_int64, vp, vp, i32, C.c_int64, vp]),
+    "spn_tau_grad": (i32, [vp, vp, i32, vp, i32, i32, C.c_float, vp, vp, vp, vp]),
     "spn_fusion_bwd": (i32, [C.POINTER(FusionCfg), vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "spn_prof_enable": (i32, [i32]),
     "spn_prof_select": (i32, [C.c_uint, i32]),

@@ -27,17 +27,18 @@ from .vision_tower import VisionTower
 
 class _FusionBankStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, tau_param, model, ids, mask, tokens, labels):
+    def forward(ctx, anchor, tau_param, model, ids, mask, token_bank, token_idx, labels):
         enc = model.fusion
         tau = float(tau_param.detach())
-        proj = enc.forward(ids, mask, tokens)
+        proj = enc.forward(ids, mask, token_bank=token_bank, token_idx=token_idx)
         q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
         bank = model._target_bank_dev
         saved = ops.bank_logits_buffer(qb.shape[0], bank.shape[0], qb.device)
         stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
-        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0], saved=saved)
-        return mean.reshape(()).clone()
+        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0], saved=saved,
+                                        tau_dev=tau_param.detach().reshape(1))
+        return mean.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -47,12 +48,16 @@ class _FusionBankStep(torch.autograd.Function):
         # the incoming d(loss) scales the (linear) backward on the device: no host synchronisation on it
         scale = grad_out.detach().to(torch.float32).reshape(1)
         dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], 1.0 / st["B"],
-                             M_total=bank.shape[0], saved=st["saved"])[:, :enc.Dp].contiguous()
-        dtau = (-(st["q"] * dq).sum() / st["tau"] * scale[0]).reshape(())   # models.py:29: tau is an nn.Parameter
+                             M_total=bank.shape[0], saved=st["saved"])
+        # models.py:29: tau is an nn.Parameter.  dq = d loss / d q here, so d loss / d tau = -(1 / tau) sum q . dq = tau x the
+        # kernel's -(sum) / tau^2, times autograd's incoming scalar - one launch, nothing computed by torch
+        dtau = torch.empty(1, dtype=torch.float32, device=dq.device)
+        ops.tau_grad(st["q"], dq, st["tau_dev"], dtau, alpha=st["tau"], scale_dev=scale)
         snap = gradsink.snapshot(m._params, enc.grads, enc.named_views)
-        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dq, scale=scale))
+        dqc = dq if dq.shape[1] == enc.Dp else dq[:, :enc.Dp].contiguous()
+        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dqc, scale=scale))
         gradsink.publish(m._params, flat, enc.named_views, snap)
-        return torch.zeros((), device=grad_out.device), dtau, None, None, None, None, None
+        return None, dtau.reshape(()), None, None, None, None, None, None
 
 
 class BlipRetrievalFacade(nn.Module):
@@ -161,7 +166,7 @@ class CIRPlus(nn.Module):
         if transform == "targetpad":
             from .preprocess import TargetPadTransform
             self.preprocess = TargetPadTransform(target_ratio, self.input_dim, self.device)
-        self.refer_bank = None
+        self._refer_bank = self._refer_bank_dev = None
         self._target_bank = self._target_bank_dev = None
 
     def _register(self, dotted, param):
@@ -182,6 +187,18 @@ class CIRPlus(nn.Module):
     def target_bank(self, bank):
         self._target_bank = bank
         self._target_bank_dev = None if bank is None else ops.prepare_bank(bank.to(self.device, torch.float32))
+
+    @property
+    def refer_bank(self):
+        return self._refer_bank
+
+    @refer_bank.setter
+    def refer_bank(self, bank):
+        """[N, S, W] reference-token bank (fp32 in host RAM in the reference, blip4cir/models.py:47,76).  The training step reads
+        it from a bf16 image on the device, built on the first forward() after an assignment (26.6 GB at 30 000 x 577 x 768;
+        ops.token_bank_bf16 uploads in chunks) - the reference gathers on the host and uploads 227 MB per step (models.py:97-100)."""
+        self._refer_bank = bank
+        self._refer_bank_dev = None
 
     def load_refer_bank(self, bank_path):
         self.refer_bank = torch.load(bank_path)
@@ -280,9 +297,14 @@ class CIRPlus(nn.Module):
         parameters and of `tau`."""
         ids, mask = self.tokenize(text)
         idx = refer_indexs if self.plus else indexs
-        tokens = self.refer_bank[idx.to(self.refer_bank.device)].to(self.device, torch.float32)
+        if self._refer_bank is None:
+            raise RuntimeError("no reference-token bank: extract_bank_features / load_refer_bank first (train.py:103-108)")
+        ops.check_index_range(idx, self._refer_bank.shape[0], "refer_indexs" if self.plus else "indexs")
+        if self._refer_bank_dev is None:
+            self._refer_bank_dev = ops.token_bank_bf16(self._refer_bank, self.device)
         labels = target_indexs.to(self.device, torch.int64)
-        loss = _FusionBankStep.apply(self._anchor, self.tau, self, ids, mask, tokens, labels)
+        loss = _FusionBankStep.apply(self._anchor, self.tau, self, ids, mask, self._refer_bank_dev,
+                                     idx.to(self.device, torch.int64), labels)
         return {"bank_loss": loss}
 
     def parameters_changed(self):

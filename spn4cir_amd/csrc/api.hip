@@ -522,6 +522,26 @@ int spn_fusion_fwd(const spn_fusion_cfg* cfg, const float* params, const void* w
     return fusion_fwd(fc(cfg), params, CBF(weights_bf16), ids, mask, enc, (char*)acts, proj_out, ST(stream));
 }
 
+int spn_fusion_fwd_bank(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
+                        const int32_t* mask, const void* token_bank_bf16, int64_t bank_rows, const int64_t* token_idx, void* acts,
+                        float* proj_out, void* stream) {
+    if (!cfg || !params || !weights_bf16 || !ids || !token_bank_bf16 || !token_idx || bank_rows <= 0 || !acts || !proj_out)
+        return SPN_ERR_ARG;
+    return fusion_fwd(fc(cfg), params, CBF(weights_bf16), ids, mask, nullptr, (char*)acts, proj_out, ST(stream), CBF(token_bank_bf16),
+                      token_idx, bank_rows);
+}
+
+int spn_gather_bank_rows_bf16(const void* bank_bf16, int64_t bank_rows, const int64_t* idx, void* out_bf16, int B, int64_t row_elems,
+                              void* stream) {
+    if (row_elems <= 0) return SPN_ERR_ARG;
+    return gather_bank_rows_bf16(CBF(bank_bf16), idx, bank_rows, BF(out_bf16), B, (size_t)row_elems, ST(stream));
+}
+
+int spn_tau_grad(const float* q, const float* dqk, int lddq, const float* tau_dev, int B, int D, float alpha, const float* scale_dev,
+                 float* dtau, float* inv_tau, void* stream) {
+    return tau_grad(q, dqk, lddq, tau_dev, B, D, alpha, scale_dev, dtau, inv_tau, ST(stream));
+}
+
 int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                    void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, void* stream) {
     if (!cfg || !params || !weights_bf16 || !ids || !acts || !dproj || !grads || !ws) return SPN_ERR_ARG;

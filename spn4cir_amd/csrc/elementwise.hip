@@ -43,6 +43,92 @@ int scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, bf16
     return SPN_OK;
 }
 
+// out[b, :] = bank[idx[b], :] for rows of `row_elems` bf16 (a multiple of 8): the reference-token gather of the BLIP step
+// (blip4cir/models.py:97-100: refer_bank[refer_indexs] - there a host gather + a 227 MB upload per step) from a bf16 token bank
+// that lives on the device, straight into the K/V projections' A operand.  An index outside the bank writes zeros (never
+// dereferenced).  grid = (chunks per row, B): 16-byte loads / stores, every lane one piece per iteration.
+__global__ __launch_bounds__(256) void gather_bank_rows_bf16_kernel(const bf16_t* __restrict__ bank, const int64_t* __restrict__ idx,
+                                                                   int64_t n_rows, bf16_t* __restrict__ out, size_t row_elems) {
+    const int b = blockIdx.y;
+    const int64_t r = idx[b];
+    const bool ok = r >= 0 && r < n_rows;
+    const u32x4* src = (const u32x4*)(bank + (size_t)(ok ? r : 0) * row_elems);
+    u32x4* dst = (u32x4*)(out + (size_t)b * row_elems);
+    const size_t n16 = row_elems / 8;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = ok ? __builtin_nontemporal_load(src + i) : z;
+}
+
+int gather_bank_rows_bf16(const bf16_t* bank, const int64_t* idx, int64_t n_rows, bf16_t* out, int B, size_t row_elems,
+                          hipStream_t st) {
+    if (!bank || !idx || !out || B <= 0 || n_rows <= 0) return SPN_ERR_ARG;
+    if (row_elems % 8 || ((uintptr_t)bank & 15) || ((uintptr_t)out & 15)) return SPN_ERR_SHAPE;
+    const size_t n16 = row_elems / 8;
+    int gx = (int)((n16 + 255) / 256);
+    const int want = (2048 + B - 1) / B;                // ~8 workgroups per CU over the whole grid
+    if (gx > want) gx = want;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gather_bank_rows_bf16_kernel, dim3(gx, B), dim3(256), 0, st, bank, idx, n_rows, out, row_elems);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+// Learnable temperature of the BLIP step (blip4cir/models.py:29, logits = q . bank / tau): with dqk = d loss / d (q / tau),
+//   d loss / d tau = -(sum_b <q_b, dqk_b>) / tau^2   (times alpha and an optional device scalar: a caller whose gradient
+//   is d loss / d q passes alpha = tau, autograd's incoming d(loss) as the scalar),   and 1 / tau for the kernels that scale by it.
+// One workgroup, fixed summation order (thread = (row mod 4, column quad); then the 256-leaf tree): bit-reproducible.
+__global__ __launch_bounds__(256) void tau_grad_kernel(const float* __restrict__ q, const float* __restrict__ dqk, int lddq,
+                                                      const float* __restrict__ tau, int B, int D, float alpha,
+                                                      const float* __restrict__ scale_dev, float* __restrict__ dtau,
+                                                      float* __restrict__ inv_tau) {
+    __shared__ float red[256];
+    // thread = (row group tid / 64, column quad lane): 16-byte loads, four rows in flight per thread, no integer division
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        if (c + 4 <= D && (D % 4) == 0 && (lddq % 4) == 0) {
+            int b = rg;
+            for (; b + 12 < B; b += 16) {
+                f32x4 a[4], g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] = *(const f32x4*)(q + (size_t)(b + 4 * k) * D + c);
+                    g[k] = *(const f32x4*)(dqk + (size_t)(b + 4 * k) * lddq + c);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc += a[k][0] * g[k][0] + a[k][1] * g[k][1] + a[k][2] * g[k][2] + a[k][3] * g[k][3];
+            }
+            for (; b < B; b += 4) {
+                const f32x4 a = *(const f32x4*)(q + (size_t)b * D + c), g = *(const f32x4*)(dqk + (size_t)b * lddq + c);
+                acc += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+            }
+        } else {
+            for (int b = rg; b < B; b += 4)
+                for (int e = c; e < min(c + 4, D); ++e) acc += q[(size_t)b * D + e] * dqk[(size_t)b * lddq + e];
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float it = 1.0f / tau[0];
+        if (dtau) dtau[0] = -red[0] * it * it * alpha * (scale_dev ? scale_dev[0] : 1.0f);
+        if (inv_tau) inv_tau[0] = it;
+    }
+}
+
+int tau_grad(const float* q, const float* dqk, int lddq, const float* tau, int B, int D, float alpha, const float* scale_dev,
+             float* dtau, float* inv_tau, hipStream_t st) {
+    if (!q || !dqk || !tau || B <= 0 || D <= 0 || lddq < D || (!dtau && !inv_tau)) return SPN_ERR_ARG;
+    hipLaunchKernelGGL(tau_grad_kernel, dim3(1), dim3(256), 0, st, q, dqk, lddq, tau, B, D, alpha, scale_dev, dtau, inv_tau);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
     if (n == 0) return SPN_OK;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, x, y, n);
@@ -506,8 +592,12 @@ int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx
 // Dead-token elimination for the causal text tower: rows after the EOT token influence neither the pooled
 // feature nor any gradient, so only the cu[B] live rows are materialised (sequence b = rows cu[b]..cu[b+1]-1).
 __global__ void build_row_map_kernel(const int32_t* __restrict__ cu, int32_t* __restrict__ row_b,
-                                     int32_t* __restrict__ row_l, int32_t* __restrict__ eot_row) {
+                                     int32_t* __restrict__ row_l, int32_t* __restrict__ eot_row, int32_t* __restrict__ cu_copy) {
     const int b = blockIdx.x, r0 = cu[b], n = cu[b + 1] - r0;
+    if (cu_copy && threadIdx.x == 0) {               // the caller's prefix sums into the activation arena (no runtime memcpy)
+        cu_copy[b] = r0;
+        if (b == (int)gridDim.x - 1) cu_copy[b + 1] = r0 + n;
+    }
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         row_b[r0 + l] = b;
         row_l[r0 + l] = l;
@@ -515,8 +605,8 @@ __global__ void build_row_map_kernel(const int32_t* __restrict__ cu, int32_t* __
     if (threadIdx.x == 0) eot_row[b] = r0 + n - 1;
 }
 
-int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st) {
-    hipLaunchKernelGGL(build_row_map_kernel, dim3(B), dim3(64), 0, st, cu, row_b, row_l, eot_row);
+int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st, int32_t* cu_copy) {
+    hipLaunchKernelGGL(build_row_map_kernel, dim3(B), dim3(64), 0, st, cu, row_b, row_l, eot_row, cu_copy);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }

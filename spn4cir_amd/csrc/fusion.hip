@@ -223,7 +223,8 @@ static AttnArgs cross_attn_args(const FusionCfg& c, const FusionLayerActs& A) {
 }
 
 int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* mask,
-               const float* enc, char* acts, float* proj_out, hipStream_t st) {
+               const float* enc, char* acts, float* proj_out, hipStream_t st, const bf16_t* token_bank, const int64_t* token_idx,
+               int64_t bank_rows) {
     SPN_TRYF(fusion_check(c));
     FusionLayout t;
     fusion_layout(c, &t);
@@ -232,7 +233,10 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     hipLaunchKernelGGL(fusion_mask_kernel, dim3((c.B + 63) / 64), dim3(64), 0, st, mask, A.key_bias, A.last, A.zero_idx, c.B,
                        c.L);
     SPN_CHECK_LAUNCH();
-    SPN_TRYF(cast_f32_bf16(enc, A.enc_b, (size_t)TS * E, st));
+    // image tokens of the batch as the bf16 A operand of the K/V projections: cast of a caller-gathered fp32 block, or gathered
+    // here from a device-resident bf16 token bank (row = one image's S x E tokens; blip4cir/models.py:97-100)
+    if (token_bank) SPN_TRYF(gather_bank_rows_bf16(token_bank, token_idx, bank_rows, A.enc_b, c.B, (size_t)c.S * E, st));
+    else SPN_TRYF(cast_f32_bf16(enc, A.enc_b, (size_t)TS * E, st));
     SPN_TRYF(embed_fwd(ids, params + t.word, params + t.pos, A.emb, c.B, c.L, W, c.vocab, st));
     FusionLayerActs first = fusion_layer_acts_at(A.layers, c);
     SPN_TRYF(layernorm_fwd(A.emb, params + t.emb_ln_g, params + t.emb_ln_b, first.xb_in, first.x_in, A.emb_mean, A.emb_rstd, T,

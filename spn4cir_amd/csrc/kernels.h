@@ -92,6 +92,9 @@ int negtype_head(const float* R, const float* T, const float* I, int B, int D, f
 
 // elementwise.hip
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
+int gather_bank_rows_bf16(const bf16_t* bank, const int64_t* idx, int64_t n_rows, bf16_t* out, int B, size_t row_elems, hipStream_t st);
+int tau_grad(const float* q, const float* dqk, int lddq, const float* tau, int B, int D, float alpha, const float* scale_dev,
+             float* dtau, float* inv_tau, hipStream_t st);
 // y[b, :D] = bf16(x[b, :] * s), y[b, D:ldo] = 0; s = *scale_dev (device scalar) or its reciprocal
 int scale_cast_bf16(const float* x, const float* scale_dev, int reciprocal, bf16_t* y, int B, int D, int ldo, hipStream_t st);
 int transpose_bf16(const bf16_t* x, bf16_t* y, int rows, int cols, hipStream_t st);             // y[c][r] = x[r][c]
@@ -128,7 +131,7 @@ int eot_argmax(const int32_t* ids, int32_t* eot, int B, int L, hipStream_t st);
 int gather_rows_f32(const float* x, const int32_t* eot, float* out, int B, int L, int W, hipStream_t st);
 int scatter_rows_f32(const float* src, const int32_t* eot, float* dx, bf16_t* dx_bf16, int B, int L, int W,
                      hipStream_t st);
-int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st);
+int build_row_map(const int32_t* cu, int32_t* row_b, int32_t* row_l, int32_t* eot_row, int B, hipStream_t st, int32_t* cu_copy = nullptr);
 int embed_fwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* row_l, const float* tok_emb,
                      const float* pos_emb, float* x, int T, int L, int W, int vocab, hipStream_t st);
 size_t embed_bwd_packed_ws_bytes(int L, int W);

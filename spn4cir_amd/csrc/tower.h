@@ -85,7 +85,8 @@ size_t fusion_act_bytes(const FusionCfg& c);
 size_t fusion_ws_bytes(const FusionCfg& c);
 int fusion_refresh_bf16(const FusionCfg& c, const float* params, bf16_t* wb, hipStream_t st);
 int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* mask,
-               const float* enc, char* acts, float* proj_out, hipStream_t st);
+               const float* enc, char* acts, float* proj_out, hipStream_t st, const bf16_t* token_bank = nullptr,
+               const int64_t* token_idx = nullptr, int64_t bank_rows = 0);
 int fusion_bwd(const FusionCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts,
                const float* dproj, float* grads, char* ws, size_t ws_bytes, hipStream_t st);
 // phase 0 = head (needs dproj), 1 = layers [l_lo, l_hi) top-down with their weight gradients, 2 = tail (embeddings)

@@ -530,10 +530,8 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
     BlockActs first = block_acts_at(A.blocks, bc);
     if (c.T > 0) {
         // the prefix sums live in the arena from here on, so the backward phases need no extra argument
-        hipError_t he = hipMemcpyAsync(A.cu, cu_seqlens, (size_t)(c.B + 1) * 4, hipMemcpyDeviceToDevice, st);
-        if (he != hipSuccess) return (int)he;
         bc.cu = A.cu;
-        SPN_TRY(build_row_map(A.cu, A.row_b, A.row_l, A.eot_row, c.B, st));
+        SPN_TRY(build_row_map(cu_seqlens, A.row_b, A.row_l, A.eot_row, c.B, st, cu_seqlens == A.cu ? nullptr : A.cu));
         SPN_TRY(embed_fwd_packed(ids, A.row_b, A.row_l, params + t.tok, params + t.pos, first.x_in, c.T, c.L, c.W, c.vocab,
                                  st));
     } else {

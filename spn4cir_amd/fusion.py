@@ -98,10 +98,24 @@ class FusionEncoder:
         (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
         return self._stale or self.params._version != getattr(self, "_seen_version", -1)
 
-    def forward(self, ids, mask, enc):
-        """ids int32 [B,L], mask int32 [B,L] or None, enc fp32 [B,S,E] (device) -> text_proj output fp32 [B,Dp]."""
+    def forward(self, ids, mask, enc=None, token_bank=None, token_idx=None):
+        """ids int32 [B,L], mask int32 [B,L] or None -> text_proj output fp32 [B,Dp].  The reference image tokens are either
+        `enc` fp32 [B,S,E] (device; cast to bf16 inside) or - the resident-bank form of the training step - rows `token_idx`
+        (int64 [B], device) of `token_bank` bf16 [N,S,E] on the device, gathered by the library straight into the K/V
+        projections' operand (spn_fusion_fwd_bank; blip4cir/models.py:97-100)."""
         B, L = ids.shape
-        S = enc.shape[1]
+        if (enc is None) == (token_bank is None):
+            raise ValueError("give the image tokens either as enc= or as token_bank= + token_idx=")
+        if token_bank is not None:
+            if token_bank.dtype != torch.bfloat16 or not token_bank.is_cuda or token_bank.dim() != 3 or not token_bank.is_contiguous():
+                raise ValueError("token_bank must be a contiguous bf16 [N, S, E] device tensor (ops.token_bank_bf16)")
+            if token_idx is None or token_idx.dtype != torch.int64 or not token_idx.is_cuda or token_idx.numel() != B:
+                raise ValueError("token_idx must be an int64 [B] device tensor")
+            if token_bank.shape[2] != self.E:
+                raise ValueError(f"token_bank width {token_bank.shape[2]} != encoder width {self.E}")
+            S = token_bank.shape[1]
+        else:
+            S = enc.shape[1]
         cfg = self._cfg(B, L, S)
         if self.is_stale():
             check(lib().spn_fusion_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()), "fusion_refresh")
@@ -113,10 +127,15 @@ class FusionEncoder:
             self._key = (B, L, S)
         ids = ids.to(self.device, torch.int32).contiguous()
         mask = None if mask is None else mask.to(self.device, torch.int32).contiguous()
-        enc = enc.to(self.device, torch.float32).contiguous()
         out = torch.empty(B, self.Dp, dtype=torch.float32, device=self.device)
-        check(lib().spn_fusion_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(mask), _p(enc), _p(self._acts),
-                                   _p(out), _stream()), "fusion_fwd")
+        if token_bank is not None:
+            check(lib().spn_fusion_fwd_bank(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(mask), _p(token_bank),
+                                            token_bank.shape[0], _p(token_idx.contiguous()), _p(self._acts), _p(out), _stream()),
+                  "fusion_fwd_bank")
+        else:
+            enc = enc.to(self.device, torch.float32).contiguous()
+            check(lib().spn_fusion_fwd(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(mask), _p(enc), _p(self._acts),
+                                       _p(out), _stream()), "fusion_fwd")
         self._last = (ids, cfg)
         return out
 
@@ -238,23 +257,32 @@ class BlipStage2Trainer:
             self._m_begin = 0
             self._bank = ops.prepare_bank(target_bank.to(dev, torch.float32), bank_dtype)
 
-    def step(self, ids, mask, ref_tokens, labels):
-        """ids/mask int32 [B_local, L], ref_tokens fp32 [B_local, S, E], labels int64 [B_local] global bank rows.
-        Returns the global mean loss (1-element device tensor)."""
+    def set_token_bank(self, refer_bank):
+        """The reference-token bank of blip4cir/models.py:45-89 ([N, 577, W] fp32, host RAM there) as a bf16 image on the device
+        (26.6 GB at 30 000 x 577 x 768): step(..., token_idx=) then gathers the batch's rows on the device."""
+        self._token_bank = ops.token_bank_bf16(refer_bank, self.enc.device)
+
+    def step(self, ids, mask, ref_tokens, labels, token_idx=None):
+        """ids/mask int32 [B_local, L], labels int64 [B_local] global bank rows; the reference image tokens either as
+        ref_tokens fp32 [B_local, S, E] or (ref_tokens=None) as rows token_idx int64 [B_local] of the bank given to
+        set_token_bank.  Returns the global mean loss (1-element device tensor)."""
         enc = self.enc
         from .trainer import wgrad_groups
-        proj = enc.forward(ids, mask, ref_tokens)
+        if ref_tokens is None:
+            if token_idx is None or getattr(self, "_token_bank", None) is None:
+                raise ValueError("step(ref_tokens=None) needs set_token_bank(...) and token_idx=")
+            proj = enc.forward(ids, mask, token_bank=self._token_bank, token_idx=token_idx.to(enc.device, torch.int64))
+        else:
+            proj = enc.forward(ids, mask, ref_tokens)
         q, _, inv = ops.combine_l2norm_fwd(None, None, proj)
         # the temperature is a parameter that lives on the device (models.py:29): logits = (q / tau) . bank with the bank
         # kernels at inv_tau = 1, every factor of tau applied by device-side scalars - no host read, so the host keeps
         # enqueueing the next step while this one runs
-        inv_tau = torch.reciprocal(self.tau)
         qs = ops.scale_cast_bf16(q, self.tau, reciprocal=True, ldo=self._bank.shape[1])
         ctx = self.loss_dp.forward(qs, labels, self._bank, self._m_begin, self._M_total, 1.0, self.ls)
-        dqk = self.loss_dp.backward(ctx)[:, :enc.Dp].contiguous()         # d loss / d (q / tau)
-        if self.learn_tau:
-            self._tau_g.copy_((-(q * dqk).sum() * inv_tau * inv_tau).reshape(1))      # d loss / d tau
-        dproj = ops.combine_l2norm_bwd(q, inv, dqk, scale=inv_tau)
+        dqk = self.loss_dp.backward(ctx)                                  # d loss / d (q / tau), [B, ldq]
+        inv_tau = ops.tau_grad(q, dqk, self.tau, self._tau_g if self.learn_tau else None)     # d loss / d tau and 1 / tau, one launch
+        dproj = ops.combine_l2norm_bwd(q, inv, dqk if dqk.shape[1] == enc.Dp else dqk[:, :enc.Dp].contiguous(), scale=inv_tau)
         groups = wgrad_groups(enc.layers, self.world)
         enc.backward_phased(dproj, self.reducer.on_span_ready, groups if self.world > 1 else None)
         self.reducer.finish()

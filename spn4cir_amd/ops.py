@@ -442,6 +442,44 @@ def bank_grad_q(q_bf16, bank_bf16, labels, inv_tau, row_lse, grad_scale, M_total
 
 
 # -------------------------------------------------------------------------------- AdamW
+def tau_grad(q, dqk, tau_dev, dtau_out=None, alpha=1.0, scale_dev=None):
+    """-> inv_tau (1-element device tensor); dtau_out (optional 1-element fp32 device tensor) <- -alpha * scale_dev *
+    (sum q . dqk) / tau^2 (spn_tau_grad; dqk may carry padding columns: its leading dimension is passed along)."""
+    _req(q, torch.float32, "q")
+    _req(dqk, torch.float32, "dqk")
+    B, D = q.shape
+    inv = torch.empty(1, dtype=torch.float32, device=q.device)
+    check(lib().spn_tau_grad(_p(q), _p(dqk), dqk.stride(0), _p(tau_dev), B, D, float(alpha), _p(scale_dev), _p(dtau_out), _p(inv),
+                             _stream()), "tau_grad")
+    return inv
+
+
+def token_bank_bf16(bank, device, chunk=512):
+    """fp32 / bf16 [N, S, E] token bank (host or device) -> contiguous bf16 [N, S, E] on `device`, uploaded and converted in
+    chunks of `chunk` images (a 30 000 x 577 x 768 bank is 53 GB in fp32: never two copies of it anywhere)."""
+    if bank.dim() != 3:
+        raise ValueError("token bank must be [N, S, E]")
+    if bank.dtype == torch.bfloat16 and bank.is_cuda and bank.is_contiguous():
+        return bank
+    N, S, E = bank.shape
+    out = torch.empty(N, S, E, dtype=torch.bfloat16, device=device)
+    for s in range(0, N, chunk):
+        blk = bank[s:s + chunk].to(device, non_blocking=False)
+        if blk.dtype == torch.float32:
+            check(lib().spn_cast_f32_bf16(_p(blk.contiguous()), _p(out[s:s + chunk]), blk.numel(), _stream()), "cast_f32_bf16")
+        else:
+            out[s:s + chunk].copy_(blk)
+    return out
+
+
+def gather_bank_rows_bf16(bank, idx):
+    """out[b] = bank[idx[b]] for a contiguous bf16 [N, ...] device bank and int64 [B] device indices (spn_gather_bank_rows_bf16)."""
+    row = bank[0].numel()
+    out = torch.empty((idx.numel(),) + tuple(bank.shape[1:]), dtype=torch.bfloat16, device=bank.device)
+    check(lib().spn_gather_bank_rows_bf16(_p(bank), bank.shape[0], _p(idx), _p(out), idx.numel(), row, _stream()), "gather_bank_rows")
+    return out
+
+
 def scale_cast_bf16(x, scale_dev, reciprocal=False, ldo=None):
     """bf16(x * s) with s = the 1-element fp32 DEVICE tensor scale_dev (or 1 / s), zero padded to ldo columns: a query
     scaled by a learnable temperature without reading it on the host (spn_scale_cast_bf16)."""

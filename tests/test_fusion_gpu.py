@@ -354,3 +354,62 @@ def test_blip_reference_call_pattern_strings_to_metrics(golden_dir, tmp_path):
             assert err < 4e-2, (k, err)
     print("worst relative L2 gradient error:", worst)
     assert "blip.temp" in model.state_dict() and named["visual_encoder.blocks.0.attn.qkv.weight"].grad is None
+
+
+def test_token_bank_gather_and_tau_grad(golden_dir):
+    """spn_gather_bank_rows_bf16 (bit-exact copy, zero rows for indices outside the bank), spn_fusion_fwd_bank == spn_fusion_fwd on
+    the same (bf16-representable) tokens, spn_tau_grad against fp64, and the trainer's resident-bank step == its token step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd import ops
+    from spn4cir_amd.fusion import BlipStage2Trainer, FusionEncoder, fusion_cfg_from_state_dict
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn(37, 21, 192, generator=g).to(torch.bfloat16)
+    idx = torch.tensor([5, 0, 36, 5, -1, 37, 12], dtype=torch.int64)
+    out = ops.gather_bank_rows_bf16(bank.cuda(), idx.cuda()).cpu()
+    for b, r in enumerate(idx.tolist()):
+        want = bank[r] if 0 <= r < 37 else torch.zeros_like(bank[0])
+        assert torch.equal(out[b], want), b
+    # tau gradient: dqk with a padded leading dimension, alpha and a device scalar
+    q = torch.randn(9, 40, generator=g)
+    dqk = torch.randn(9, 64, generator=g)
+    tau = torch.tensor([0.037])
+    sc = torch.tensor([3.0])
+    dtau = torch.zeros(1, device="cuda")
+    inv = ops.tau_grad(q.cuda(), dqk.cuda(), tau.cuda(), dtau, alpha=0.5, scale_dev=sc.cuda())
+    ref = -(q.double() * dqk[:, :40].double()).sum() / tau.double() ** 2 * 0.5 * 3.0
+    assert abs(dtau.item() - ref.item()) < 1e-5 * abs(ref.item()) and abs(inv.item() - 1 / 0.037) < 1e-4
+    # the resident-bank forward / step equal the token forward / step when the tokens are bf16-representable
+    z = np.load(os.path.join(golden_dir, "blip_fusion.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    c = fusion_cfg_from_state_dict(sd)
+
+    def make():
+        enc = FusionEncoder(c["hidden"], c["layers"], c["heads"], c["intermediate"], c["enc_width"], sd["text_proj.weight"].shape[0],
+                            c["vocab"], c["max_pos"], "cuda")
+        enc.load_state_dict(sd)
+        return enc
+    ids, mask = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["mask"]).cuda()
+    B = ids.shape[0]
+    tb = torch.randn(11, z["enc"].shape[1], c["enc_width"], generator=g).to(torch.bfloat16).cuda()
+    ti = torch.tensor([3, 10, 0, 3], dtype=torch.int64)[:B].cuda()
+    e1, e2 = make(), make()
+    p_bank = e1.forward(ids, mask, token_bank=tb, token_idx=ti).clone()
+    p_tok = e2.forward(ids, mask, tb[ti].float()).clone()
+    assert torch.equal(p_bank, p_tok)
+    with pytest.raises(ValueError):
+        e1.forward(ids, mask)
+    labels = torch.from_numpy(z["labels"]).cuda()
+    t1, t2 = BlipStage2Trainer(e1, tau=0.03, lr=1e-3), BlipStage2Trainer(e2, tau=0.03, lr=1e-3)
+    for t in (t1, t2):
+        t.set_bank(torch.from_numpy(z["bank"]))
+    t1.set_token_bank(tb)
+    for it in range(2):
+        l1 = t1.step(ids, mask, None, labels, token_idx=ti)
+        l2 = t2.step(ids, mask, tb[ti].float(), labels)
+        if it == 0:
+            assert torch.equal(l1, l2)                              # same forward bit for bit
+    # the word-embedding gradient is a scatter of float atomics (order varies from run to run): last-bit differences after a step
+    assert (l1 - l2).abs().item() < 1e-5 and (e1.params - e2.params).abs().max().item() < 1e-5
+    assert abs(t1.tau.item() - t2.tau.item()) < 1e-7
+    assert t1.tau.item() != 0.03                                    # the learnable temperature moved (models.py:29)

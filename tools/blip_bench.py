@@ -1,6 +1,7 @@
 """BLIP4CIR stage-2 step throughput (BASELINE.json config 4 shape on ONE GPU): BERT-base fusion encoder
 (12 layers, 768, 12 heads, cross-attention over 577 image tokens), B=128, 32-token captions, 30 000 x 256 bank,
-tau 0.03, AdamW; reference token bank resident on the device in fp32 (a random [N_img, 577, 768] slab).
+tau 0.03, AdamW; reference token bank resident on the device in bf16 ([--images, 577, enc_width]: 30 000 images = 26.6 / 35.4 GB),
+gathered per step by the library (spn_fusion_fwd_bank).
 
     python tools/blip_bench.py [--enc-width 768|1024] [--steps 10]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 tools/blip_bench.py
@@ -20,7 +21,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=577)
     ap.add_argument("--enc-width", type=int, default=768)
     ap.add_argument("--bank", type=int, default=30000)
-    ap.add_argument("--images", type=int, default=2000)
+    ap.add_argument("--images", type=int, default=30000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bank-mode", default="sharded", choices=["sharded", "replicated"])
@@ -48,15 +49,19 @@ def main():
     lens = torch.randint(6, L + 1, (B,), generator=g)
     mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int32)
     ids = (ids * mask).to(dev); mask = mask.to(dev)
-    ref_bank = torch.randn(a.images, a.tokens, a.enc_width, device=dev)          # per-image token bank (models.py:76)
+    ref_bank = torch.empty(a.images, a.tokens, a.enc_width, dtype=torch.bfloat16, device=dev)   # per-image token bank (models.py:76)
+    dgen = torch.Generator(device=dev).manual_seed(5)
+    for s0 in range(0, a.images, 1000):
+        n = min(1000, a.images - s0)
+        ref_bank[s0:s0 + n].copy_(torch.randn(n, a.tokens, a.enc_width, generator=dgen, device=dev))
     ridx = torch.randint(0, a.images, (B,), generator=g).to(dev)
     labels = torch.randint(0, a.bank, (B,), generator=g).to(dev)
     trainer = BlipStage2Trainer(enc, tau=0.03, lr=5e-6, bank_mode=a.bank_mode)
     trainer.set_bank(torch.nn.functional.normalize(torch.randn(a.bank, 256, generator=g)))
+    trainer.set_token_bank(ref_bank)
 
     def one(i):
-        tokens = ref_bank[ridx]                                                  # [B, 577, E] gather (models.py:98)
-        return trainer.step(ids, mask, tokens, labels)
+        return trainer.step(ids, mask, None, labels, token_idx=ridx)             # rows gathered on the device (models.py:98)
 
     for i in range(a.warmup):
         loss = one(i)

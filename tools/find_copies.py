@@ -16,6 +16,8 @@ def main():
     from spn4cir_amd.models import CIRPlus
     from spn4cir_amd.trainer import Stage2Trainer
     dev = torch.device("cuda", 0)
+    if "--blip" in sys.argv:
+        return blip(dev)
     W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
     model = CIRPlus(synthetic.text_state_dict(W, layers, D, seed=0), tau=0.02, device=dev, plus=True)
     target, refer = synthetic.banks(40000, D, seed=2)
@@ -36,6 +38,44 @@ def main():
         for _ in range(2):
             tr.step(ids, ridx, lab, **kw)
         torch.cuda.synchronize()
+    report(prof)
+
+
+def blip(dev):
+    """The blip4cir stage-2 step (config 4's shape at a small token bank) under the same lens."""
+    from torch.profiler import ProfilerActivity, profile
+    from spn4cir_amd.fusion import BlipStage2Trainer, FusionEncoder
+    g = torch.Generator().manual_seed(0)
+    enc = FusionEncoder(768, 12, 12, 3072, 768, 256, 30524, 512, dev)
+    with torch.no_grad():
+        for k, v in enc.named_views().items():
+            if k.endswith("LayerNorm.weight"):
+                v.fill_(1.0)
+            elif v.dim() >= 2:
+                v.copy_((torch.randn(v.shape, generator=g) * 0.02).to(dev))
+    enc.mark_stale()
+    B, L, S, M, N = 128, 32, 577, 30000, 500
+    ids = torch.randint(1000, 30522, (B, L), generator=g, dtype=torch.int32)
+    ids[:, 0] = 30523
+    mask = torch.ones(B, L, dtype=torch.int32)
+    ids, mask = ids.to(dev), mask.to(dev)
+    bank = torch.randn(N, S, 768, device=dev).to(torch.bfloat16)
+    ridx = torch.randint(0, N, (B,), generator=g).to(dev)
+    labels = torch.randint(0, M, (B,), generator=g).to(dev)
+    tr = BlipStage2Trainer(enc, tau=0.03, lr=5e-6, bank_mode="replicated")
+    tr.set_bank(torch.nn.functional.normalize(torch.randn(M, 256, generator=g)))
+    tr.set_token_bank(bank)
+    for _ in range(3):
+        tr.step(ids, mask, None, labels, token_idx=ridx)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for _ in range(2):
+            tr.step(ids, mask, None, labels, token_idx=ridx)
+        torch.cuda.synchronize()
+    report(prof)
+
+
+def report(prof):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
     for ev in prof.events():
