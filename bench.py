@@ -62,7 +62,8 @@ def parse():
                         "(no data-path collective: at M = 40 000 the sharded variant puts three latency-bound collectives on the "
                         "critical path to save ~40 us of bank kernel), sharded above (north_star's all-gather of queries)")
     p.add_argument("--no-alt-bank-mode", action="store_true",
-                   help="N > 1: skip the short extra measurement of the OTHER bank mode reported as bank_mode_alt")
+                   help="N > 1: skip the short extra measurements reported as bank_mode_alt (the OTHER bank mode), strong (B_global = "
+                        "256 split over the ranks) and grad_comm_bf16 (bf16 gradient buckets)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-prof", action="store_true")
     p.add_argument("--prof-every", type=int, default=17,
@@ -604,6 +605,43 @@ def main():
                "ms_per_step": round(dta.item() / n_alt * 1e3, 3), "steps": n_alt}
         del tr2
 
+    # N > 1: two more brief measurements with the same protocol, so that the first multi-GPU run settles what DESIGN.md section 6
+    # only predicts - (a) STRONG scaling: config 3's B_global = 256 split over the ranks (256 / N per GPU; SURVEY 8d asks for
+    # both regimes), (b) the gradient buckets exchanged as bf16 (all-to-all + fp32 rank-order sum + all-gather) at the weak shape
+    strong, comm16 = None, None
+    if (world > 1 or force_dp) and not args.no_alt_bank_mode:
+        def brief(tr, ids_, ridx_, labels_, host_, bglob):
+            for _ in range(max(2, args.warmup)):
+                tr.step(ids_, ridx_, labels_, ids_host=host_)
+            barrier()
+            t0_ = time.perf_counter()
+            n_ = max(5, args.steps // 2)
+            for _ in range(n_):
+                tr.step(ids_, ridx_, labels_, ids_host=host_)
+            barrier()
+            d_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+            return {"value": round(bglob * n_ / d_.item(), 1), "unit": "triplets/sec", "ms_per_step": round(d_.item() / n_ * 1e3, 3),
+                    "steps": n_}
+        if 256 % world == 0 and 256 // world >= 8:
+            bs = 256 // world
+            ids_s = synthetic.token_ids(256, seed=1)
+            ridx_s, lab_s = synthetic.triplet_indices(256, args.bank, seed=4)
+            sl_s = slice(rank * bs, (rank + 1) * bs)
+            tr3 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False)
+            tr3.set_banks(refer, target)
+            host_s = ids_s[sl_s].contiguous() if ids_host is not None else None
+            strong = brief(tr3, ids_s[sl_s].to(dev), ridx_s[sl_s].to(dev), lab_s[sl_s].to(dev), host_s, 256)
+            strong.update(scaling="strong", global_batch=256, batch_per_gpu=bs, bank_mode=args.bank_mode)
+            del tr3
+        tr4 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, grad_comm_dtype="bf16")
+        tr4.set_banks(refer, target)
+        comm16 = brief(tr4, ids, ridx, labels, ids_host, B_global)
+        comm16.update(grad_comm_dtype="bf16", note="weak-scaling shape; dense gradient buckets cross the links as bf16 "
+                                                   "(all-to-all, fp32 sum in rank order, all-gather); headline uses fp32 all-reduce")
+        del tr4
+
     if rank == 0:
         per_kernel = {}
         if prof:
@@ -683,6 +721,10 @@ def main():
             out["packed_eot"] = packed
         if alt:
             out["bank_mode_alt"] = alt
+        if strong:
+            out["strong"] = strong
+        if comm16:
+            out["grad_comm_bf16"] = comm16
         if world == 1 and not args.no_recall:     # checker legs run at N = 1 only: the other ranks would sit in the exit barrier
             rec = recall_block(args, sd, model, dev)
             if rec:

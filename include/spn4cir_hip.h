@@ -82,6 +82,12 @@ size_t spn_gemm_tn_grouped_workspace_bytes(int Kr);
 /* ---------------------------------------------------------------- elementwise / reductions */
 int spn_cast_f32_bf16(const float* x, void* y_bf16, size_t n, void* stream);
 /* y = bf16(x) and yt = bf16(x)^T for x [rows, cols]; either output may be NULL */
+int spn_cast_bf16_f32(const void* x_bf16, float* y, size_t n, void* stream);
+/* bf16 gradient exchange between data-parallel replicas (the reference is single-GPU; SURVEY 8d prices the gradient all-reduce at
+ * 247 MB in bf16 against 494 MB in fp32): chunks_bf16 [n_ranks][m] = every rank's bf16 copy of ONE slice of the flat gradient (as an
+ * all-to-all delivers them), out_bf16 [m] = bf16(sum over the ranks in rank order, accumulated in fp32) - the same bits on every
+ * rank.  m % 8 == 0, 16-byte aligned buffers. */
+int spn_sum_ranks_bf16(const void* chunks_bf16, int n_ranks, size_t m, void* out_bf16, void* stream);
 int spn_cast_transpose_f32_bf16(const float* x, void* y_bf16, void* yt_bf16, int rows, int cols, void* stream);
 /* out[c] (+)= sum_r x[r][c]  (bias gradients) */
 int spn_colsum_bf16(const void* x_bf16, int rows, int cols, int ld, float* out, int accumulate, void* ws,

@@ -531,6 +531,12 @@ int spn_fusion_fwd_bank(const spn_fusion_cfg* cfg, const float* params, const vo
                       token_idx, bank_rows);
 }
 
+int spn_cast_bf16_f32(const void* x_bf16, float* y, size_t n, void* stream) { return cast_bf16_f32(CBF(x_bf16), y, n, ST(stream)); }
+
+int spn_sum_ranks_bf16(const void* chunks_bf16, int n_ranks, size_t m, void* out_bf16, void* stream) {
+    return sum_ranks_bf16(CBF(chunks_bf16), n_ranks, m, BF(out_bf16), ST(stream));
+}
+
 int spn_gather_bank_rows_bf16(const void* bank_bf16, int64_t bank_rows, const int64_t* idx, void* out_bf16, int B, int64_t row_elems,
                               void* stream) {
     if (row_elems <= 0) return SPN_ERR_ARG;

@@ -129,6 +129,55 @@ int tau_grad(const float* q, const float* dqk, int lddq, const float* tau, int B
     return SPN_OK;
 }
 
+// bf16 gradient exchange (distributed.GradBucketReducer(comm_dtype="bf16")): the ranks' bf16 chunks of one slice, stacked [G][m],
+// summed in fp32 in RANK ORDER (identical on every rank) and rounded once to bf16 - the value every replica then receives.
+__global__ __launch_bounds__(256) void sum_ranks_bf16_kernel(const bf16_t* __restrict__ x, int G, size_t m8, bf16_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m8; i += (size_t)gridDim.x * 256) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < G; ++r) {
+            const bf16x8 v = *(const bf16x8*)(x + ((size_t)r * m8 + i) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+        *(bf16x8*)(out + i * 8) = o;
+    }
+}
+
+int sum_ranks_bf16(const bf16_t* x, int G, size_t m, bf16_t* out, hipStream_t st) {
+    if (!x || !out || G <= 0) return SPN_ERR_ARG;
+    if (m % 8 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return SPN_ERR_SHAPE;
+    if (!m) return SPN_OK;
+    const size_t m8 = m / 8;
+    const int blocks = (int)((m8 + 255) / 256 < 2048 ? (m8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sum_ranks_bf16_kernel, dim3(blocks), dim3(256), 0, st, x, G, m8, out);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const bf16_t* s = x + i * 4;
+        *(f32x4*)(y + i * 4) = f32x4{bf2f(s[0]), bf2f(s[1]), bf2f(s[2]), bf2f(s[3])};
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) y[i] = bf2f(x[i]);
+}
+
+int cast_bf16_f32(const bf16_t* x, float* y, size_t n, hipStream_t st) {
+    if (!n) return SPN_OK;
+    if (!x || !y) return SPN_ERR_ARG;
+    if (((uintptr_t)y & 15) || ((uintptr_t)x & 7)) return SPN_ERR_SHAPE;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? ((n4 + 255) / 256 ? (n4 + 255) / 256 : 1) : 2048);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks), dim3(256), 0, st, x, y, n);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st) {
     if (n == 0) return SPN_OK;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, x, y, n);

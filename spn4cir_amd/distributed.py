@@ -266,19 +266,99 @@ class SparseRowReducer:
         self._plan = None
 
 
+class _HipExchangeKernels:
+    """The three elementwise passes of the bf16 gradient exchange on the library's kernels (spn_cast_f32_bf16,
+    spn_sum_ranks_bf16, spn_cast_bf16_f32), on torch's current stream."""
+
+    @staticmethod
+    def to_bf16(src_f32, dst_bf16):
+        from . import ops
+        ops.check(ops.lib().spn_cast_f32_bf16(ops._p(src_f32), ops._p(dst_bf16), src_f32.numel(), ops._stream()), "cast_f32_bf16")
+
+    @staticmethod
+    def sum_ranks(chunks_bf16, world, out_bf16):
+        from . import ops
+        ops.check(ops.lib().spn_sum_ranks_bf16(ops._p(chunks_bf16), world, out_bf16.numel(), ops._p(out_bf16), ops._stream()),
+                  "sum_ranks_bf16")
+
+    @staticmethod
+    def to_f32(src_bf16, dst_f32):
+        from . import ops
+        ops.check(ops.lib().spn_cast_bf16_f32(ops._p(src_bf16), ops._p(dst_f32), dst_f32.numel(), ops._stream()), "cast_bf16_f32")
+
+
+class _Bf16Work:
+    """Handle of one bf16 bucket exchange: wait() = the second collective has landed, the summed slice is back in the flat fp32
+    gradient, and the caller's current stream is ordered behind all of it."""
+
+    def __init__(self, reducer, s, e, full, work, comm):
+        self.r, self.s, self.e, self.full, self.work, self.comm = reducer, s, e, full, work, comm
+
+    def wait(self):
+        r = self.r
+        with r._on(self.comm):
+            self.work.wait()
+            r.kernels.to_f32(self.full[:self.e - self.s], r.flat[self.s:self.e])
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.full = None
+
+
 class GradBucketReducer:
     """Sum the flat gradient over ranks in buckets, overlapped with the rest of backward.
 
     `on_span_ready(start, end)` is called by TextTower.backward_phased as soon as the kernels that
     finalise flat[start:end] are enqueued; torch's RCCL stream waits for exactly that point of the
     compute stream and runs the all-reduce concurrently with the following layers.  Small spans are
-    merged until `bucket_elems` is reached (xGMI all-reduce wants >= tens of MB per call)."""
+    merged until `bucket_elems` is reached (xGMI all-reduce wants >= tens of MB per call).
 
-    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20):
+    comm_dtype="bf16" (optional; default fp32 = one all-reduce per bucket): half the bytes on the links (247 MB
+    instead of 494 MB per step for ViT-L/14's text tower) with fp32 accumulation and bit-identical replicas.  Per bucket:
+      cast the slice to bf16 [G x m] -> all-to-all (rank j receives every rank's chunk j) -> sum the G chunks in fp32 IN RANK
+      ORDER, round once to bf16 (spn_sum_ranks_bf16) -> all-gather of the reduced chunks -> cast back into the flat fp32 gradient.
+    Every replica - the chunk's owner included - takes the all-gathered bf16 value, so the replicas stay bit-identical; what the
+    gradient loses is one bf16 rounding of each rank's contribution and one of the sum (the bf16-operand weight-gradient GEMMs
+    that produced it carry rounding of the same size).  The passes run on a dedicated stream between the two collectives; the
+    host never blocks.  `kernels` = the elementwise passes (the HIP kernels by default; CPU tests inject torch ones)."""
+
+    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20, comm_dtype="fp32", kernels=None):
+        if comm_dtype not in ("fp32", "bf16"):
+            raise ValueError(comm_dtype)
         self.flat, self.group, self.bucket_elems = flat_grads, group, bucket_elems
-        self.world, _ = _world(group)
+        self.world, self.rank = _world(group)
+        self.comm_dtype = comm_dtype
+        self.kernels = kernels or _HipExchangeKernels
+        self._comm_stream = None
         self._pending = []      # [(start, end)] contiguous-or-not spans waiting for a bucket
         self._works = []
+
+    def _on(self, stream):
+        import contextlib
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def _exchange_bf16(self, s, e):
+        """-> handle whose wait() completes flat[s:e] = sum over ranks (see the class docstring)."""
+        G, n = self.world, e - s
+        m = ((n + G - 1) // G + 7) // 8 * 8
+        comm = None
+        if self.flat.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+            comm = self._comm_stream
+            comm.wait_stream(torch.cuda.current_stream())          # the slice is final at this point of the compute stream
+        with self._on(comm):
+            # padding behind element n (the tail of the last chunk) stays uninitialised: whatever it sums to lands behind
+            # element n of `full`, which is never read
+            send = torch.empty(G * m, dtype=torch.bfloat16, device=self.flat.device)
+            self.kernels.to_bf16(self.flat[s:e], send[:n])
+            recv = torch.empty(G * m, dtype=torch.bfloat16, device=self.flat.device)
+            w1 = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+            w1.wait()                                              # stream-ordered on the communication stream, not the host
+            red = torch.empty(m, dtype=torch.bfloat16, device=self.flat.device)
+            self.kernels.sum_ranks(recv, G, red)
+            full = torch.empty(G * m, dtype=torch.bfloat16, device=self.flat.device)
+            w2 = dist.all_gather_into_tensor(full, red, group=self.group, async_op=True)
+        return _Bf16Work(self, s, e, full, w2, comm)
 
     def _flush(self):
         if not self._pending:
@@ -292,7 +372,10 @@ class GradBucketReducer:
             else:
                 merged.append([s, e])
         for s, e in merged:
-            self._works.append((s, e, dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)))
+            if self.comm_dtype == "bf16":
+                self._works.append((s, e, self._exchange_bf16(s, e)))
+            else:
+                self._works.append((s, e, dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)))
         self._pending = []
 
     def on_span_ready(self, start, end):

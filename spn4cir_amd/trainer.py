@@ -42,7 +42,7 @@ def wgrad_groups(layers, world):
 
 class Stage2Trainer:
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="replicated", check_finite=False, pack=True):
+                 bank_mode="replicated", check_finite=False, pack=True, grad_comm_dtype="fp32"):
         self.model, self.tower = model, model.tower
         # pack (default): when step() gets the ids on the host too (ids_host=), the text tower computes only the rows up to each
         # caption's EOT token - same features bit for bit, same loss and gradients.  The prefix sums are built on the host and go
@@ -59,7 +59,9 @@ class Stage2Trainer:
         self.check_finite = check_finite
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=self.tower.device)
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.tower.device)   # applied steps (check_finite mode)
-        self.reducer = GradBucketReducer(self.tower.grads, group)
+        # grad_comm_dtype="bf16": the dense gradient buckets cross the links as bf16 (all-to-all + fp32 sum in rank order +
+        # all-gather; distributed.GradBucketReducer) - half the bytes, replicas still bit-identical
+        self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype)
         # token-embedding gradients: exchanged as touched rows when the caller also hands the ids on the host (step(ids_host=))
         self.sparse_embed = SparseRowReducer(group) if (self.world > 1 or _dp._FORCE) else None
         self._bank = None

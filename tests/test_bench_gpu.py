@@ -31,6 +31,11 @@ def test_bench_two_ranks_shared_gpu(mode):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 512
     assert d["metric"] == "triplets/sec" and d["value"] > 0 and d["scaling"] == "weak"
     assert "bank_mode_alt" in d and "roofline" in d
+    # strong scaling (B_global = 256 split over the ranks) and the bf16 gradient exchange, measured with the same protocol
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["global_batch"] == 256 and st["batch_per_gpu"] == 128 and st["value"] > 0
+    assert abs(st["value"] - 256 / (st["ms_per_step"] * 1e-3)) < 1e-2 * st["value"]
+    assert d["grad_comm_bf16"]["grad_comm_dtype"] == "bf16" and d["grad_comm_bf16"]["value"] > 0
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
 

@@ -125,6 +125,31 @@ def _worker(rank, world, port, mode, out):
         for s, e in [(250, 1000), (0, 250)]:
             red3.on_span_ready(s, e)
         ok_red = ok_red and red3.finish(keep_span=(0, 250)) == [] and torch.equal(flat3, want)
+        # bf16 bucket exchange: all-to-all + fp32 sum in rank order + all-gather; every rank ends with the SAME bits, equal to
+        # bf16(sum_r fp32(bf16(g_r))) element by element, also for a bucket length that is no multiple of world * 8
+        class TorchKernels:
+            @staticmethod
+            def to_bf16(src, dst):
+                dst.copy_(src.to(torch.bfloat16))
+
+            @staticmethod
+            def sum_ranks(chunks, G, out_):
+                out_.copy_(chunks.view(G, -1).float().sum(0).to(torch.bfloat16))
+
+            @staticmethod
+            def to_f32(src, dst):
+                dst.copy_(src.float())
+        gg = torch.Generator().manual_seed(5)
+        base = torch.randn(world, 1003, generator=gg)
+        flat4 = base[rank].clone()
+        red4 = GradBucketReducer(flat4, None, bucket_elems=400, comm_dtype="bf16", kernels=TorchKernels)
+        for s, e in [(700, 1003), (301, 700), (0, 301)]:
+            red4.on_span_ready(s, e)
+        kept4 = red4.finish(keep_span=(0, 301))
+        for w in kept4:
+            w.wait()
+        want4 = base.to(torch.bfloat16).float().sum(0).to(torch.bfloat16).float()
+        ok_red = ok_red and len(kept4) == 1 and torch.equal(flat4, want4)
         out.put((rank, ok_loss, ok_grad, ok_red, ctx["loss"].item(), ref.item()))
     finally:
         dist.destroy_process_group()

@@ -41,7 +41,7 @@ def _worker(rank, world, port, mode, out):
         sd, target, refer, ids, ridx, labels = _setup()
         dev = torch.device("cuda", 0)
         model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
-        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode)
+        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, grad_comm_dtype=os.environ.get("SPN_TEST_DDP_COMM", "fp32"))
         tr.set_banks(refer, target)
         bl = B // world
         sl = slice(rank * bl, (rank + 1) * bl)
@@ -55,13 +55,16 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,layers,sparse", [("sharded", 2, 0), ("replicated", 2, 0),
-                                                ("sharded", 6, 0),   # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
-                                                ("replicated", 6, 1), ("sharded", 2, 1)])   # embedding rows exchanged sparsely
-def test_two_ranks_match_single_process(mode, layers, sparse, monkeypatch):
+@pytest.mark.parametrize("mode,layers,sparse,comm", [("sharded", 2, 0, "fp32"), ("replicated", 2, 0, "fp32"),
+                                                     ("sharded", 6, 0, "fp32"),   # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
+                                                     ("replicated", 6, 1, "fp32"), ("sharded", 2, 1, "fp32"),   # embedding rows exchanged sparsely
+                                                     # gradient buckets as bf16: all-to-all + fp32 sum in rank order + all-gather
+                                                     ("replicated", 2, 0, "bf16"), ("replicated", 6, 1, "bf16")])
+def test_two_ranks_match_single_process(mode, layers, sparse, comm, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("SPN_TEST_DDP_SPARSE", str(sparse))
+    monkeypatch.setenv("SPN_TEST_DDP_COMM", comm)
     monkeypatch.setenv("SPN_TEST_DDP_LAYERS", str(layers))
     from spn4cir_amd.models import CIRPlus
     from spn4cir_amd.trainer import Stage2Trainer
@@ -120,6 +123,17 @@ for mode, sparse in (("sharded", False), ("replicated", False), ("replicated", T
     l, p = run(mode, sparse)                          # every collective now goes through RCCL
     assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5, (mode, sparse, l, ref_l)
     assert (p - ref_p).abs().max().item() < 1e-6, (mode, sparse)
+# the bf16 bucket exchange on RCCL (all_to_all_single + all_gather_into_tensor on the reducer's own stream, the library's cast /
+# rank-sum kernels between them): with one rank the "sum" is the bf16 rounding of the gradient - an AdamW step away at most
+def run_bf16():
+    model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode="replicated", grad_comm_dtype="bf16")
+    tr.set_banks(refer, target)
+    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    return ls, model.tower.params.clone()
+l, p = run_bf16()
+assert max(abs(a - b) for a, b in zip(l, ref_l)) < 2e-3, (l, ref_l)
+assert (p - ref_p).abs().max().item() < 4.2e-3 and ((p - ref_p).abs() > 2e-3).float().mean().item() < 1e-3
 dist.barrier(); torch.cuda.synchronize()
 dist.destroy_process_group()
 print("NCCL_WORLD1_OK")
