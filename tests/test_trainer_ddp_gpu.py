@@ -110,7 +110,7 @@ torch.cuda.set_device(dev)
 sd, target, refer, ids, ridx, labels = _setup()
 def run(mode, sparse=False):
     model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
-    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode)
+    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, pack=False)    # dense on both sides: the comparison below is to 1e-6
     tr.set_banks(refer, target)
     # sparse: the touched-row exchange of the token-embedding gradient - the extra gloo group next to NCCL, the async
     # all_gather_into_tensor and the index_add_ on the RCCL stream
