@@ -419,6 +419,15 @@ def recall_block(args, sd, model, dev):
                       f"exact tower {exact_s * 1e3:.0f} ms on the GPU"}
 
 
+def _build_info():
+    """How __graft_entry__.build() produced the library this run loaded: compiled by that call or reused (spn4cir_amd/build_info.json)."""
+    try:
+        with open(os.path.join(ROOT, "spn4cir_amd", "build_info.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {"mode": "unknown (no build_info.json: the library was not built through __graft_entry__.build())"}
+
+
 def collect_kernels(lib, n_steps, rows, W):
     """kernels[] entries from the library's HIP-event records (spn_prof_*), after n_steps steps with every class timed."""
     ks = []
@@ -674,6 +683,9 @@ def main():
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tpath)
             roof = {"bound": bound, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    # the PMC passes cannot run inside this process: the figure is REPLAYED from the committed rocprofv3 passes of this
+                    # same command (profiles/), not measured by this run
+                    "traffic_replayed": traffic is not None,
                     "kernel": name, "launches": dn, "avg_us": round(dms / dn * 1e3, 1),
                     "share_of_step": round(dms / dn * launches_total / (dt * 1e3), 3),
                     "timed": f"HIP-event pairs around every {max(1, args.prof_every)}-th launch inside the timed region",
@@ -714,7 +726,7 @@ def main():
             "roofline": roof,
             # every SPN_* variable the library saw when it was loaded (its A/B switches read that snapshot only): a stray
             # one that changes a kernel is visible next to the number
-            "lib_config": _lib.config_dump(),
+            "lib_config": dict(_lib.config_dump(), build=_build_info()),
         }
         out.update(extra)
         if packed:

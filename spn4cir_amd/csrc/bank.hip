@@ -1809,7 +1809,7 @@ static int launch_bank(const BankArgs& a, const BankChunking& c, const float* ro
 
 // ---- fused forward + backward pass (one bank read per step); save buffer = [nchunks][B][D] O partials, [nchunks][B][4] stats
 // Routing of the forward / backward pair, process-wide (spn_bank_config): 0 = default, 1 = second-generation streaming pair
-// below 128 queries (csrc/bank2.hip - compiled only into -DSPN_EXPERIMENTS builds: measured slower),
+// below 128 queries (csrc/bank2.hip - compiled only into -DSPN_EXPERIMENTS builds: measured slower, LABNOTES.md section 5.4),
 // 2 = the fused single pass also at B >= 256, 3 = two passes everywhere, 4 = default routing with the e4m3 fused pass on the
 // kernel that keeps a bf16 tile image.  Environment defaults (read when the library is loaded): SPN_BANK2=1 -> 1,
 // SPN_BANK_FUSED_LARGE=1 -> 2, SPN_BANK_FUSED=0 -> 3.

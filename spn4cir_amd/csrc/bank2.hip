@@ -623,7 +623,7 @@ static int launch_dslice_bwd(const BankArgs& a, const DSliceGeom& g, const float
 }
 
 // ------------------------------------------------------------------------------------------------ host
-// Default OFF (measured): at B = 32, M = 40 000 the pair needs 23.7 / 26.9 us against the
+// Default OFF (measured, LABNOTES.md section 7.6): at B = 32, M = 40 000 the pair needs 23.7 / 26.9 us against the
 // first-generation kernels' 19.7 / 23.1 us - the per-wave serial structure (load queries, wait, stream) has more fixed
 // cost than the block-cooperative kernels, and at that bank size fixed cost is half of the pass.  SPN_BANK2=1 or
 // spn_bank_config(1) selects them (they win on the backward pass of large e4m3 banks: 137 vs 151 us at 400 000 rows).

@@ -493,7 +493,7 @@ int embed_fwd(const int32_t* ids, const float* tok_emb, const float* pos_emb, fl
 // the causal mask and are skipped); dtok must be zero on entry.  dpos[l,:] = sum_b dx[b,l,:].
 // One wave per token row: dead rows (after the EOT token, or the skipped id) leave at once; a live row is added with
 // lane-contiguous atomics (one instruction = 256 contiguous bytes; the earlier 4-floats-per-lane form spread each
-// instruction over 16 cache lines: 73 us at B = 256, L = 77, this: see DESIGN.md).
+// instruction over 16 cache lines: 73 us at B = 256, L = 77, this: see LABNOTES.md).
 __global__ __launch_bounds__(256) void embed_bwd_tok_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ eot,
                                                            const float* __restrict__ dx, float* __restrict__ dtok, int BL,
                                                            int L, int W, int vocab, int skip_id) {

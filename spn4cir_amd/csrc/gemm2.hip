@@ -1193,7 +1193,7 @@ static bool dispatch_nt2p(const bf16_t* A, const bf16_t* B, int M, int N, int K,
 
 #endif  // SPN_EXPERIMENTS (persistent NT kernel)
 
-#ifdef SPN_EXPERIMENTS   // the hand-scheduled 4-wave kernel: measured slower in the step, not in the shipped library
+#ifdef SPN_EXPERIMENTS   // the hand-scheduled 4-wave kernel: measured slower in the step (LABNOTES.md 5.3), not in the shipped library
 // Epilogue of gemm_nt3: FULL 256x256 tiles only (the launcher routes anything else to gemm_nt2), straight-line code, and
 // wave-private: wave (wr, wc) owns the 128x128 sub-tile rows wr*128.., columns wc*128.. and turns it row-major through
 // its OWN 32 KB of LDS, so after the one barrier that ends the k loop no wave waits for another - with one wave per SIMD

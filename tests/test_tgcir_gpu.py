@@ -61,7 +61,7 @@ def test_tgcir_head_kernels_match_oracle():
     assert rel(dtokens, tok_d.grad) < 2e-2
     gv = h.named_views(h.grads)
     for k in tgcir_head.HEAD_KEYS:
-        # text_fc / TokenLearner see bf16 GEMM operands (dz, tokens): the training path's per-parameter gate (DESIGN.md
+        # text_fc / TokenLearner see bf16 GEMM operands (dz, tokens): the training path's per-parameter gate (LABNOTES.md
         # section 3); s_remain_map runs on the fp32-exact GEMMs end to end
         assert rel(gv[k], hd[k].grad.reshape(gv[k].shape)) < (1e-2 if k.startswith("s_remain_map") else 5e-2), k
 
@@ -90,7 +90,7 @@ def test_text_tower_token_output_and_backward():
     flat = t.backward_tokens(dfe.cuda(), dtok.cuda()).clone()
     grads = t.named_views(flat)
     for k, v in grads.items():
-        assert rel(v, sdd[k].grad) < 5e-2, k           # the training path's per-parameter gate (DESIGN.md section 3)
+        assert rel(v, sdd[k].grad) < 5e-2, k           # the training path's per-parameter gate (DESIGN.md section 5)
     # the same backward pass in phases (spn_text_bwd_tokens_head / layer groups / spn_text_bwd_tail_tokens): every span reported
     # exactly once, and the gradients bit-identical when the grouping is the one-call form's
     for groups in (None, [c["layers"]], [1] * c["layers"]):
