@@ -224,6 +224,12 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     const long t128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const bool small = gemm_cfg() == 3 && t256 < 112 && t128 >= 2 * t256 && mode != GEMM_BANKSTATS;
     if (!gemm_use_v1() && !small) return gemm_nt2(A, B, M, N, K, lda, ldb, mode, ep, st);
+#ifdef SPN_EXPERIMENTS
+    // SPN_NT_MID=1..4 (experiments build; measured slower, gemm2.hip: gemm_nt2_mid): the small products on a mid-size tile of the
+    // second-generation kernel
+    static const int nt_mid = [] { const char* e = spn_env("SPN_NT_MID"); return e ? atoi(e) : 0; }();
+    if (small && nt_mid > 0 && !gemm_use_v1()) return gemm_nt2_mid(A, B, M, N, K, lda, ldb, mode, ep, st, nt_mid);
+#endif
     if (M <= 0 || N <= 0 || K <= 0) return SPN_ERR_ARG;
     if (K % BK || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
     if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;

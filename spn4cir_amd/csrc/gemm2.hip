@@ -1613,6 +1613,40 @@ int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int
     }
 }
 
+// Mid-size NT tiles on the second-generation kernel (v_mfma_f32_32x32x16_bf16, LDS-DMA ring), for products with too few
+// 256 x 256 tiles to fill the chip (the packed text tower's ~5 k rows, 32 triplets per GPU under 8-way data parallelism: 2 464
+// rows, the BERT side of the BLIP step: 4 096 rows) - gemm_nt() routes them here when SPN_NT_MID selects a variant:
+//   1: 128 x 128 x 64, 4 waves (2 x 2, wave tile 64 x 64), 2 stages = 64 KB  -> two workgroups per CU
+//   2: 128 x 128 x 64, 4 waves, 3 stages = 96 KB                              -> one workgroup per CU, counted vmcnt
+//   3: 128 x 256 x 64, 8 waves (2 x 4, wave tile 64 x 64), 2 stages = 96 KB
+//   4: 64 x 256 x 64, 4 waves (1 x 4), 2 stages = 80 KB                       -> two workgroups per CU
+// Measured and NOT kept (round 5, tools/small_gemm_bench.py, profiles/r05_small_gemm_mid_tiles.txt; sum of the qkv / out / fc + GELU /
+// c_proj products at 2 464 / 4 096 / 5 248 rows): the routed 128 x 128 kernel of gemm.hip 82.3 / 97.5 / 103.3 us; variant 1: 97.1 /
+// 106.3 / 112.0; 2: 91.3 / 96.1 / 104.3; 3: 107.8 / 115.2 / 121.3; 4: 101.1 / 109.1 / 114.4 - at 10-30 us per launch these products
+// are bound by fill / drain of a single round, not by the tile's steady state.  Experiments build only.
+#ifdef SPN_EXPERIMENTS
+int gemm_nt2_mid(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode, const GemmEpilogue& ep,
+                 hipStream_t st, int variant) {
+    if (M <= 0 || N <= 0 || K <= 0) return SPN_ERR_ARG;
+    if (K % BK2 || N % 4 || lda % 8 || ldb % 8 || ep.ldc % 4) return SPN_ERR_SHAPE;
+    if ((uint64_t)M * lda * 2 >= (1ull << 32) || (uint64_t)N * ldb * 2 >= (1ull << 32)) return SPN_ERR_SHAPE;
+    if (!ep.out_f32 && !ep.out_bf16) return SPN_ERR_ARG;
+    GemmEpilogue e2 = ep;
+    e2.direct_store = 0;
+    e2.dbg = 0;
+    ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
+    switch (variant) {
+        case 1: return dispatch_nt2<128, 128, 2, 2, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 2: return dispatch_nt2<128, 128, 2, 2, 3>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 3: return dispatch_nt2<128, 256, 2, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        case 4: return dispatch_nt2<64, 256, 1, 4, 2>(A, B, M, N, K, lda, ldb, mode, e2, st);
+        default: return SPN_ERR_ARG;
+    }
+}
+#else
+int gemm_nt2_mid(const bf16_t*, const bf16_t*, int, int, int, int, int, int, const GemmEpilogue&, hipStream_t, int) { return SPN_ERR_ARG; }
+#endif
+
 // ----------------------------------------------------------------------------------- TN
 // LDS image of a [64 k][COLS] bf16 tile: row k at byte k*2*COLS; the 32-byte chunk holding logical
 // columns 16c..16c+15 sits at chunk position c ^ ((k&3)<<1): the two 16-lane groups of a half-wave

@@ -55,6 +55,8 @@ size_t gemm_tn_workspace_bytes(int Kr, int N1, int N2);
 // gemm2.hip (second generation; gemm_nt / gemm_tn dispatch to these unless SPN_GEMM_V1=1)
 int gemm_nt2(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode,
              const GemmEpilogue& ep, hipStream_t st);
+int gemm_nt2_mid(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb, int mode, const GemmEpilogue& ep,
+                 hipStream_t st, int variant);
 // logits statistics of q [B, D] against bank [M, D] on the GEMM path; partial [ceil(M/256)][B][4] floats
 int gemm_bank_stats(const bf16_t* q, const bf16_t* bank, int B, int M, int D, int ldq, int ldb, const int64_t* labels,
                     float inv_tau, int m_begin, float* partial, hipStream_t st, bf16_t* p_out = nullptr, int ldp = 0,
