@@ -617,7 +617,7 @@ def main():
     # N > 1: two more brief measurements with the same protocol, so that the first multi-GPU run settles what DESIGN.md section 6
     # only predicts - (a) STRONG scaling: config 3's B_global = 256 split over the ranks (256 / N per GPU; SURVEY 8d asks for
     # both regimes), (b) the gradient buckets exchanged as bf16 (all-to-all + fp32 rank-order sum + all-gather) at the weak shape
-    strong, comm16 = None, None
+    strong, comm16, comm_direct = None, None, None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
         def brief(tr, ids_, ridx_, labels_, host_, bglob):
             for _ in range(max(2, args.warmup)):
@@ -650,6 +650,12 @@ def main():
         comm16.update(grad_comm_dtype="bf16", note="weak-scaling shape; dense gradient buckets cross the links as bf16 "
                                                    "(all-to-all, fp32 sum in rank order, all-gather); headline uses fp32 all-reduce")
         del tr4
+        tr5 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, grad_comm_algo="direct")
+        tr5.set_banks(refer, target)
+        comm_direct = brief(tr5, ids, ridx, labels, ids_host, B_global)
+        comm_direct.update(grad_comm_algo="direct", note="weak-scaling shape; fp32 buckets through all-to-all + rank-order sum + "
+                           "all-gather (every xGMI link at once) instead of RCCL's all-reduce")
+        del tr5
 
     if rank == 0:
         per_kernel = {}
@@ -737,6 +743,8 @@ def main():
             out["strong"] = strong
         if comm16:
             out["grad_comm_bf16"] = comm16
+        if comm_direct:
+            out["grad_comm_direct_fp32"] = comm_direct
         if world == 1 and not args.no_recall:     # checker legs run at N = 1 only: the other ranks would sit in the exit barrier
             rec = recall_block(args, sd, model, dev)
             if rec:

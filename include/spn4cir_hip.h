@@ -88,6 +88,9 @@ int spn_cast_bf16_f32(const void* x_bf16, float* y, size_t n, void* stream);
  * all-to-all delivers them), out_bf16 [m] = bf16(sum over the ranks in rank order, accumulated in fp32) - the same bits on every
  * rank.  m % 8 == 0, 16-byte aligned buffers. */
 int spn_sum_ranks_bf16(const void* chunks_bf16, int n_ranks, size_t m, void* out_bf16, void* stream);
+/* The fp32 flavour (the "direct reduce-scatter + all-gather that drives all 7 links concurrently" of SURVEY section 5, built from an
+ * all-to-all and an all-gather): out[i] = sum over the ranks, in rank order, of chunks[r][i]; m % 4 == 0, 16-byte aligned. */
+int spn_sum_ranks_f32(const float* chunks, int n_ranks, size_t m, float* out, void* stream);
 int spn_cast_transpose_f32_bf16(const float* x, void* y_bf16, void* yt_bf16, int rows, int cols, void* stream);
 /* out[c] (+)= sum_r x[r][c]  (bias gradients) */
 int spn_colsum_bf16(const void* x_bf16, int rows, int cols, int ld, float* out, int accumulate, void* ws,

@@ -537,6 +537,10 @@ int spn_sum_ranks_bf16(const void* chunks_bf16, int n_ranks, size_t m, void* out
     return sum_ranks_bf16(CBF(chunks_bf16), n_ranks, m, BF(out_bf16), ST(stream));
 }
 
+int spn_sum_ranks_f32(const float* chunks, int n_ranks, size_t m, float* out, void* stream) {
+    return sum_ranks_f32(chunks, n_ranks, m, out, ST(stream));
+}
+
 int spn_gather_bank_rows_bf16(const void* bank_bf16, int64_t bank_rows, const int64_t* idx, void* out_bf16, int B, int64_t row_elems,
                               void* stream) {
     if (row_elems <= 0) return SPN_ERR_ARG;

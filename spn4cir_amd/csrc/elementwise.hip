@@ -157,6 +157,27 @@ int sum_ranks_bf16(const bf16_t* x, int G, size_t m, bf16_t* out, hipStream_t st
     return SPN_OK;
 }
 
+// fp32 flavour of the same exchange (direct reduce-scatter + all-gather over all xGMI links): out[i] = sum over the
+// ranks in rank order of x[r][i]
+__global__ __launch_bounds__(256) void sum_ranks_f32_kernel(const float* __restrict__ x, int G, size_t m4, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m4; i += (size_t)gridDim.x * 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < G; ++r) acc += *(const f32x4*)(x + ((size_t)r * m4 + i) * 4);
+        *(f32x4*)(out + i * 4) = acc;
+    }
+}
+
+int sum_ranks_f32(const float* x, int G, size_t m, float* out, hipStream_t st) {
+    if (!x || !out || G <= 0) return SPN_ERR_ARG;
+    if (m % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return SPN_ERR_SHAPE;
+    if (!m) return SPN_OK;
+    const size_t m4 = m / 4;
+    const int blocks = (int)((m4 + 255) / 256 < 2048 ? (m4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sum_ranks_f32_kernel, dim3(blocks), dim3(256), 0, st, x, G, m4, out);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {

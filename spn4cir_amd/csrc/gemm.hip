@@ -223,6 +223,13 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const bool small = gemm_cfg() == 3 && t256 < 112 && t128 >= 2 * t256 && mode != GEMM_BANKSTATS;
+#ifdef SPN_EXPERIMENTS
+    {   // SPN_NT_MID_ALL=1 with SPN_NT_MID=v: EVERY product on the mid-size tile variant v (A/B against the 256 x 256 kernel)
+        static const int mid_all = [] { const char* e = spn_env("SPN_NT_MID_ALL"); return e ? atoi(e) : 0; }();
+        static const int mid_v = [] { const char* e = spn_env("SPN_NT_MID"); return e ? atoi(e) : 0; }();
+        if (mid_all && mid_v > 0 && mode != GEMM_BANKSTATS && !gemm_use_v1()) return gemm_nt2_mid(A, B, M, N, K, lda, ldb, mode, ep, st, mid_v);
+    }
+#endif
     if (!gemm_use_v1() && !small) return gemm_nt2(A, B, M, N, K, lda, ldb, mode, ep, st);
 #ifdef SPN_EXPERIMENTS
     // SPN_NT_MID=1..4 (experiments build; measured slower, gemm2.hip: gemm_nt2_mid): the small products on a mid-size tile of the

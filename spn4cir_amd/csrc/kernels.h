@@ -96,6 +96,7 @@ int negtype_head(const float* R, const float* T, const float* I, int B, int D, f
 int cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t st);
 int cast_bf16_f32(const bf16_t* x, float* y, size_t n, hipStream_t st);
 int sum_ranks_bf16(const bf16_t* x, int G, size_t m, bf16_t* out, hipStream_t st);
+int sum_ranks_f32(const float* x, int G, size_t m, float* out, hipStream_t st);
 int gather_bank_rows_bf16(const bf16_t* bank, const int64_t* idx, int64_t n_rows, bf16_t* out, int B, size_t row_elems, hipStream_t st);
 int tau_grad(const float* q, const float* dqk, int lddq, const float* tau, int B, int D, float alpha, const float* scale_dev,
              float* dtau, float* inv_tau, hipStream_t st);

@@ -286,10 +286,17 @@ class _HipExchangeKernels:
         from . import ops
         ops.check(ops.lib().spn_cast_bf16_f32(ops._p(src_bf16), ops._p(dst_f32), dst_f32.numel(), ops._stream()), "cast_bf16_f32")
 
+    @staticmethod
+    def sum_ranks_f32(chunks_f32, world, out_f32):
+        from . import ops
+        ops.check(ops.lib().spn_sum_ranks_f32(ops._p(chunks_f32), world, out_f32.numel(), ops._p(out_f32), ops._stream()),
+                  "sum_ranks_f32")
+
 
 class _Bf16Work:
-    """Handle of one bf16 bucket exchange: wait() = the second collective has landed, the summed slice is back in the flat fp32
-    gradient, and the caller's current stream is ordered behind all of it."""
+    """Handle of one direct bucket exchange: wait() = the second collective has landed, the summed slice is in the flat fp32
+    gradient (cast back from `full` for the bf16 flavour; gathered in place for fp32), and the caller's current stream is ordered
+    behind all of it."""
 
     def __init__(self, reducer, s, e, full, work, comm):
         self.r, self.s, self.e, self.full, self.work, self.comm = reducer, s, e, full, work, comm
@@ -298,7 +305,8 @@ class _Bf16Work:
         r = self.r
         with r._on(self.comm):
             self.work.wait()
-            r.kernels.to_f32(self.full[:self.e - self.s], r.flat[self.s:self.e])
+            if self.full is not None:
+                r.kernels.to_f32(self.full[:self.e - self.s], r.flat[self.s:self.e])
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
         self.full = None
@@ -321,9 +329,16 @@ class GradBucketReducer:
     that produced it carry rounding of the same size).  The passes run on a dedicated stream between the two collectives; the
     host never blocks.  `kernels` = the elementwise passes (the HIP kernels by default; CPU tests inject torch ones)."""
 
-    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20, comm_dtype="fp32", kernels=None):
+    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20, comm_dtype="fp32", kernels=None, algo=None):
         if comm_dtype not in ("fp32", "bf16"):
             raise ValueError(comm_dtype)
+        # algo "ring" = one RCCL all-reduce per bucket (fp32 only); "direct" = all-to-all + rank-order sum + all-gather: every
+        # rank exchanges one S / G chunk with every other rank over its own xGMI link, all links at once (SURVEY section 5's
+        # one-shot reduce-scatter + all-gather, from RCCL's point-to-point collectives).  bf16 implies direct.
+        algo = algo or ("direct" if comm_dtype == "bf16" else "ring")
+        if algo not in ("ring", "direct") or (comm_dtype == "bf16" and algo != "direct"):
+            raise ValueError((comm_dtype, algo))
+        self.algo = algo
         self.flat, self.group, self.bucket_elems = flat_grads, group, bucket_elems
         self.world, self.rank = _world(group)
         self.comm_dtype = comm_dtype
@@ -360,6 +375,28 @@ class GradBucketReducer:
             w2 = dist.all_gather_into_tensor(full, red, group=self.group, async_op=True)
         return _Bf16Work(self, s, e, full, w2, comm)
 
+    def _exchange_f32(self, s, e):
+        """direct fp32 exchange, in place: needs (e - s) % (4 * world) == 0 (true for every span of the towers here); None
+        otherwise (the caller falls back to the ring all-reduce for that bucket)."""
+        G, n = self.world, e - s
+        if n % (4 * G):
+            return None
+        m = n // G
+        comm = None
+        if self.flat.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+            comm = self._comm_stream
+            comm.wait_stream(torch.cuda.current_stream())
+        with self._on(comm):
+            recv = torch.empty(n, dtype=torch.float32, device=self.flat.device)
+            w1 = dist.all_to_all_single(recv, self.flat[s:e], group=self.group, async_op=True)
+            w1.wait()
+            red = torch.empty(m, dtype=torch.float32, device=self.flat.device)
+            self.kernels.sum_ranks_f32(recv, G, red)
+            w2 = dist.all_gather_into_tensor(self.flat[s:e], red, group=self.group, async_op=True)
+        return _Bf16Work(self, s, e, None, w2, comm)
+
     def _flush(self):
         if not self._pending:
             return
@@ -372,10 +409,14 @@ class GradBucketReducer:
             else:
                 merged.append([s, e])
         for s, e in merged:
+            work = None
             if self.comm_dtype == "bf16":
-                self._works.append((s, e, self._exchange_bf16(s, e)))
-            else:
-                self._works.append((s, e, dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)))
+                work = self._exchange_bf16(s, e)
+            elif self.algo == "direct":
+                work = self._exchange_f32(s, e)
+            if work is None:
+                work = dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)
+            self._works.append((s, e, work))
         self._pending = []
 
     def on_span_ready(self, start, end):

@@ -42,7 +42,7 @@ def wgrad_groups(layers, world):
 
 class Stage2Trainer:
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="replicated", check_finite=False, pack=True, grad_comm_dtype="fp32"):
+                 bank_mode="replicated", check_finite=False, pack=True, grad_comm_dtype="fp32", grad_comm_algo=None):
         self.model, self.tower = model, model.tower
         # pack (default): when step() gets the ids on the host too (ids_host=), the text tower computes only the rows up to each
         # caption's EOT token - same features bit for bit, same loss and gradients.  The prefix sums are built on the host and go
@@ -61,7 +61,8 @@ class Stage2Trainer:
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.tower.device)   # applied steps (check_finite mode)
         # grad_comm_dtype="bf16": the dense gradient buckets cross the links as bf16 (all-to-all + fp32 sum in rank order +
         # all-gather; distributed.GradBucketReducer) - half the bytes, replicas still bit-identical
-        self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype)
+        # grad_comm_algo="direct" (fp32): the same exchange with fp32 payloads instead of RCCL's ring all-reduce
+        self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype, algo=grad_comm_algo)
         # token-embedding gradients: exchanged as touched rows when the caller also hands the ids on the host (step(ids_host=))
         self.sparse_embed = SparseRowReducer(group) if (self.world > 1 or _dp._FORCE) else None
         self._bank = None

@@ -36,6 +36,7 @@ def test_bench_two_ranks_shared_gpu(mode):
     assert st["scaling"] == "strong" and st["global_batch"] == 256 and st["batch_per_gpu"] == 128 and st["value"] > 0
     assert abs(st["value"] - 256 / (st["ms_per_step"] * 1e-3)) < 1e-2 * st["value"]
     assert d["grad_comm_bf16"]["grad_comm_dtype"] == "bf16" and d["grad_comm_bf16"]["value"] > 0
+    assert d["grad_comm_direct_fp32"]["grad_comm_algo"] == "direct" and d["grad_comm_direct_fp32"]["value"] > 0
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
 

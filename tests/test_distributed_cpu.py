@@ -139,6 +139,13 @@ def _worker(rank, world, port, mode, out):
             @staticmethod
             def to_f32(src, dst):
                 dst.copy_(src.float())
+
+            @staticmethod
+            def sum_ranks_f32(chunks, G, out_):
+                acc = torch.zeros_like(out_)
+                for r in range(G):                                   # rank order, as the kernel
+                    acc += chunks.view(G, -1)[r]
+                out_.copy_(acc)
         gg = torch.Generator().manual_seed(5)
         base = torch.randn(world, 1003, generator=gg)
         flat4 = base[rank].clone()
@@ -150,6 +157,22 @@ def _worker(rank, world, port, mode, out):
             w.wait()
         want4 = base.to(torch.bfloat16).float().sum(0).to(torch.bfloat16).float()
         ok_red = ok_red and len(kept4) == 1 and torch.equal(flat4, want4)
+        # direct fp32 exchange (all-to-all + rank-order sum + all-gather, in place); a bucket whose length is no multiple of
+        # 4 * world falls back to the ring all-reduce
+        flat5 = base[rank, :1000].clone()
+        red5 = GradBucketReducer(flat5, None, bucket_elems=300, kernels=TorchKernels, algo="direct")
+        for s, e in [(600, 1000), (296, 600), (0, 296)]:
+            red5.on_span_ready(s, e)
+        red5.finish()
+        want5 = torch.zeros(1000)
+        for r in range(world):
+            want5 += base[r, :1000]
+        ok_red = ok_red and torch.equal(flat5, want5)
+        flat6 = base[rank, :1003].clone()
+        red6 = GradBucketReducer(flat6, None, bucket_elems=10 ** 9, kernels=TorchKernels, algo="direct")
+        red6.on_span_ready(0, 1003)
+        red6.finish()
+        ok_red = ok_red and torch.allclose(flat6, base[:, :1003].sum(0), atol=1e-6)
         out.put((rank, ok_loss, ok_grad, ok_red, ctx["loss"].item(), ref.item()))
     finally:
         dist.destroy_process_group()

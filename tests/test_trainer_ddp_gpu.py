@@ -41,7 +41,9 @@ def _worker(rank, world, port, mode, out):
         sd, target, refer, ids, ridx, labels = _setup()
         dev = torch.device("cuda", 0)
         model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
-        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, grad_comm_dtype=os.environ.get("SPN_TEST_DDP_COMM", "fp32"))
+        comm = os.environ.get("SPN_TEST_DDP_COMM", "fp32")
+        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, grad_comm_dtype="bf16" if comm == "bf16" else "fp32",
+                           grad_comm_algo="direct" if comm == "direct" else None)
         tr.set_banks(refer, target)
         bl = B // world
         sl = slice(rank * bl, (rank + 1) * bl)
@@ -59,7 +61,9 @@ def _worker(rank, world, port, mode, out):
                                                      ("sharded", 6, 0, "fp32"),   # 6 blocks: three weight-gradient groups (4 + 1 + 1) per rank
                                                      ("replicated", 6, 1, "fp32"), ("sharded", 2, 1, "fp32"),   # embedding rows exchanged sparsely
                                                      # gradient buckets as bf16: all-to-all + fp32 sum in rank order + all-gather
-                                                     ("replicated", 2, 0, "bf16"), ("replicated", 6, 1, "bf16")])
+                                                     ("replicated", 2, 0, "bf16"), ("replicated", 6, 1, "bf16"),
+                                                     # fp32 buckets through the same direct exchange instead of the ring all-reduce
+                                                     ("sharded", 6, 0, "direct")])
 def test_two_ranks_match_single_process(mode, layers, sparse, comm, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -131,6 +135,14 @@ def run_bf16():
     tr.set_banks(refer, target)
     ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
     return ls, model.tower.params.clone()
+def run_direct():
+    model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode="replicated", pack=False, grad_comm_algo="direct")
+    tr.set_banks(refer, target)
+    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    return ls, model.tower.params.clone()
+l, p = run_direct()                                   # one rank: the "sum" is the gradient itself - same step as the ring path
+assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5 and (p - ref_p).abs().max().item() < 1e-6
 l, p = run_bf16()
 assert max(abs(a - b) for a, b in zip(l, ref_l)) < 2e-3, (l, ref_l)
 assert (p - ref_p).abs().max().item() < 4.2e-3 and ((p - ref_p).abs() > 2e-3).float().mean().item() < 1e-3
