@@ -404,6 +404,35 @@ int spn_preprocess_image(const uint8_t* src_rgb, int H, int W, int pad_x, int pa
                          const float* mean3, const float* std3, void* tmp, float* out_chw, uint8_t* out_u8_hwc,
                          void* stream);
 
+/* ---------------------------------------------------------------- JPEG decode (baseline, batched)
+ * Replaces the host decode `PIL.Image.open(path)` + `.convert("RGB")` of the reference's datasets
+ * (clip4cir/data_utils_negplus.py:17,268-319) for the calls that decode whole galleries - the bank builders
+ * (models_negplus.py:59-125) and extract_index_features (utils.py:24-50): file bytes in, RGB uint8 [H][W][3] in device memory
+ * out (what spn_preprocess_image consumes), bit for bit what Pillow / libjpeg-turbo produce at their default settings (islow IDCT,
+ * fancy upsampling).  Scope: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grayscale or YCbCr with chroma
+ * 1x1 and luma 1x1 / 2x1 / 2x2; the host parses markers and tables (spn4cir_amd/jpeg.py) and sends anything else to Pillow.
+ * spn_jpeg_image: one record per image (offsets into the batch buffers); spn_jpeg_segment: one independently decodable entropy
+ * segment (a scan, or one restart interval: byte_off points behind its RSTn marker); spn_jpeg_huff: a Huffman table in decode form
+ * (9-bit look-ahead: length << 8 | symbol, 0 = longer code; canonical maxcode / value offsets for lengths 10..16).
+ * coefs: int16 scratch of coef_elems elements (zeroed inside the call), planes: uint8 scratch, rgb: output; max_blocks / max_pixels:
+ * the largest per-component block count / per-image pixel count of the batch (grid sizing). */
+typedef struct {
+    int32_t width, height, ncomp, hs, vs, mcux, mcuy, restart_interval;
+    uint32_t scan_off, scan_len;
+    uint32_t coef_off[3];
+    int32_t blocks_x[3], blocks_y[3];
+    uint32_t plane_off[3];
+    int32_t qt[3], dc_tab[3], ac_tab[3];
+    uint32_t rgb_off;
+    int32_t first_seg, n_seg;
+    int32_t reserved[6];
+} spn_jpeg_image;
+typedef struct { int32_t image, mcu_first, mcu_count; uint32_t byte_off; } spn_jpeg_segment;
+typedef struct { uint16_t look[512]; int32_t maxcode[18]; int32_t valoff[17]; uint8_t sym[256]; uint8_t pad[4]; } spn_jpeg_huff;
+int spn_jpeg_decode_batch(const uint8_t* bytes, const spn_jpeg_image* images, int n_images, const spn_jpeg_segment* segments,
+                          int n_segments, const spn_jpeg_huff* huff, const uint16_t* qtabs, int16_t* coefs, size_t coef_elems,
+                          uint8_t* planes, uint8_t* rgb, int max_blocks, int max_pixels, void* stream);
+
 /* ---------------------------------------------------------------- CLIP vision tower (inference)
  * VisionTransformer.forward (clip/model.py:223-242): frozen in stage 2, used by the bank builders
  * (models_negplus.py:59-125) and extract_index_features (utils.py:24-50).  image: fp32 [B,3,res,res]

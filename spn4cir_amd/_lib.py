@@ -66,6 +66,7 @@ _SIGS = {
     "spn_cast_bf16_f32": (i32, [vp, vp, sz, vp]),
     "spn_sum_ranks_bf16": (i32, [vp, i32, sz, vp, vp]),
     "spn_sum_ranks_f32": (i32, [vp, i32, sz, vp, vp]),
+    "spn_jpeg_decode_batch": (i32, [vp, vp, i32, vp, i32, vp, vp, vp, sz, vp, vp, i32, i32, vp]),
     "spn_cast_transpose_f32_bf16": (i32, [vp, vp, vp, i32, i32, vp]),
     "spn_colsum_bf16": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "spn_colsum_workspace_bytes": (sz, [i32, i32]),

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import gradsink, ops
+from .preprocess import gpu_decode_scope, stack_images
 from .fusion import FusionEncoder, fusion_cfg_from_state_dict
 from .vision_tower import VisionTower
 
@@ -204,17 +205,18 @@ class CIRPlus(nn.Module):
         self.refer_bank = torch.load(bank_path)
 
     @staticmethod
-    def _image_batches(dataset, bs=32):
+    def _image_batches(dataset, bs=128):
         n = len(dataset)
         for s in range(0, n, bs):
-            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            with gpu_decode_scope(dataset):                         # undecoded JPEGs come back as file bytes: decoded on the GPU per batch
+                items = [dataset[i] for i in range(s, min(n, s + bs))]
             items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
             if items:
                 yield items
 
     def _embed(self, images):
         """img_embed + normalised vision_proj of token 0 for a list of [3, H, H] tensors."""
-        tokens, pooled = self.img_embed(torch.stack(images).to(self.device, torch.float32), return_pool_and_normalized=True)
+        tokens, pooled = self.img_embed(stack_images(images).to(self.device, torch.float32), return_pool_and_normalized=True)
         return tokens, pooled
 
     def extract_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):

@@ -537,6 +537,13 @@ int spn_sum_ranks_bf16(const void* chunks_bf16, int n_ranks, size_t m, void* out
     return sum_ranks_bf16(CBF(chunks_bf16), n_ranks, m, BF(out_bf16), ST(stream));
 }
 
+int spn_jpeg_decode_batch(const uint8_t* bytes, const spn_jpeg_image* images, int n_images, const spn_jpeg_segment* segments,
+                          int n_segments, const spn_jpeg_huff* huff, const uint16_t* qtabs, int16_t* coefs, size_t coef_elems,
+                          uint8_t* planes, uint8_t* rgb, int max_blocks, int max_pixels, void* stream) {
+    return jpeg_decode_batch(bytes, images, n_images, segments, n_segments, huff, qtabs, coefs, coef_elems, planes, rgb, max_blocks,
+                             max_pixels, ST(stream));
+}
+
 int spn_sum_ranks_f32(const float* chunks, int n_ranks, size_t m, float* out, void* stream) {
     return sum_ranks_f32(chunks, n_ranks, m, out, ST(stream));
 }

@@ -1,0 +1,243 @@
+// Baseline JPEG decode, per-work-item cores shared by the device kernels (jpeg.hip) and the host unit-test harness
+// (tests/native/jpeg_core_host.cpp compiles THIS file with g++ so that the exact source the GPU runs is checked against Pillow on
+// the CPU; the harness is test infrastructure - the product has no CPU decode path).
+//
+// What is restated (Pillow = libjpeg-turbo at its default decompression settings, which is what the reference's
+// `PIL.Image.open(path)` / `.convert("RGB")` runs inside its DataLoader workers, clip4cir/data_utils_negplus.py:17,268-319):
+//   ITU-T T.81 Huffman entropy decoding (F.2.2), dequantisation, the IJG "islow" integer inverse DCT (13-bit constants, two
+//   passes, descale 11 / 18 bits, +128, saturate), "fancy" triangle-filter chroma upsampling for h2v1 / h2v2 with edge
+//   replication (plain replication when the chroma plane is <= 2 samples wide), fixed-point YCbCr -> RGB (16-bit scaled constants).
+// CPU restatement of the same (numpy, independent code): oracle/jpeg_decode.py, pinned against Pillow.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SPN_JHD __host__ __device__ __forceinline__
+#else
+#define SPN_JHD inline
+#endif
+
+namespace spnjpeg {
+
+// One image of a batch (mirrors spn_jpeg_image in include/spn4cir_hip.h; 40 x 32-bit words).
+struct Image {
+    int32_t width, height, ncomp, hs, vs;        // luma sampling factors (chroma is 1 x 1): 1x1, 2x1, 2x2
+    int32_t mcux, mcuy, restart_interval;
+    uint32_t scan_off, scan_len;                 // entropy-coded segment in the batch's byte buffer
+    uint32_t coef_off[3];                        // int16 ELEMENT offset of each component's [blocks_y][blocks_x][64] coefficients
+    int32_t blocks_x[3], blocks_y[3];            // padded (whole-MCU) block grid per component
+    uint32_t plane_off[3];                       // byte offset of each component's uint8 plane [8 blocks_y][8 blocks_x]
+    int32_t qt[3], dc_tab[3], ac_tab[3];         // indices into the batch's quantiser / Huffman table arrays
+    uint32_t rgb_off;                            // byte offset of the [height][width][3] output
+    int32_t first_seg, n_seg;                    // this image's entropy segments in the segment array (restart intervals)
+    int32_t reserved[6];
+};
+static_assert(sizeof(Image) == 40 * 4, "spn_jpeg_image layout");
+
+// One independently decodable piece of an entropy-coded segment: a whole scan, or one restart interval.
+struct Segment {
+    int32_t image, mcu_first, mcu_count;
+    uint32_t byte_off;                           // first byte of the piece (behind the RSTn marker)
+};
+
+// Huffman table in decode form: 9-bit look-ahead (entry = length << 8 | symbol, 0 = longer code), canonical slow path.
+struct Huff {
+    uint16_t look[512];
+    int32_t maxcode[18];                         // [l] = largest code of length l (-1: none); [17] sentinel
+    int32_t valoff[17];                          // [l] = index of the first symbol of length l minus its smallest code
+    uint8_t sym[256];
+    uint8_t pad[4];
+};
+static_assert(sizeof(Huff) == 1024 + 72 + 68 + 256 + 4, "spn_jpeg_huff layout");
+
+SPN_JHD int zigzag(int k) {
+    const unsigned char z[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7,
+                                 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46,
+                                 53, 60, 61, 54, 47, 55, 62, 63};
+    return z[k];
+}
+
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc;
+    int n;
+    // top up to > 56 bits; a marker (FF xx, xx != 0) ends the data: zero bits from there on, the pointer stays on the marker
+    SPN_JHD void fill() {
+        while (n <= 56) {
+            unsigned b = 0;
+            if (p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    const unsigned nx = (p + 1 < end) ? p[1] : 0xD9u;
+                    if (nx == 0) p += 2;
+                    else b = 0;
+                } else {
+                    ++p;
+                }
+            }
+            acc = (acc << 8) | b;
+            n += 8;
+        }
+    }
+    SPN_JHD unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1u)); }
+    SPN_JHD void skip(int k) { n -= k; }
+};
+
+SPN_JHD int huff_decode(BitReader& br, const Huff& t) {
+    br.fill();
+    const unsigned e = t.look[br.peek(9)];
+    if (e) {
+        br.skip((int)(e >> 8));
+        return (int)(e & 255u);
+    }
+    for (int l = 10; l <= 16; ++l) {
+        const int code = (int)br.peek(l);
+        if (code <= t.maxcode[l]) {
+            br.skip(l);
+            return t.sym[(t.valoff[l] + code) & 255];
+        }
+    }
+    br.skip(16);                                 // not a code of this table (corrupt data): the IJG decoder substitutes 0
+    return 0;
+}
+
+SPN_JHD int receive_extend(BitReader& br, int s) {
+    if (s == 0) return 0;
+    br.fill();
+    const int v = (int)br.peek(s);
+    br.skip(s);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+// Entropy-decode one segment: writes the NON-ZERO coefficients (natural order) of its MCUs; the coefficient buffer is zero on entry.
+// Returns 0, or a negative code for a truncated / inconsistent stream (the image is still written as far as it went).
+SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* bytes, const Huff* tabs, int16_t* coefs) {
+    BitReader br;
+    br.p = bytes + sg.byte_off;
+    br.end = bytes + im.scan_off + im.scan_len;
+    br.acc = 0;
+    br.n = 0;
+    int pred[3] = {0, 0, 0};
+    const int mcu_end = sg.mcu_first + sg.mcu_count;
+    for (int mcu = sg.mcu_first; mcu < mcu_end; ++mcu) {
+        const int my = mcu / im.mcux, mx = mcu - my * im.mcux;
+        for (int c = 0; c < im.ncomp; ++c) {
+            const int ch = c == 0 ? im.hs : 1, cv = c == 0 ? im.vs : 1;
+            const Huff& dct = tabs[im.dc_tab[c]];
+            const Huff& act = tabs[im.ac_tab[c]];
+            for (int by = 0; by < cv; ++by)
+                for (int bx = 0; bx < ch; ++bx) {
+                    int16_t* blk = coefs + im.coef_off[c] + ((size_t)(my * cv + by) * im.blocks_x[c] + (mx * ch + bx)) * 64;
+                    const int t = huff_decode(br, dct);
+                    pred[c] += receive_extend(br, t & 15);
+                    blk[0] = (int16_t)pred[c];
+                    int k = 1;
+                    while (k < 64) {
+                        const int rs = huff_decode(br, act);
+                        const int r = rs >> 4, s = rs & 15;
+                        if (s == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > 63) break;
+                        blk[zigzag(k)] = (int16_t)receive_extend(br, s);
+                        ++k;
+                    }
+                }
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ inverse DCT
+SPN_JHD void idct_1d(const int32_t* x, int stride, int32_t* o, int ostride, int shift) {
+    const int32_t x0 = x[0], x1 = x[stride], x2 = x[2 * stride], x3 = x[3 * stride], x4 = x[4 * stride], x5 = x[5 * stride],
+                  x6 = x[6 * stride], x7 = x[7 * stride];
+    int32_t z1 = (x2 + x6) * 4433;
+    const int32_t tmp2 = z1 + x6 * (-15137);
+    const int32_t tmp3 = z1 + x2 * 6270;
+    const int32_t tmp0 = (int32_t)((uint32_t)(x0 + x4) << 13);
+    const int32_t tmp1 = (int32_t)((uint32_t)(x0 - x4) << 13);
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int32_t t0 = x7, t1 = x5, t2 = x3, t3 = x1;
+    z1 = t0 + t3;
+    int32_t z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+    const int32_t z5 = (z3 + z4) * 9633;
+    t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+    z1 *= -7373; z2 *= -20995;
+    z3 = z3 * (-16069) + z5;
+    z4 = z4 * (-3196) + z5;
+    t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+    const int32_t rnd = 1 << (shift - 1);
+    o[0] = (tmp10 + t3 + rnd) >> shift;
+    o[7 * ostride] = (tmp10 - t3 + rnd) >> shift;
+    o[ostride] = (tmp11 + t2 + rnd) >> shift;
+    o[6 * ostride] = (tmp11 - t2 + rnd) >> shift;
+    o[2 * ostride] = (tmp12 + t1 + rnd) >> shift;
+    o[5 * ostride] = (tmp12 - t1 + rnd) >> shift;
+    o[3 * ostride] = (tmp13 + t0 + rnd) >> shift;
+    o[4 * ostride] = (tmp13 - t0 + rnd) >> shift;
+}
+
+// coef [64] natural order x q [64] -> out [8 rows][8] uint8 at `stride` bytes per row
+SPN_JHD void idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride) {
+    int32_t in[64], ws[64];
+    for (int i = 0; i < 64; ++i) in[i] = (int32_t)coef[i] * (int32_t)q[i];
+    for (int c = 0; c < 8; ++c) idct_1d(in + c, 8, ws + c, 8, 13 - 2);               // pass 1: down each column
+    for (int r = 0; r < 8; ++r) {
+        int32_t row[8];
+        idct_1d(ws + r * 8, 1, row, 1, 13 + 2 + 3);                                   // pass 2: along each row
+        for (int c = 0; c < 8; ++c) {
+            int v = row[c] + 128;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out[(size_t)r * stride + c] = (uint8_t)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ upsampling + colour conversion
+SPN_JHD int chroma_at(const Image& im, const uint8_t* plane, int pstride, int x, int y) {
+    if (im.hs == 1) return plane[(size_t)y * pstride + x];                               // 4:4:4
+    const int dw = (im.width + 1) >> 1;                                                  // downsampled width (hs == 2)
+    const int cx = x >> 1;
+    if (im.vs == 1) {                                                                    // h2v1
+        const uint8_t* row = plane + (size_t)y * pstride;
+        const int p = row[cx];
+        if (dw <= 2) return p;
+        if (x == 0 || x == 2 * dw - 1) return p;
+        return (x & 1) ? (3 * p + row[cx + 1] + 2) >> 2 : (3 * p + row[cx - 1] + 1) >> 2;
+    }
+    const int dh = (im.height + 1) >> 1;                                                 // h2v2
+    const int cy = y >> 1;
+    if (dw <= 2) return plane[(size_t)cy * pstride + cx];
+    int ny = (y & 1) ? cy + 1 : cy - 1;
+    ny = ny < 0 ? 0 : (ny > dh - 1 ? dh - 1 : ny);
+    const uint8_t* r0 = plane + (size_t)cy * pstride;
+    const uint8_t* r1 = plane + (size_t)ny * pstride;
+    const int cs = 3 * r0[cx] + r1[cx];
+    if (x == 0) return (cs * 4 + 8) >> 4;
+    if (x == 2 * dw - 1) return (cs * 4 + 7) >> 4;
+    if (x & 1) return (cs * 3 + 3 * r0[cx + 1] + r1[cx + 1] + 7) >> 4;
+    return (cs * 3 + 3 * r0[cx - 1] + r1[cx - 1] + 8) >> 4;
+}
+
+SPN_JHD int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// pixel (x, y) of image im -> rgb[3]
+SPN_JHD void pixel_rgb(const Image& im, const uint8_t* planes, int x, int y, uint8_t* rgb) {
+    const int Y = planes[im.plane_off[0] + (size_t)y * (im.blocks_x[0] * 8) + x];
+    if (im.ncomp == 1) {
+        rgb[0] = rgb[1] = rgb[2] = (uint8_t)Y;
+        return;
+    }
+    const int cb = chroma_at(im, planes + im.plane_off[1], im.blocks_x[1] * 8, x, y) - 128;
+    const int cr = chroma_at(im, planes + im.plane_off[2], im.blocks_x[2] * 8, x, y) - 128;
+    rgb[0] = (uint8_t)clamp255(Y + ((91881 * cr + 32768) >> 16));
+    rgb[1] = (uint8_t)clamp255(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+    rgb[2] = (uint8_t)clamp255(Y + ((116130 * cb + 32768) >> 16));
+}
+
+}  // namespace spnjpeg

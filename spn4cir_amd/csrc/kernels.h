@@ -115,7 +115,11 @@ int colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, int acc
                 hipStream_t st);
 size_t colsum_workspace_bytes(int rows, int cols);
 int fold_rows(const float* ws, size_t stride, int n, size_t C, float* out, float alpha, int accumulate, hipStream_t st);
-int zero_fill_f32(float* p, size_t n, hipStream_t st);     // elementwise.hip: the library's own zero fill (no hipMemsetAsync on the step)
+int zero_fill_f32(float* p, size_t n, hipStream_t st);
+// jpeg.hip: baseline JPEG batch decode (Huffman -> IDCT -> upsample + colour), see include/spn4cir_hip.h spn_jpeg_decode_batch
+int jpeg_decode_batch(const uint8_t* bytes, const void* images, int n_images, const void* segs, int n_segs, const void* huff,
+                      const uint16_t* qtabs, int16_t* coefs, size_t coef_elems, uint8_t* planes, uint8_t* rgb, int max_blocks,
+                      int max_pixels, hipStream_t st);     // elementwise.hip: the library's own zero fill (no hipMemsetAsync on the step)
 constexpr int FOLD_BATCH_MAX = 32;
 struct FoldBatch {            // out[i][c] = sum_{r < n} ws[i][r * stride + c], c < C, for i < items
     const float* ws[FOLD_BATCH_MAX];

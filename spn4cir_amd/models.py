@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from . import gradsink, ops
+from .preprocess import gpu_decode_scope, stack_images
 from .text_tower import TextTower, text_cfg_from_state_dict
 from .vision_tower import VisionTower, vision_cfg_from_state_dict
 
@@ -231,10 +232,11 @@ class CIRPlus(nn.Module):
     # (reference_image, caption, target_image, index, target_index, reference_index_all, target_index_all)
     # with images already preprocessed to fp32 [3, res, res]; 'unlabeled' mode yields single images.
     @staticmethod
-    def _image_batches(dataset, bs=32):
+    def _image_batches(dataset, bs=128):
         n = len(dataset)
         for s in range(0, n, bs):
-            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            with gpu_decode_scope(dataset):                         # undecoded JPEGs come back as file bytes: decoded on the GPU per batch
+                items = [dataset[i] for i in range(s, min(n, s + bs))]
             items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
             if items:
                 yield items
@@ -247,8 +249,8 @@ class CIRPlus(nn.Module):
         refer = torch.zeros(len(cirDataset), self.output_dim)
         target = torch.zeros(cirDataset.image_id, self.output_dim)
         for items in self._image_batches(cirDataset):
-            ref = self.encode_image(torch.stack([it[0] for it in items]))
-            tgt = self.encode_image(torch.stack([it[2] for it in items]))
+            ref = self.encode_image(stack_images([it[0] for it in items]))
+            tgt = self.encode_image(stack_images([it[2] for it in items]))
             index = torch.tensor([int(it[3]) for it in items])
             ref_all = torch.tensor([int(it[5]) for it in items])
             tgt_all = torch.tensor([int(it[6]) for it in items])
@@ -267,8 +269,8 @@ class CIRPlus(nn.Module):
         for items in self._image_batches(cirDataset):
             ref_all = torch.tensor([int(it[5]) for it in items], device=self.device)
             tgt_all = torch.tensor([int(it[6]) for it in items], device=self.device)
-            refer[ref_all] = self.encode_image(torch.stack([it[0] for it in items]))
-            refer[tgt_all] = self.encode_image(torch.stack([it[2] for it in items]))
+            refer[ref_all] = self.encode_image(stack_images([it[0] for it in items]))
+            refer[tgt_all] = self.encode_image(stack_images([it[2] for it in items]))
         self.refer_bank = refer
         if bank_path:
             torch.save(refer, bank_path)
@@ -281,7 +283,7 @@ class CIRPlus(nn.Module):
         else:
             feats = []
             for items in self._image_batches(cirDataset):
-                f = self.encode_image(torch.stack(list(items)))
+                f = self.encode_image(stack_images(items))
                 feats.append(ops.combine_l2norm_fwd(None, None, f)[0].cpu())
             unl = torch.cat(feats) if feats else torch.zeros(0, self.output_dim)
             if bank_path:

@@ -67,13 +67,64 @@ def targetpad_geometry(w, h, target_ratio, dim):
     return hp, vp, ow, oh, int(round((ow - dim) / 2.0)), int(round((oh - dim) / 2.0))
 
 
+class DeferredImage:
+    """A JPEG file's bytes standing in for its preprocessed tensor: what `TargetPadTransform(gpu_decode=True)` returns for a
+    not-yet-decoded PIL JPEG, so that the callers that handle whole batches (bank builders, extract_index_features) decode the batch
+    on the GPU at once (`stack_images`).  `.tensor()` realises one image alone."""
+    __slots__ = ("data", "transform")
+
+    def __init__(self, data, transform):
+        self.data, self.transform = data, transform
+
+    def tensor(self):
+        return self.transform.realize([self])[0]
+
+
+class gpu_decode_scope:
+    """`with gpu_decode_scope(dataset): ...` - while the block runs, a dataset whose `preprocess` is a TargetPadTransform hands out
+    DeferredImage for undecoded JPEGs, so that the block's `stack_images` decodes them on the GPU batch by batch.  The callers that
+    use it (bank builders, extract_index_features) run in the main process and consume the items themselves; everybody else keeps
+    getting tensors from `model.preprocess(img)`.  SPN_GPU_JPEG=0 switches it off (host decode everywhere)."""
+
+    def __init__(self, dataset):
+        import os
+        t = getattr(dataset, "preprocess", None)
+        self.t = t if isinstance(t, TargetPadTransform) and os.environ.get("SPN_GPU_JPEG", "1") != "0" else None
+
+    def __enter__(self):
+        if self.t is not None:
+            self.old, self.t.gpu_decode = self.t.gpu_decode, True
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.t.gpu_decode = self.old
+        return False
+
+
+def stack_images(images):
+    """[n] preprocessed image tensors and / or DeferredImage -> fp32 [n, 3, dim, dim] on the device: the deferred ones are decoded
+    in ONE batched GPU call (spn_jpeg_decode_batch) and preprocessed from device memory."""
+    images = list(images)
+    pending = [i for i, im in enumerate(images) if isinstance(im, DeferredImage)]
+    if pending:
+        done = images[pending[0]].transform.realize([images[i] for i in pending])
+        for i, t in zip(pending, done):
+            images[i] = t
+    return torch.stack([im.to(images[0].device) for im in images])
+
+
 class TargetPadTransform:
     """GPU `targetpad_transform(target_ratio, dim)`: uint8 RGB [H, W, 3] (numpy / CPU or device tensor, or a PIL
     image) -> fp32 [3, dim, dim] on the device, bit-identical to the reference's CPU pipeline.  PIL images in modes
-    other than RGB / L are padded / resized / cropped by Pillow in their own mode first (`_native_mode_u8`)."""
+    other than RGB / L are padded / resized / cropped by Pillow in their own mode first (`_native_mode_u8`).
+    gpu_decode=True: a PIL JPEG that has not been decoded yet (`PIL.Image.open(path)` only reads the header - the reference's
+    datasets hand exactly that to the transform, data_utils_negplus.py:268-319) is NOT decoded on the host: its file bytes come back
+    as a `DeferredImage`, and `stack_images` / `realize` decode whole batches on the GPU (spn4cir_amd/jpeg.py)."""
 
-    def __init__(self, target_ratio=1.25, dim=224, device="cuda", mean=CLIP_MEAN, std=CLIP_STD):
+    def __init__(self, target_ratio=1.25, dim=224, device="cuda", mean=CLIP_MEAN, std=CLIP_STD, gpu_decode=False):
         self.target_ratio, self.dim, self.device = float(target_ratio), int(dim), torch.device(device)
+        self.gpu_decode = bool(gpu_decode)
         self._mean = (C.c_float * 3)(*mean)
         self._std = (C.c_float * 3)(*std)
         self._tables = {}
@@ -108,8 +159,39 @@ class TargetPadTransform:
         image = image.crop((left, top, left + self.dim, top + self.dim))
         return np.array(image.convert("RGB"), dtype=np.uint8)
 
+    def _undecoded_jpeg_bytes(self, image):
+        """File bytes of a PIL JPEG whose pixels have not been loaded (None otherwise)."""
+        if getattr(image, "format", None) != "JPEG" or getattr(image, "mode", None) not in ("RGB", "L"):
+            return None
+        try:
+            if image.im is not None:                    # already decoded by somebody: nothing to save
+                return None
+        except AttributeError:
+            return None
+        name = getattr(image, "filename", "")
+        try:
+            if name:
+                with open(name, "rb") as f:
+                    return f.read()
+            fp = getattr(image, "fp", None)
+            if fp is not None and hasattr(fp, "getvalue"):
+                return fp.getvalue()
+        except OSError:
+            return None
+        return None
+
+    def realize(self, deferred):
+        """[DeferredImage] -> [fp32 [3, dim, dim]]: one batched GPU decode, then the preprocessing kernels per image."""
+        from . import jpeg
+        rgb, _ = jpeg.decode_batch([d.data for d in deferred], self.device)
+        return [self(t) for t in rgb]
+
     def __call__(self, image, return_uint8=False):
         if not torch.is_tensor(image):
+            if self.gpu_decode and not return_uint8 and hasattr(image, "convert"):
+                data = self._undecoded_jpeg_bytes(image)
+                if data is not None:
+                    return DeferredImage(data, self)
             if hasattr(image, "convert"):
                 if image.mode not in ("RGB", "L"):
                     return self(self._native_mode_u8(image), return_uint8)

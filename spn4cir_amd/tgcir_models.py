@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import gradsink, ops
+from .preprocess import gpu_decode_scope, stack_images
 from ._lib import check, lib
 from .ops import _p, _stream
 from .text_tower import TextTower, text_cfg_from_state_dict
@@ -342,10 +343,11 @@ class CIRPlus(nn.Module):
         return tokens
 
     @staticmethod
-    def _image_batches(dataset, bs=32):
+    def _image_batches(dataset, bs=128):
         n = len(dataset)
         for s in range(0, n, bs):
-            items = [dataset[i] for i in range(s, min(n, s + bs))]
+            with gpu_decode_scope(dataset):                         # undecoded JPEGs come back as file bytes: decoded on the GPU per batch
+                items = [dataset[i] for i in range(s, min(n, s + bs))]
             items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
             if items:
                 yield items
@@ -358,8 +360,8 @@ class CIRPlus(nn.Module):
         NT, C = self.head.NT, self.head.C
         refer, target = torch.zeros(len(cirDataset), NT, C), torch.zeros(cirDataset.image_id, C)
         for items in self._image_batches(cirDataset):
-            rtok, rpool = self.img_embed(torch.stack([it[0] for it in items]), True)
-            _, tpool = self.img_embed(torch.stack([it[2] for it in items]), True)
+            rtok, rpool = self.img_embed(stack_images([it[0] for it in items]), True)
+            _, tpool = self.img_embed(stack_images([it[2] for it in items]), True)
             refer[torch.tensor([int(it[3]) for it in items])] = rtok.cpu()
             target[torch.tensor([int(it[5]) for it in items])] = rpool.cpu()
             target[torch.tensor([int(it[6]) for it in items])] = tpool.cpu()
@@ -374,8 +376,8 @@ class CIRPlus(nn.Module):
             return
         refer = torch.zeros(cirDataset.image_id, self.head.NT, self.head.C)
         for items in self._image_batches(cirDataset):
-            refer[torch.tensor([int(it[5]) for it in items])] = self.img_embed(torch.stack([it[0] for it in items])).cpu()
-            refer[torch.tensor([int(it[6]) for it in items])] = self.img_embed(torch.stack([it[2] for it in items])).cpu()
+            refer[torch.tensor([int(it[5]) for it in items])] = self.img_embed(stack_images([it[0] for it in items])).cpu()
+            refer[torch.tensor([int(it[6]) for it in items])] = self.img_embed(stack_images([it[2] for it in items])).cpu()
         self.refer_bank = refer
         if bank_path:
             torch.save(refer, bank_path)

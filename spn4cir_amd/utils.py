@@ -3,18 +3,21 @@ from pathlib import Path
 
 import torch
 
+from .preprocess import gpu_decode_scope, stack_images
+
 
 def extract_index_features(dataset, model, device=torch.device("cuda")):
     """utils.py:24-50: (names, images) items of a 'classic' dataset -> (features [N, D], names)."""
     feats, names = [], []
     n = len(dataset)
     for s in range(0, n, 32):
-        items = [dataset[i] for i in range(s, min(n, s + 32))]
+        with gpu_decode_scope(dataset):                         # undecoded JPEGs -> file bytes, decoded on the GPU per batch
+            items = [dataset[i] for i in range(s, min(n, s + 32))]
         items = [it for it in items if it is not None]
         if not items:
             continue
         names.extend(it[0] for it in items)
-        feats.append(model.encode_image(torch.stack([it[1] for it in items])))
+        feats.append(model.encode_image(stack_images([it[1] for it in items])))
     return torch.vstack(feats), names
 
 
@@ -24,12 +27,13 @@ def extract_index_features_fusion(dataset, model, device=torch.device("cuda")):
     toks, pooled, names = [], [], []
     n = len(dataset)
     for s in range(0, n, 32):
-        items = [dataset[i] for i in range(s, min(n, s + 32))]
+        with gpu_decode_scope(dataset):
+            items = [dataset[i] for i in range(s, min(n, s + 32))]
         items = [it for it in items if it is not None]
         if not items:
             continue
         names.extend(it[0] for it in items)
-        t, p = model.img_embed(torch.stack([it[1] for it in items]), return_pool_and_normalized=True)
+        t, p = model.img_embed(stack_images([it[1] for it in items]), return_pool_and_normalized=True)
         toks.append(t.cpu())
         pooled.append(p)
     return torch.vstack(toks), torch.vstack(pooled), names
