@@ -26,14 +26,41 @@ using spnjpeg::Huff;
 using spnjpeg::Image;
 using spnjpeg::Segment;
 
-__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const uint8_t* __restrict__ bytes, const Image* __restrict__ images,
+// Lanes per workgroup of the entropy kernel.  A lane's byte stream, table look-ups and block stores are its own, so a 64-lane
+// wave instruction touches up to 64 cache lines; with 16 lanes per workgroup a batch of 256 files spreads over 16 CUs' memory pipes
+// (each lane runs the same serial loop either way: lanes are the parallelism, not waves).
+static constexpr int JPEG_LANES = 16;
+static constexpr int JPEG_LDS = JPEG_LANES * 6 * (int)sizeof(Huff) + JPEG_LANES * 68 * 2;
+static_assert(sizeof(Huff) % 16 == 0 && JPEG_LDS <= 160 * 1024, "entropy kernel LDS");
+
+__global__ __launch_bounds__(JPEG_LANES) void jpeg_huffman_kernel(const uint8_t* __restrict__ bytes, const Image* __restrict__ images,
                                                          const Segment* __restrict__ segs, int n_segs, const Huff* __restrict__ tabs,
                                                          int16_t* __restrict__ coefs) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n_segs) return;
-    const Segment sg = segs[s];
-    const Image im = images[sg.image];
-    spnjpeg::decode_segment(im, sg, bytes, tabs, coefs);
+    // LDS of a workgroup: every lane's six Huffman tables (134 KB for 16 lanes), its block under assembly (64 int16, rows of 136 bytes
+    // = 34 dwords: the lanes' same-index accesses spread over the banks) - nothing on a lane's serial path
+    // reads global memory except its own byte stream (one prefetched dword per 32 bits)
+    extern __shared__ __attribute__((aligned(16))) char jsm[];
+    Huff* stab = (Huff*)jsm;                                                    // [JPEG_LANES][6]
+    int16_t* sblk = (int16_t*)(jsm + JPEG_LANES * 6 * sizeof(Huff));             // [JPEG_LANES][68]
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x * JPEG_LANES + lane;
+    const bool live = s < n_segs;
+    Segment sg = {0, 0, 0, 0};
+    Image im;
+    if (live) {
+        sg = segs[s];
+        im = images[sg.image];
+        for (int c = 0; c < im.ncomp; ++c) {
+            const uint4* src_d = (const uint4*)(tabs + im.dc_tab[c]);
+            const uint4* src_a = (const uint4*)(tabs + im.ac_tab[c]);
+            uint4* dst_d = (uint4*)(stab + lane * 6 + 2 * c);
+            uint4* dst_a = (uint4*)(stab + lane * 6 + 2 * c + 1);
+            for (int i = 0; i < (int)(sizeof(Huff) / 16); ++i) { dst_d[i] = src_d[i]; dst_a[i] = src_a[i]; }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    spnjpeg::decode_segment(im, sg, bytes, stab + lane * 6, coefs, sblk + lane * 68);
 }
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Image* __restrict__ images, const int16_t* __restrict__ coefs,
@@ -69,8 +96,13 @@ int jpeg_decode_batch(const uint8_t* bytes, const void* images, int n_images, co
     if (!bytes || !images || !segs || !huff || !qtabs || !coefs || !planes || !rgb) return SPN_ERR_ARG;
     if (n_images <= 0 || n_segs <= 0 || max_blocks <= 0 || max_pixels <= 0) return SPN_ERR_ARG;
     if (coef_elems % 2 || ((uintptr_t)coefs & 15)) return SPN_ERR_SHAPE;
-    SPN_TRYJ(zero_fill_f32((float*)coefs, coef_elems / 2, st));          // int16 pairs as 32-bit words
-    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((n_segs + 63) / 64), dim3(64), 0, st, bytes, (const Image*)images, (const Segment*)segs,
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)jpeg_huffman_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, JPEG_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((n_segs + JPEG_LANES - 1) / JPEG_LANES), dim3(JPEG_LANES), JPEG_LDS, st, bytes, (const Image*)images, (const Segment*)segs,
                        n_segs, (const Huff*)huff, coefs);
     SPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + 255) / 256, n_images * 3), dim3(256), 0, st, (const Image*)images, coefs, qtabs,

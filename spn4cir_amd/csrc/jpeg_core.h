@@ -24,7 +24,7 @@ struct Image {
     int32_t width, height, ncomp, hs, vs;        // luma sampling factors (chroma is 1 x 1): 1x1, 2x1, 2x2
     int32_t mcux, mcuy, restart_interval;
     uint32_t scan_off, scan_len;                 // entropy-coded segment in the batch's byte buffer
-    uint32_t coef_off[3];                        // int16 ELEMENT offset of each component's [blocks_y][blocks_x][64] coefficients
+    uint32_t coef_off[3];                        // int16 ELEMENT offset of each component's [blocks_y][blocks_x][64] coefficients (zigzag order)
     int32_t blocks_x[3], blocks_y[3];            // padded (whole-MCU) block grid per component
     uint32_t plane_off[3];                       // byte offset of each component's uint8 plane [8 blocks_y][8 blocks_x]
     int32_t qt[3], dc_tab[3], ac_tab[3];         // indices into the batch's quantiser / Huffman table arrays
@@ -50,11 +50,21 @@ struct Huff {
 };
 static_assert(sizeof(Huff) == 1024 + 72 + 68 + 256 + 4, "spn_jpeg_huff layout");
 
-SPN_JHD int zigzag(int k) {
+SPN_JHD int zigzag(int k) {                      // k-th coefficient of the zigzag scan -> natural (row-major) position
     const unsigned char z[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7,
                                  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46,
                                  53, 60, 61, 54, 47, 55, 62, 63};
     return z[k];
+}
+
+// 32-bit big-endian load from an arbitrary byte address (gfx950 global memory serves unaligned dwords: ONE global_load_dword)
+SPN_JHD uint32_t load_be32(const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    return __builtin_bswap32(*(const u32u*)p);
+#else
+    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+#endif
 }
 
 struct BitReader {
@@ -62,8 +72,26 @@ struct BitReader {
     const uint8_t* end;
     uint64_t acc;
     int n;
-    // top up to > 56 bits; a marker (FF xx, xx != 0) ends the data: zero bits from there on, the pointer stays on the marker
+    uint32_t ahead;                              // the four bytes at p, requested when p was set (latency hidden behind decoding)
+    SPN_JHD void init(const uint8_t* begin, const uint8_t* stop) {
+        p = begin; end = stop; acc = 0; n = 0;
+        ahead = (p + 4 <= end) ? load_be32(p) : 0;
+    }
+    // Keep at least 33 valid bits.  Fast path: four data bytes at once when none of them is 0xFF (no stuffing, no marker).  Slow path,
+    // byte by byte: FF 00 is a data byte 0xFF; any other FF xx is a marker - it ends the data: zero bits from there on, the
+    // pointer stays on the marker (what the IJG decoder feeds after "premature end of data segment").
     SPN_JHD void fill() {
+        if (n > 32) return;
+        if (p + 4 <= end) {
+            const uint32_t w = ahead;
+            if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {
+                acc = (acc << 32) | w;
+                n += 32;
+                p += 4;
+                ahead = (p + 4 <= end) ? load_be32(p) : 0;
+                return;
+            }
+        }
         while (n <= 56) {
             unsigned b = 0;
             if (p < end) {
@@ -79,75 +107,102 @@ struct BitReader {
             acc = (acc << 8) | b;
             n += 8;
         }
+        ahead = (p + 4 <= end) ? load_be32(p) : 0;
     }
     SPN_JHD unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1u)); }
     SPN_JHD void skip(int k) { n -= k; }
 };
 
-SPN_JHD int huff_decode(BitReader& br, const Huff& t) {
-    br.fill();
-    const unsigned e = t.look[br.peek(9)];
+// One Huffman symbol AND the value bits behind it from ONE 32-bit window of the stream (code <= 16 bits + value <= 15 bits): returns
+// the symbol; *value = the sign-extended magnitude of (symbol & 15) bits (T.81 F.2.2.1 EXTEND), 0 when that is 0 bits.
+// A lane's decode loop is a serial chain - on this GPU every dependent VALU instruction of a lone wave costs ~9-18 cycles and an LDS
+// round trip ~64 (tools/lat/lat.hip) - so what counts is instructions per symbol: one refill test, one 64-bit shift, one look-up.
+SPN_JHD int decode_symbol(BitReader& br, const Huff& t, int* value) {
+    br.fill();                                                   // >= 33 valid bits
+    const uint32_t w = (uint32_t)(br.acc >> (br.n - 32));        // the next 32 bits, left-aligned
+    unsigned e = t.look[w >> 23];
+    int len, sym;
     if (e) {
-        br.skip((int)(e >> 8));
-        return (int)(e & 255u);
-    }
-    for (int l = 10; l <= 16; ++l) {
-        const int code = (int)br.peek(l);
-        if (code <= t.maxcode[l]) {
-            br.skip(l);
-            return t.sym[(t.valoff[l] + code) & 255];
+        len = (int)(e >> 8);
+        sym = (int)(e & 255u);
+    } else {
+        len = 16;
+        sym = 0;                                                 // not a code of this table (corrupt data): the IJG decoder substitutes 0
+        for (int l = 10; l <= 16; ++l) {
+            const int code = (int)(w >> (32 - l));
+            if (code <= t.maxcode[l]) {
+                len = l;
+                sym = t.sym[(t.valoff[l] + code) & 255];
+                break;
+            }
         }
     }
-    br.skip(16);                                 // not a code of this table (corrupt data): the IJG decoder substitutes 0
-    return 0;
+    const int s = sym & 15;
+    int v = 0;
+    if (s) {
+        v = (int)((w << len) >> (32 - s));
+        if (v < (1 << (s - 1))) v += 1 - (1 << s);
+    }
+    *value = v;
+    br.n -= len + s;
+    return sym;
 }
 
-SPN_JHD int receive_extend(BitReader& br, int s) {
-    if (s == 0) return 0;
-    br.fill();
-    const int v = (int)br.peek(s);
-    br.skip(s);
-    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
-}
-
-// Entropy-decode one segment: writes the NON-ZERO coefficients (natural order) of its MCUs; the coefficient buffer is zero on entry.
-// Returns 0, or a negative code for a truncated / inconsistent stream (the image is still written as far as it went).
-SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* bytes, const Huff* tabs, int16_t* coefs) {
-    BitReader br;
-    br.p = bytes + sg.byte_off;
-    br.end = bytes + im.scan_off + im.scan_len;
-    br.acc = 0;
-    br.n = 0;
-    int pred[3] = {0, 0, 0};
-    const int mcu_end = sg.mcu_first + sg.mcu_count;
-    for (int mcu = sg.mcu_first; mcu < mcu_end; ++mcu) {
-        const int my = mcu / im.mcux, mx = mcu - my * im.mcux;
-        for (int c = 0; c < im.ncomp; ++c) {
-            const int ch = c == 0 ? im.hs : 1, cv = c == 0 ? im.vs : 1;
-            const Huff& dct = tabs[im.dc_tab[c]];
-            const Huff& act = tabs[im.ac_tab[c]];
-            for (int by = 0; by < cv; ++by)
-                for (int bx = 0; bx < ch; ++bx) {
-                    int16_t* blk = coefs + im.coef_off[c] + ((size_t)(my * cv + by) * im.blocks_x[c] + (mx * ch + bx)) * 64;
-                    const int t = huff_decode(br, dct);
-                    pred[c] += receive_extend(br, t & 15);
-                    blk[0] = (int16_t)pred[c];
-                    int k = 1;
-                    while (k < 64) {
-                        const int rs = huff_decode(br, act);
-                        const int r = rs >> 4, s = rs & 15;
-                        if (s == 0) {
-                            if (r != 15) break;
-                            k += 16;
-                            continue;
-                        }
-                        k += r;
-                        if (k > 63) break;
-                        blk[zigzag(k)] = (int16_t)receive_extend(br, s);
-                        ++k;
-                    }
+// Entropy-decode the blocks of ONE component inside the current MCU (ch x cv of them).  Everything the inner loop touches is either a
+// register or the caller's fast storage: `dct` / `act` (Huffman tables: a lane's LDS copies on the device) and `blk` (the block under
+// assembly: 64 int16, 8-byte aligned, LDS).  Coefficients are kept in ZIGZAG order (the order of the stream: blk[k] = k-th coded
+// coefficient) - the inverse DCT un-zigzags with compile-time indices, which keeps a table look-up off the serial path.
+// The block is written to the coefficient buffer whole, zeros included: 128 contiguous bytes, no zero fill of the buffer beforehand.
+SPN_JHD void decode_component(BitReader& br, const Huff& dct, const Huff& act, int& pred, int ch, int cv, int16_t* comp_coefs,
+                              int blocks_x, int my, int mx, int16_t* blk) {
+    typedef uint64_t __attribute__((may_alias)) u64a;     // the block is filled as int16 and moved as 64-bit words
+    u64a* b64 = (u64a*)blk;
+    for (int by = 0; by < cv; ++by)
+        for (int bx = 0; bx < ch; ++bx) {
+            for (int i = 0; i < 16; ++i) b64[i] = 0;
+            int v;
+            decode_symbol(br, dct, &v);                         // DC: the symbol IS the magnitude category (<= 11 bits)
+            pred += v;
+            blk[0] = (int16_t)pred;
+            int k = 1;
+            while (k < 64) {
+                const int rs = decode_symbol(br, act, &v);
+                const int r = rs >> 4;
+                if ((rs & 15) == 0) {
+                    if (r != 15) break;                         // EOB
+                    k += 16;                                    // ZRL
+                    continue;
                 }
+                k += r;
+                if (k > 63) break;
+                blk[k] = (int16_t)v;
+                ++k;
+            }
+            u64a* out = (u64a*)(comp_coefs + ((size_t)(my * cv + by) * blocks_x + (mx * ch + bx)) * 64);
+            for (int i = 0; i < 16; ++i) out[i] = b64[i];
         }
+}
+
+// Entropy-decode one segment (a whole scan or one restart interval).  tabs6 = the image's six Huffman tables in the order
+// {dc, ac} of component 0, 1, 2 (the caller's fast copies; unused slots of a grayscale image are never read).
+SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* bytes, const Huff* tabs6, int16_t* coefs, int16_t* blk) {
+    BitReader br;
+    br.init(bytes + sg.byte_off, bytes + im.scan_off + im.scan_len);
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    const int ncomp = im.ncomp, hs = im.hs, vs = im.vs, mcux = im.mcux;
+    int16_t* c0 = coefs + im.coef_off[0];
+    int16_t* c1 = coefs + im.coef_off[1];
+    int16_t* c2 = coefs + im.coef_off[2];
+    const int bx0 = im.blocks_x[0], bx1 = im.blocks_x[1], bx2 = im.blocks_x[2];
+    const int mcu_end = sg.mcu_first + sg.mcu_count;
+    int my = sg.mcu_first / mcux, mx = sg.mcu_first - my * mcux;
+    for (int mcu = sg.mcu_first; mcu < mcu_end; ++mcu) {
+        decode_component(br, tabs6[0], tabs6[1], pred0, hs, vs, c0, bx0, my, mx, blk);
+        if (ncomp == 3) {
+            decode_component(br, tabs6[2], tabs6[3], pred1, 1, 1, c1, bx1, my, mx, blk);
+            decode_component(br, tabs6[4], tabs6[5], pred2, 1, 1, c2, bx2, my, mx, blk);
+        }
+        if (++mx == mcux) { mx = 0; ++my; }
     }
     return 0;
 }
@@ -182,10 +237,13 @@ SPN_JHD void idct_1d(const int32_t* x, int stride, int32_t* o, int ostride, int 
     o[4 * ostride] = (tmp13 - t0 + rnd) >> shift;
 }
 
-// coef [64] natural order x q [64] -> out [8 rows][8] uint8 at `stride` bytes per row
+// coef [64] x q [64], BOTH in zigzag order (as coded in the file) -> out [8 rows][8] uint8 at `stride` bytes per row
 SPN_JHD void idct_block(const int16_t* coef, const uint16_t* q, uint8_t* out, int stride) {
     int32_t in[64], ws[64];
-    for (int i = 0; i < 64; ++i) in[i] = (int32_t)coef[i] * (int32_t)q[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 64; ++i) in[zigzag(i)] = (int32_t)coef[i] * (int32_t)q[i];
     for (int c = 0; c < 8; ++c) idct_1d(in + c, 8, ws + c, 8, 13 - 2);               // pass 1: down each column
     for (int r = 0; r < 8; ++r) {
         int32_t row[8];

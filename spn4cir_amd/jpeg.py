@@ -19,11 +19,6 @@ import torch
 IMAGE_WORDS = 40
 HUFF_BYTES = 1424
 
-_ZIGZAG = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
-                    28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61,
-                    54, 47, 55, 62, 63], dtype=np.int64)
-
-
 class Unsupported(ValueError):
     """The file is not in the kernels' scope (progressive, CMYK, unusual sampling, ...): decode it with Pillow."""
 
@@ -33,7 +28,7 @@ def _be16(b, i):
 
 
 def parse_header(data):
-    """One pass over the markers of a JPEG file -> dict(width, height, comps=[(id, h, v, tq, td, ta)], qt={id: uint16[64] natural
+    """One pass over the markers of a JPEG file -> dict(width, height, comps=[(id, h, v, tq, td, ta)], qt={id: uint16[64] in zigzag
     order}, dc / ac = {id: (counts bytes[16], symbols bytes)}, restart_interval, scan_off).  Raises Unsupported."""
     b = memoryview(data)
     n = len(b)
@@ -65,9 +60,7 @@ def parse_header(data):
                 else:
                     vals = np.frombuffer(b[s:s + 64], dtype=np.uint8).astype(np.uint16)
                     s += 64
-                q = np.zeros(64, dtype=np.uint16)
-                q[_ZIGZAG] = vals
-                qt[tq] = q
+                qt[tq] = vals                     # kept in zigzag order, as coded: so are the kernels' coefficient blocks
         elif m == 0xC0 or m == 0xC1:
             if b[s] != 8:
                 raise Unsupported("sample precision other than 8 bits")
@@ -224,8 +217,8 @@ class Batch:
                 raise ValueError("batch too large for 32-bit offsets: decode fewer files per call")
         self.images = images
         self.segs = np.array(segs, dtype=np.uint32).reshape(-1, 4)
-        self.bytes = np.frombuffer(b"".join(chunks) + b"\xff\xd9\0\0", dtype=np.uint8)
-        self.huff = np.frombuffer(b"".join(huffs), dtype=np.uint8)
+        self.bytes = np.frombuffer(bytearray(b"".join(chunks) + b"\xff\xd9\0\0"), dtype=np.uint8)
+        self.huff = np.frombuffer(bytearray(b"".join(huffs)), dtype=np.uint8)
         self.qt = np.stack(qts).astype(np.uint16)
         self.coef_elems = (coef_off + 7) & ~7
         self.plane_bytes = plane_off

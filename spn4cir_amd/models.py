@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import gradsink, ops
-from .preprocess import gpu_decode_scope, stack_images
+from .preprocess import gpu_decode_scope, realize_items, stack_images
 from .text_tower import TextTower, text_cfg_from_state_dict
 from .vision_tower import VisionTower, vision_cfg_from_state_dict
 
@@ -232,14 +232,17 @@ class CIRPlus(nn.Module):
     # (reference_image, caption, target_image, index, target_index, reference_index_all, target_index_all)
     # with images already preprocessed to fp32 [3, res, res]; 'unlabeled' mode yields single images.
     @staticmethod
-    def _image_batches(dataset, bs=128):
+    def _image_batches(dataset, bs=128, decode_bs=1024):
+        """Items of the dataset in batches of `bs` for the image tower.  The items are fetched `decode_bs` at a time with the
+        dataset's transform in deferred mode: undecoded JPEGs come back as file bytes and the whole chunk (reference AND target
+        images) is decoded on the GPU in one call - a lane per file, so the chunk size is the decoder's parallelism."""
         n = len(dataset)
-        for s in range(0, n, bs):
-            with gpu_decode_scope(dataset):                         # undecoded JPEGs come back as file bytes: decoded on the GPU per batch
-                items = [dataset[i] for i in range(s, min(n, s + bs))]
-            items = [it for it in items if it is not None]          # utils.collate_fn drops None samples
-            if items:
-                yield items
+        for s in range(0, n, decode_bs):
+            with gpu_decode_scope(dataset):
+                items = [dataset[i] for i in range(s, min(n, s + decode_bs))]
+            items = realize_items([it for it in items if it is not None])      # utils.collate_fn drops None samples
+            for k in range(0, len(items), bs):
+                yield items[k:k + bs]
 
     def extract_bank_features(self, cirDataset, device=None, bank_path=None, reload_bank=False):
         """models_negplus.py:59-80: per-triplet raw reference features + normalised unique-image target bank."""

@@ -102,6 +102,28 @@ class gpu_decode_scope:
         return False
 
 
+def realize_items(items):
+    """[tuple / list / single] dataset items whose fields may be DeferredImage -> the same items with every deferred field replaced by
+    its preprocessed tensor; ALL deferred images of the list go through one batched GPU decode (a lane per file: the more files per
+    call, the more of the device decodes - tools/jpeg_bench.py)."""
+    refs = []
+    for i, it in enumerate(items):
+        if isinstance(it, DeferredImage):
+            refs.append((i, None, it))
+        elif isinstance(it, (tuple, list)):
+            refs.extend((i, j, f) for j, f in enumerate(it) if isinstance(f, DeferredImage))
+    if not refs:
+        return list(items)
+    done = refs[0][2].transform.realize([r[2] for r in refs])
+    out = [list(it) if isinstance(it, (tuple, list)) else it for it in items]
+    for (i, j, _), t in zip(refs, done):
+        if j is None:
+            out[i] = t
+        else:
+            out[i][j] = t
+    return [tuple(o) if isinstance(items[k], tuple) else o for k, o in enumerate(out)]
+
+
 def stack_images(images):
     """[n] preprocessed image tensors and / or DeferredImage -> fp32 [n, 3, dim, dim] on the device: the deferred ones are decoded
     in ONE batched GPU call (spn_jpeg_decode_batch) and preprocessed from device memory."""
@@ -163,10 +185,8 @@ class TargetPadTransform:
         """File bytes of a PIL JPEG whose pixels have not been loaded (None otherwise)."""
         if getattr(image, "format", None) != "JPEG" or getattr(image, "mode", None) not in ("RGB", "L"):
             return None
-        try:
-            if image.im is not None:                    # already decoded by somebody: nothing to save
-                return None
-        except AttributeError:
+        d = getattr(image, "__dict__", {})
+        if d.get("_im", d.get("im")) is not None:       # already decoded by somebody (Pillow >= 11: _im, before: im): nothing to save
             return None
         name = getattr(image, "filename", "")
         try:

@@ -104,3 +104,61 @@ def test_decode_throughput_report():
     dt = time.perf_counter() - t0
     print(f"Pillow on one host core: {32 / dt:.0f} images/s")
     assert np.array_equal(out[3].cpu().numpy(), _pil(files[3]))
+
+
+def test_bank_builders_decode_on_the_gpu(golden_dir, tmp_path, monkeypatch):
+    """extract_bank_features / extract_index_features over a dataset that does what the reference's CIRDataset does -
+    `self.preprocess(PIL.Image.open(path))` per item (data_utils_negplus.py:268-319) - with JPEG files on disk: the builders fetch the
+    items with the transform in deferred mode, decode whole chunks on the GPU and produce the SAME banks / index features, bit for bit,
+    as with host decoding (SPN_GPU_JPEG=0)."""
+    _need_gpu()
+    from test_jpeg_cpu import _synth
+    from spn4cir_amd import jpeg
+    from spn4cir_amd.models import CIRPlus
+    from spn4cir_amd.utils import extract_index_features
+    z = np.load(os.path.join(golden_dir, "tiny_clip.npz"))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    rng = np.random.default_rng(11)
+    paths = []
+    for k in range(9):
+        p = tmp_path / (f"im{k}.png" if k == 4 else f"im{k}.jpg")
+        img = Image.fromarray(_synth(rng, 40 + 7 * k, 90 - 5 * k, 2))
+        img.save(p, **({} if k == 4 else dict(format="JPEG", quality=80 + k, subsampling=k % 3, progressive=(k == 7))))
+        paths.append(str(p))
+    model = CIRPlus(sd, device=torch.device("cuda"), plus=True)
+
+    class Train:                                          # relative / train mode items: (ref img, caption, tgt img, idx, tgt id, ref id_all, tgt id_all)
+        image_id = 9
+        trip = [(0, 1), (2, 3), (4, 5), (6, 7), (8, 0), (7, 2)]
+        preprocess = model.preprocess
+
+        def __len__(self):
+            return len(self.trip)
+
+        def __getitem__(self, i):
+            r, t = self.trip[i]
+            return self.preprocess(Image.open(paths[r])), "cap", self.preprocess(Image.open(paths[t])), i, t, r, t
+
+    class Classic:                                        # classic mode items: (name, image)
+        preprocess = model.preprocess
+        data_name, split, dress_types = "fiq", "val", ["dress"]
+
+        def __len__(self):
+            return len(paths)
+
+        def __getitem__(self, i):
+            return f"n{i}", self.preprocess(Image.open(paths[i]))
+
+    calls = []
+    real = jpeg.decode_batch
+    monkeypatch.setattr(jpeg, "decode_batch", lambda files, device="cuda": (calls.append(len(files)), real(files, device))[1])
+    model.extract_bank_features(Train(), bank_path=None)
+    refer_gpu, target_gpu = model.refer_bank.clone(), model.target_bank.clone()
+    feats_gpu, names = extract_index_features(Classic(), model)
+    assert calls == [10, 8], calls          # ONE decode call per chunk: 12 image fields minus the PNG's two, 9 files minus the PNG
+    monkeypatch.setenv("SPN_GPU_JPEG", "0")
+    model.extract_bank_features(Train(), bank_path=None)
+    feats_host, names2 = extract_index_features(Classic(), model)
+    assert len(calls) == 2 and names == names2 == [f"n{i}" for i in range(9)]
+    assert torch.equal(model.refer_bank, refer_gpu) and torch.equal(model.target_bank, target_gpu)
+    assert torch.equal(feats_gpu, feats_host)
