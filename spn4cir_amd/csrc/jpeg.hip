@@ -30,18 +30,16 @@ using spnjpeg::Segment;
 // wave instruction touches up to 64 cache lines; with 16 lanes per workgroup a batch of 256 files spreads over 16 CUs' memory pipes
 // (each lane runs the same serial loop either way: lanes are the parallelism, not waves).
 static constexpr int JPEG_LANES = 16;
-static constexpr int JPEG_LDS = JPEG_LANES * 6 * (int)sizeof(Huff) + JPEG_LANES * 68 * 2;
+static constexpr int JPEG_LDS = JPEG_LANES * 6 * (int)sizeof(Huff);
 static_assert(sizeof(Huff) % 16 == 0 && JPEG_LDS <= 160 * 1024, "entropy kernel LDS");
 
 __global__ __launch_bounds__(JPEG_LANES) void jpeg_huffman_kernel(const uint8_t* __restrict__ bytes, const Image* __restrict__ images,
                                                          const Segment* __restrict__ segs, int n_segs, const Huff* __restrict__ tabs,
                                                          int16_t* __restrict__ coefs) {
-    // LDS of a workgroup: every lane's six Huffman tables (134 KB for 16 lanes), its block under assembly (64 int16, rows of 136 bytes
-    // = 34 dwords: the lanes' same-index accesses spread over the banks) - nothing on a lane's serial path
-    // reads global memory except its own byte stream (one prefetched dword per 32 bits)
+    // LDS of a workgroup: every lane's six Huffman tables (134 KB for 16 lanes) - nothing on a lane's serial path reads global
+    // memory except its own byte stream (one prefetched dword per 32 bits); coefficients leave as 2-byte stores nobody waits for
     extern __shared__ __attribute__((aligned(16))) char jsm[];
     Huff* stab = (Huff*)jsm;                                                    // [JPEG_LANES][6]
-    int16_t* sblk = (int16_t*)(jsm + JPEG_LANES * 6 * sizeof(Huff));             // [JPEG_LANES][68]
     const int lane = threadIdx.x;
     const int s = blockIdx.x * JPEG_LANES + lane;
     const bool live = s < n_segs;
@@ -60,7 +58,7 @@ __global__ __launch_bounds__(JPEG_LANES) void jpeg_huffman_kernel(const uint8_t*
     }
     __syncthreads();
     if (!live) return;
-    spnjpeg::decode_segment(im, sg, bytes, stab + lane * 6, coefs, sblk + lane * 68);
+    spnjpeg::decode_segment(im, sg, bytes, stab + lane * 6, coefs);
 }
 
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const Image* __restrict__ images, const int16_t* __restrict__ coefs,
@@ -102,6 +100,7 @@ int jpeg_decode_batch(const uint8_t* bytes, const void* images, int n_images, co
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    SPN_TRYJ(zero_fill_f32((float*)coefs, coef_elems / 2, st));          // int16 pairs as 32-bit words: only non-zero coefficients are stored
     hipLaunchKernelGGL(jpeg_huffman_kernel, dim3((n_segs + JPEG_LANES - 1) / JPEG_LANES), dim3(JPEG_LANES), JPEG_LDS, st, bytes, (const Image*)images, (const Segment*)segs,
                        n_segs, (const Huff*)huff, coefs);
     SPN_CHECK_LAUNCH();

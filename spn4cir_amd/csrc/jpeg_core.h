@@ -57,25 +57,28 @@ SPN_JHD int zigzag(int k) {                      // k-th coefficient of the zigz
     return z[k];
 }
 
-// 32-bit big-endian load from an arbitrary byte address (gfx950 global memory serves unaligned dwords: ONE global_load_dword)
-SPN_JHD uint32_t load_be32(const uint8_t* p) {
+// 32-bit load from an arbitrary byte address, RAW (gfx950 global memory serves unaligned dwords: ONE global_load_dword), and its
+// big-endian reading.  The two are separate on purpose: the byte swap at the point of USE lets the load issued at the end of one
+// refill stay in flight until the next refill needs it (swapping where it is loaded puts the wait right behind the load).
+SPN_JHD uint32_t load_raw32(const uint8_t* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef uint32_t __attribute__((aligned(1))) u32u;
-    return __builtin_bswap32(*(const u32u*)p);
+    return *(const u32u*)p;
 #else
-    return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 #endif
 }
+SPN_JHD uint32_t be32(uint32_t raw) { return __builtin_bswap32(raw); }
 
 struct BitReader {
     const uint8_t* p;
     const uint8_t* end;
     uint64_t acc;
     int n;
-    uint32_t ahead;                              // the four bytes at p, requested when p was set (latency hidden behind decoding)
+    uint32_t ahead;                              // the four bytes at p (raw), requested when p was set: latency hidden behind decoding
     SPN_JHD void init(const uint8_t* begin, const uint8_t* stop) {
         p = begin; end = stop; acc = 0; n = 0;
-        ahead = (p + 4 <= end) ? load_be32(p) : 0;
+        ahead = (p + 4 <= end) ? load_raw32(p) : 0;
     }
     // Keep at least 33 valid bits.  Fast path: four data bytes at once when none of them is 0xFF (no stuffing, no marker).  Slow path,
     // byte by byte: FF 00 is a data byte 0xFF; any other FF xx is a marker - it ends the data: zero bits from there on, the
@@ -83,12 +86,12 @@ struct BitReader {
     SPN_JHD void fill() {
         if (n > 32) return;
         if (p + 4 <= end) {
-            const uint32_t w = ahead;
+            const uint32_t w = ahead;                                      // byte order does not matter for the 0xFF test
             if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {
-                acc = (acc << 32) | w;
+                acc = (acc << 32) | be32(w);
                 n += 32;
                 p += 4;
-                ahead = (p + 4 <= end) ? load_be32(p) : 0;
+                ahead = (p + 4 <= end) ? load_raw32(p) : 0;
                 return;
             }
         }
@@ -107,7 +110,7 @@ struct BitReader {
             acc = (acc << 8) | b;
             n += 8;
         }
-        ahead = (p + 4 <= end) ? load_be32(p) : 0;
+        ahead = (p + 4 <= end) ? load_raw32(p) : 0;
     }
     SPN_JHD unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1u)); }
     SPN_JHD void skip(int k) { n -= k; }
@@ -148,61 +151,66 @@ SPN_JHD int decode_symbol(BitReader& br, const Huff& t, int* value) {
     return sym;
 }
 
-// Entropy-decode the blocks of ONE component inside the current MCU (ch x cv of them).  Everything the inner loop touches is either a
-// register or the caller's fast storage: `dct` / `act` (Huffman tables: a lane's LDS copies on the device) and `blk` (the block under
-// assembly: 64 int16, 8-byte aligned, LDS).  Coefficients are kept in ZIGZAG order (the order of the stream: blk[k] = k-th coded
-// coefficient) - the inverse DCT un-zigzags with compile-time indices, which keeps a table look-up off the serial path.
-// The block is written to the coefficient buffer whole, zeros included: 128 contiguous bytes, no zero fill of the buffer beforehand.
-SPN_JHD void decode_component(BitReader& br, const Huff& dct, const Huff& act, int& pred, int ch, int cv, int16_t* comp_coefs,
-                              int blocks_x, int my, int mx, int16_t* blk) {
-    typedef uint64_t __attribute__((may_alias)) u64a;     // the block is filled as int16 and moved as 64-bit words
-    u64a* b64 = (u64a*)blk;
-    for (int by = 0; by < cv; ++by)
-        for (int bx = 0; bx < ch; ++bx) {
-            for (int i = 0; i < 16; ++i) b64[i] = 0;
-            int v;
-            decode_symbol(br, dct, &v);                         // DC: the symbol IS the magnitude category (<= 11 bits)
-            pred += v;
-            blk[0] = (int16_t)pred;
-            int k = 1;
-            while (k < 64) {
-                const int rs = decode_symbol(br, act, &v);
-                const int r = rs >> 4;
-                if ((rs & 15) == 0) {
-                    if (r != 15) break;                         // EOB
-                    k += 16;                                    // ZRL
-                    continue;
-                }
-                k += r;
-                if (k > 63) break;
-                blk[k] = (int16_t)v;
-                ++k;
-            }
-            u64a* out = (u64a*)(comp_coefs + ((size_t)(my * cv + by) * blocks_x + (mx * ch + bx)) * 64);
-            for (int i = 0; i < 16; ++i) out[i] = b64[i];
-        }
-}
-
-// Entropy-decode one segment (a whole scan or one restart interval).  tabs6 = the image's six Huffman tables in the order
-// {dc, ac} of component 0, 1, 2 (the caller's fast copies; unused slots of a grayscale image are never read).
-SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* bytes, const Huff* tabs6, int16_t* coefs, int16_t* blk) {
+// Entropy-decode one segment (a whole scan or one restart interval) as ONE flat loop over symbols.  tabs6 = the image's six Huffman
+// tables in the order {dc, ac} of component 0, 1, 2 (the caller's fast copies - a lane's LDS slots on the device; unused slots of a
+// grayscale image are never read).  Coefficients are stored in ZIGZAG order (the order of the stream: position k of a block = its
+// k-th coded coefficient; the inverse DCT un-zigzags with compile-time indices), straight into the zero-filled coefficient buffer:
+// one 2-byte store per non-zero coefficient, nothing to wait for.
+// Why a flat loop: the lanes of a wave decode different files in lockstep.  With a loop per block the wave re-converges at every
+// block end, so every block costs the LONGEST block among the lanes (measured: 1 357 cycles per symbol of lane 0 for 16 different
+// photos side by side); here a lane's position (component, block, coefficient) is plain data, block changes are a few predicated
+// integer instructions, and the wave runs max-over-lanes of the TOTAL symbol count.
+SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* bytes, const Huff* tabs6, int16_t* coefs) {
     BitReader br;
     br.init(bytes + sg.byte_off, bytes + im.scan_off + im.scan_len);
-    int pred0 = 0, pred1 = 0, pred2 = 0;
     const int ncomp = im.ncomp, hs = im.hs, vs = im.vs, mcux = im.mcux;
-    int16_t* c0 = coefs + im.coef_off[0];
-    int16_t* c1 = coefs + im.coef_off[1];
-    int16_t* c2 = coefs + im.coef_off[2];
+    const int nb0 = hs * vs;                                   // luma blocks per MCU (chroma: one each)
+    int16_t* const c0 = coefs + im.coef_off[0];
+    int16_t* const c1 = coefs + im.coef_off[1];
+    int16_t* const c2 = coefs + im.coef_off[2];
     const int bx0 = im.blocks_x[0], bx1 = im.blocks_x[1], bx2 = im.blocks_x[2];
-    const int mcu_end = sg.mcu_first + sg.mcu_count;
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int mcu_left = sg.mcu_count;
     int my = sg.mcu_first / mcux, mx = sg.mcu_first - my * mcux;
-    for (int mcu = sg.mcu_first; mcu < mcu_end; ++mcu) {
-        decode_component(br, tabs6[0], tabs6[1], pred0, hs, vs, c0, bx0, my, mx, blk);
-        if (ncomp == 3) {
-            decode_component(br, tabs6[2], tabs6[3], pred1, 1, 1, c1, bx1, my, mx, blk);
-            decode_component(br, tabs6[4], tabs6[5], pred2, 1, 1, c2, bx2, my, mx, blk);
+    int c = 0, bi = 0, k = 0;                                  // component, block inside the MCU's component, coefficient index
+    int16_t* blk = c0 + ((size_t)(my * vs) * bx0 + mx * hs) * 64;
+    while (mcu_left > 0) {
+        int v;
+        const int sym = decode_symbol(br, tabs6[2 * c + (k != 0)], &v);
+        if (k == 0) {                                          // DC: the symbol is the magnitude category, v the difference
+            const int p = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + v;
+            if (c == 0) pred0 = p; else if (c == 1) pred1 = p; else pred2 = p;
+            blk[0] = (int16_t)p;
+            k = 1;
+        } else {
+            const int r = sym >> 4;
+            if ((sym & 15) == 0) {
+                k = (r == 15) ? k + 16 : 64;                   // ZRL : EOB
+            } else {
+                k += r;
+                if (k <= 63) blk[k] = (int16_t)v;
+                ++k;
+            }
         }
-        if (++mx == mcux) { mx = 0; ++my; }
+        if (k >= 64) {                                         // next block: inside the component, next component, next MCU
+            k = 0;
+            ++bi;
+            if (bi >= (c == 0 ? nb0 : 1)) {
+                bi = 0;
+                ++c;
+                if (c >= ncomp) {
+                    c = 0;
+                    --mcu_left;
+                    if (++mx == mcux) { mx = 0; ++my; }
+                }
+            }
+            if (c == 0) {
+                const int by = hs == 2 ? bi >> 1 : bi, bx = hs == 2 ? bi & 1 : 0;
+                blk = c0 + ((size_t)(my * vs + by) * bx0 + (mx * hs + bx)) * 64;
+            } else {
+                blk = (c == 1 ? c1 : c2) + ((size_t)my * (c == 1 ? bx1 : bx2) + mx) * 64;
+            }
+        }
     }
     return 0;
 }

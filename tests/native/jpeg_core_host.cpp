@@ -10,8 +10,7 @@ using namespace spnjpeg;
 extern "C" int jpeg_core_decode_host(const uint8_t* bytes, const Image* images, int n_images, const Segment* segs, int n_segs,
                                      const Huff* huff, const uint16_t* qtabs, int16_t* coefs, size_t coef_elems, uint8_t* planes,
                                      uint8_t* rgb) {
-    std::memset(coefs, 0x5A, coef_elems * sizeof(int16_t));          // poison: decode_segment must write every block whole
-    alignas(8) int16_t blk[64];
+    std::memset(coefs, 0, coef_elems * sizeof(int16_t));             // the kernels' zero fill
     for (int s = 0; s < n_segs; ++s) {
         const Image& im = images[segs[s].image];
         Huff tabs6[6];                                                 // the kernel copies the same six tables into a lane's LDS slots
@@ -19,7 +18,7 @@ extern "C" int jpeg_core_decode_host(const uint8_t* bytes, const Image* images, 
             tabs6[2 * c] = huff[im.dc_tab[c]];
             tabs6[2 * c + 1] = huff[im.ac_tab[c]];
         }
-        decode_segment(im, segs[s], bytes, tabs6, coefs, blk);
+        decode_segment(im, segs[s], bytes, tabs6, coefs);
     }
     for (int i = 0; i < n_images; ++i) {
         const Image& im = images[i];

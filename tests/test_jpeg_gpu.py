@@ -155,7 +155,7 @@ def test_bank_builders_decode_on_the_gpu(golden_dir, tmp_path, monkeypatch):
     model.extract_bank_features(Train(), bank_path=None)
     refer_gpu, target_gpu = model.refer_bank.clone(), model.target_bank.clone()
     feats_gpu, names = extract_index_features(Classic(), model)
-    assert calls == [10, 8], calls          # ONE decode call per chunk: 12 image fields minus the PNG's two, 9 files minus the PNG
+    assert calls == [11, 8], calls          # ONE decode call per chunk: 12 image fields minus the one PNG field, 9 files minus the PNG
     monkeypatch.setenv("SPN_GPU_JPEG", "0")
     model.extract_bank_features(Train(), bank_path=None)
     feats_host, names2 = extract_index_features(Classic(), model)
