@@ -594,25 +594,34 @@ def main():
 
     trainer.pack = False
     # N > 1: the other bank mode, measured briefly with the same barrier / max-over-ranks protocol (not the headline)
+    def guarded(fn):
+        """An extra measurement must never cost the headline: a failure (the same on every rank: the code path is) is reported in
+        the JSON line instead of raised."""
+        try:
+            return fn()
+        except Exception as exc:          # noqa: BLE001
+            return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     alt = None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
-        other = "sharded" if args.bank_mode == "replicated" else "replicated"
-        tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other, pack=False)
-        tr2.set_banks(refer, target)
-        for _ in range(max(2, args.warmup)):
-            tr2.step(ids, ridx, labels, ids_host=ids_host)
-        barrier()
-        t0 = time.perf_counter()
-        n_alt = max(5, args.steps // 2)
-        for _ in range(n_alt):
-            tr2.step(ids, ridx, labels, ids_host=ids_host)
-        barrier()
-        dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(dta, op=dist.ReduceOp.MAX)
-        alt = {"bank_mode": other, "value": round(B_global * n_alt / dta.item(), 1), "unit": "triplets/sec",
-               "ms_per_step": round(dta.item() / n_alt * 1e3, 3), "steps": n_alt}
-        del tr2
+        def measure_alt():
+            other = "sharded" if args.bank_mode == "replicated" else "replicated"
+            tr2 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=other, pack=False)
+            tr2.set_banks(refer, target)
+            for _ in range(max(2, args.warmup)):
+                tr2.step(ids, ridx, labels, ids_host=ids_host)
+            barrier()
+            t0 = time.perf_counter()
+            n_alt = max(5, args.steps // 2)
+            for _ in range(n_alt):
+                tr2.step(ids, ridx, labels, ids_host=ids_host)
+            barrier()
+            dta = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(dta, op=dist.ReduceOp.MAX)
+            return {"bank_mode": other, "value": round(B_global * n_alt / dta.item(), 1), "unit": "triplets/sec",
+                    "ms_per_step": round(dta.item() / n_alt * 1e3, 3), "steps": n_alt}
+        alt = guarded(measure_alt)
 
     # N > 1: two more brief measurements with the same protocol, so that the first multi-GPU run settles what DESIGN.md section 6
     # only predicts - (a) STRONG scaling: config 3's B_global = 256 split over the ranks (256 / N per GPU; SURVEY 8d asks for
@@ -633,7 +642,7 @@ def main():
                 dist.all_reduce(d_, op=dist.ReduceOp.MAX)
             return {"value": round(bglob * n_ / d_.item(), 1), "unit": "triplets/sec", "ms_per_step": round(d_.item() / n_ * 1e3, 3),
                     "steps": n_}
-        if 256 % world == 0 and 256 // world >= 8:
+        def measure_strong():
             bs = 256 // world
             ids_s = synthetic.token_ids(256, seed=1)
             ridx_s, lab_s = synthetic.triplet_indices(256, args.bank, seed=4)
@@ -641,21 +650,24 @@ def main():
             tr3 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False)
             tr3.set_banks(refer, target)
             host_s = ids_s[sl_s].contiguous() if ids_host is not None else None
-            strong = brief(tr3, ids_s[sl_s].to(dev), ridx_s[sl_s].to(dev), lab_s[sl_s].to(dev), host_s, 256)
-            strong.update(scaling="strong", global_batch=256, batch_per_gpu=bs, bank_mode=args.bank_mode)
-            del tr3
-        tr4 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, grad_comm_dtype="bf16")
-        tr4.set_banks(refer, target)
-        comm16 = brief(tr4, ids, ridx, labels, ids_host, B_global)
-        comm16.update(grad_comm_dtype="bf16", note="weak-scaling shape; dense gradient buckets cross the links as bf16 "
-                                                   "(all-to-all, fp32 sum in rank order, all-gather); headline uses fp32 all-reduce")
-        del tr4
-        tr5 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, grad_comm_algo="direct")
-        tr5.set_banks(refer, target)
-        comm_direct = brief(tr5, ids, ridx, labels, ids_host, B_global)
-        comm_direct.update(grad_comm_algo="direct", note="weak-scaling shape; fp32 buckets through all-to-all + rank-order sum + "
-                           "all-gather (every xGMI link at once) instead of RCCL's all-reduce")
-        del tr5
+            r = brief(tr3, ids_s[sl_s].to(dev), ridx_s[sl_s].to(dev), lab_s[sl_s].to(dev), host_s, 256)
+            r.update(scaling="strong", global_batch=256, batch_per_gpu=bs, bank_mode=args.bank_mode)
+            return r
+
+        def measure_comm(**kw):
+            tr4 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, **kw)
+            tr4.set_banks(refer, target)
+            r = brief(tr4, ids, ridx, labels, ids_host, B_global)
+            r.update(kw)
+            return r
+        if 256 % world == 0 and 256 // world >= 8:
+            strong = guarded(measure_strong)
+        comm16 = guarded(lambda: measure_comm(grad_comm_dtype="bf16"))
+        comm16["note"] = ("weak-scaling shape; dense gradient buckets cross the links as bf16 (all-to-all, fp32 sum in rank order, "
+                          "all-gather); headline uses fp32 all-reduce")
+        comm_direct = guarded(lambda: measure_comm(grad_comm_algo="direct"))
+        comm_direct["note"] = ("weak-scaling shape; fp32 buckets through all-to-all + rank-order sum + all-gather (every xGMI link at "
+                               "once) instead of RCCL's all-reduce")
 
     if rank == 0:
         per_kernel = {}
