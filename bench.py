@@ -626,7 +626,7 @@ def main():
     # N > 1: two more brief measurements with the same protocol, so that the first multi-GPU run settles what DESIGN.md section 6
     # only predicts - (a) STRONG scaling: config 3's B_global = 256 split over the ranks (256 / N per GPU; SURVEY 8d asks for
     # both regimes), (b) the gradient buckets exchanged as bf16 (all-to-all + fp32 rank-order sum + all-gather) at the weak shape
-    strong, comm16, comm_direct = None, None, None
+    strong, comm16, comm_direct, collectives = None, None, None, None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
         def brief(tr, ids_, ridx_, labels_, host_, bglob):
             for _ in range(max(2, args.warmup)):
@@ -665,6 +665,57 @@ def main():
         comm16 = guarded(lambda: measure_comm(grad_comm_dtype="bf16"))
         comm16["note"] = ("weak-scaling shape; dense gradient buckets cross the links as bf16 (all-to-all, fp32 sum in rank order, "
                           "all-gather); headline uses fp32 all-reduce")
+        def measure_collectives():
+            """achieved all-reduce bandwidth and the overlap of the gradient exchange with backward.  (1) the dense
+            gradient buckets alone, in the trainer's own bucket pattern, nothing else on the device; (2) the weak-shape step
+            with the bucket exchange switched off (same kernels, replicas drift - measurement only); overlap = the share of (1)
+            that the headline step hides: 1 - (step - step_without_exchange) / exchange_alone."""
+            tr6 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False)
+            spans = tr6.tower.layer_spans()
+            tok = tr6.tower.vocab * tr6.tower.width if ids_host is not None else 0        # rows exchanged sparsely in the step
+            elems = sum(e - max(s_, tok) for s_, e in spans if e > tok)
+
+            def exchange():
+                for s_, e in spans:
+                    tr6.reducer.on_span_ready(max(s_, tok), e) if e > max(s_, tok) else None
+                tr6.reducer.finish()
+            for _ in range(2):
+                exchange()
+            barrier()
+            t0_ = time.perf_counter()
+            n_ = 5
+            for _ in range(n_):
+                exchange()
+            barrier()
+            d_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+            t_ex = d_.item() / n_
+            q_local = torch.zeros(B, D, dtype=torch.bfloat16, device=dev)
+            q_all = torch.empty(B_global, D, dtype=torch.bfloat16, device=dev)
+            for _ in range(3):
+                dist.all_gather_into_tensor(q_all, q_local)
+            barrier()
+            t0_ = time.perf_counter()
+            for _ in range(20):
+                dist.all_gather_into_tensor(q_all, q_local)
+            barrier()
+            t_ag = (time.perf_counter() - t0_) / 20
+            del tr6
+            nocomm = measure_comm(grad_comm_algo="none")
+            bytes_ = elems * 4
+            out_ = {"dense_gradient_bytes": bytes_, "exchange_alone_ms": round(t_ex * 1e3, 3),
+                    "allreduce_busbw_GBps": round(bytes_ * 2 * (world - 1) / max(world, 1) / t_ex / 1e9, 1) if world > 1 else None,
+                    "allgather_queries_us": round(t_ag * 1e6, 1), "allgather_queries_bytes": B_global * D * 2,
+                    "step_without_exchange_ms": nocomm.get("ms_per_step"), "headline_step_ms": round(dt * 1e3 / args.steps, 3),
+                    "xgmi_links_per_gpu": 7,
+                    "note": "busbw = bytes x 2 (G - 1) / G / time (the all-reduce convention); per link: busbw / 7 when every link "
+                            "carries an equal share"}
+            if nocomm.get("ms_per_step") and t_ex > 0:
+                hidden = 1.0 - (out_["headline_step_ms"] - nocomm["ms_per_step"]) / (t_ex * 1e3)
+                out_["overlap_fraction"] = round(max(0.0, min(1.0, hidden)), 3)
+            return out_
+        collectives = guarded(measure_collectives)
         comm_direct = guarded(lambda: measure_comm(grad_comm_algo="direct"))
         comm_direct["note"] = ("weak-scaling shape; fp32 buckets through all-to-all + rank-order sum + all-gather (every xGMI link at "
                                "once) instead of RCCL's all-reduce")
@@ -757,6 +808,8 @@ def main():
             out["grad_comm_bf16"] = comm16
         if comm_direct:
             out["grad_comm_direct_fp32"] = comm_direct
+        if collectives:
+            out["collectives"] = collectives
         if world == 1 and not args.no_recall:     # checker legs run at N = 1 only: the other ranks would sit in the exit barrier
             rec = recall_block(args, sd, model, dev)
             if rec:

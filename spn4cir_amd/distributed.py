@@ -336,7 +336,8 @@ class GradBucketReducer:
         # rank exchanges one S / G chunk with every other rank over its own xGMI link, all links at once (SURVEY section 5's
         # one-shot reduce-scatter + all-gather, from RCCL's point-to-point collectives).  bf16 implies direct.
         algo = algo or ("direct" if comm_dtype == "bf16" else "ring")
-        if algo not in ("ring", "direct") or (comm_dtype == "bf16" and algo != "direct"):
+        # algo "none": MEASUREMENT ONLY (bench.py's overlap figure) - buckets are not exchanged at all, the replicas drift apart
+        if algo not in ("ring", "direct", "none") or (comm_dtype == "bf16" and algo != "direct"):
             raise ValueError((comm_dtype, algo))
         self.algo = algo
         self.flat, self.group, self.bucket_elems = flat_grads, group, bucket_elems
@@ -420,7 +421,7 @@ class GradBucketReducer:
         self._pending = []
 
     def on_span_ready(self, start, end):
-        if _skip(self.world):
+        if _skip(self.world) or self.algo == "none":
             return
         self._pending.append((start, end))
         if sum(e - s for s, e in self._pending) >= self.bucket_elems:

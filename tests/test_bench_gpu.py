@@ -37,6 +37,11 @@ def test_bench_two_ranks_shared_gpu(mode):
     assert abs(st["value"] - 256 / (st["ms_per_step"] * 1e-3)) < 1e-2 * st["value"]
     assert d["grad_comm_bf16"]["grad_comm_dtype"] == "bf16" and d["grad_comm_bf16"]["value"] > 0
     assert d["grad_comm_direct_fp32"]["grad_comm_algo"] == "direct" and d["grad_comm_direct_fp32"]["value"] > 0
+    # achieved all-reduce bandwidth and overlap of the gradient exchange with backward (meaningless on a shared GPU: shape only)
+    c = d["collectives"]
+    assert "error" not in c, c
+    assert c["exchange_alone_ms"] > 0 and c["allreduce_busbw_GBps"] > 0 and c["allgather_queries_us"] > 0
+    assert c["step_without_exchange_ms"] > 0 and 0.0 <= c["overlap_fraction"] <= 1.0 and c["dense_gradient_bytes"] > 0
     assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
 
 
