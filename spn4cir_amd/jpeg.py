@@ -35,6 +35,7 @@ def parse_header(data):
     if n < 4 or b[0] != 0xFF or b[1] != 0xD8:
         raise Unsupported("no SOI marker")
     pos, qt, dc, ac, ri, frame = 2, {}, {}, {}, 0, None
+    saw_jfif, adobe_transform = False, None
     while True:
         if pos + 4 > n or b[pos] != 0xFF:
             raise Unsupported("marker expected")
@@ -78,6 +79,10 @@ def parse_header(data):
                 s += 17 + ns
         elif m == 0xDD:
             ri = _be16(b, s)
+        elif m == 0xE0 and e - s >= 5 and bytes(b[s:s + 5]) == b"JFIF\0":
+            saw_jfif = True
+        elif m == 0xEE and e - s >= 12 and bytes(b[s:s + 5]) == b"Adobe":
+            adobe_transform = b[s + 11]
         elif m == 0xDA:
             if frame is None:
                 raise Unsupported("scan before frame header")
@@ -102,9 +107,12 @@ def parse_header(data):
             raise Unsupported("chroma sampling factors other than 1x1")
         if (comps[0][1], comps[0][2]) not in ((1, 1), (2, 1), (2, 2)):
             raise Unsupported("luma sampling %dx%d" % (comps[0][1], comps[0][2]))
-        # an Adobe APP14 transform flag 0 (RGB stored as is) or non-JFIF component ids (e.g. 'R','G','B') are not YCbCr
-        if [c[0] for c in comps] == [0x52, 0x47, 0x42]:
-            raise Unsupported("RGB-coded JPEG")
+        # colour space as the IJG library decides it (jdapimin.c default_decompress_parms): JFIF -> YCbCr; else an Adobe marker's
+        # transform flag (0 = the three components are RGB as stored); else component ids 'R','G','B' mean RGB
+        if not saw_jfif:
+            if (adobe_transform is not None and adobe_transform != 1) or \
+                    (adobe_transform is None and [c[0] for c in comps] == [0x52, 0x47, 0x42]):
+                raise Unsupported("RGB-coded JPEG")
     elif len(comps) == 1:
         comps[0][1] = comps[0][2] = 1            # a single-component scan is never interleaved
     else:

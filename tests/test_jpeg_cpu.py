@@ -106,6 +106,10 @@ def test_out_of_scope_files_are_refused():
     buf = io.BytesIO(); img.convert("CMYK").save(buf, "JPEG"); cases["cmyk"] = buf.getvalue()
     buf = io.BytesIO(); img.save(buf, "JPEG", subsampling="4:1:1") if False else img.save(buf, "PNG"); cases["png"] = buf.getvalue()
     cases["truncated"] = cases["progressive"][:30]
+    try:                                                                      # RGB stored as is (Adobe transform 0 / no JFIF marker)
+        buf = io.BytesIO(); img.save(buf, "JPEG", keep_rgb=True); cases["rgb"] = buf.getvalue()
+    except TypeError:
+        pass
     for name, data in cases.items():
         with pytest.raises(jpeg.Unsupported):
             jpeg.parse_header(data)
