@@ -258,6 +258,45 @@ def blip_config4_block(args, dev):
     return out
 
 
+def jpeg_decode_block(dev):
+    """SURVEY 8f-3 (image decode in front of the frozen image tower): batched GPU decode of FashionIQ-sized baseline JPEGs
+    (spn_jpeg_decode_batch) beside Pillow on one host core; pixels compared with Pillow's on the spot."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from spn4cir_amd import jpeg
+    rng = np.random.default_rng(0)
+    files = []
+    for _ in range(8):
+        h, w = 600, 400
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.zeros((h, w, 3))
+        for _k in range(10):
+            cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(30, 200)
+            img += np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * r * r))[..., None] * rng.uniform(0, 255, 3)
+        img = img / img.max() * 255 + rng.normal(0, 3, (h, w, 3))
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=90)
+        files.append(buf.getvalue())
+    t0 = time.perf_counter()
+    ref = [np.asarray(Image.open(io.BytesIO(f)).convert("RGB")) for f in files]
+    pil_rate = len(files) / (time.perf_counter() - t0)
+    out = {"file_kb": round(sum(len(f) for f in files) / len(files) / 1024, 1), "image": "400 x 600, 4:2:0, quality 90",
+           "pillow_one_host_core_images_per_s": round(pil_rate, 1)}
+    jpeg.decode_batch(files, dev)
+    torch.cuda.synchronize()
+    for n in (256, 1024):
+        fl = (files * (n // len(files)))[:n]
+        t0 = time.perf_counter()
+        dec, fb = jpeg.decode_batch(fl, dev)
+        torch.cuda.synchronize()
+        out[f"gpu_images_per_s_batch_{n}"] = round(n / (time.perf_counter() - t0), 1)
+    out["bit_identical_to_pillow"] = bool(not fb and all(np.array_equal(dec[i].cpu().numpy(), ref[i % len(files)]) for i in range(16)))
+    out["note"] = ("whole call: host marker parsing + upload + Huffman (a lane per file) + IDCT + upsampling / colour; used by the bank "
+                   "builders and extract_index_features in 1 024-item chunks")
+    return out
+
+
 def _fp8_min_b():
     from spn4cir_amd import ops
     return ops.fp8_image_min_b()
@@ -822,6 +861,7 @@ def main():
             out["blip_config4"] = guarded(lambda: blip_config4_block(args, dev))       # extras never cost the headline line
             torch.cuda.empty_cache()
             out["fp8_config5"] = guarded(lambda: fp8_config5_block(args, sd, CIRPlus, dev))
+            out["jpeg_decode"] = guarded(lambda: jpeg_decode_block(dev))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, sd, target, refer)
             out["cpu_baseline"]["config1"] = cpu_baseline_config1(args)
