@@ -11,7 +11,6 @@ Host work per file: one pass over the markers (a few hundred bytes of tables), d
 upsampling and colour conversion run on the device.  Scope (everything else raises `Unsupported`, and `decode_batch` then decodes
 that file with Pillow on the host): 8-bit baseline / extended-sequential Huffman JPEG, one interleaved scan, grayscale or YCbCr with
 1x1 chroma and 1x1 / 2x1 / 2x2 luma sampling.  Restart intervals become independent work items (one lane each)."""
-import ctypes as C
 
 import numpy as np
 import torch
