@@ -84,33 +84,30 @@ struct BitReader {
     // byte by byte: FF 00 is a data byte 0xFF; any other FF xx is a marker - it ends the data: zero bits from there on, the
     // pointer stays on the marker (what the IJG decoder feeds after "premature end of data segment").
     SPN_JHD void fill() {
-        if (n > 32) return;
-        if (p + 4 <= end) {
-            const uint32_t w = ahead;                                      // byte order does not matter for the 0xFF test
-            if ((((~w) - 0x01010101u) & w & 0x80808080u) == 0) {
-                acc = (acc << 32) | be32(w);
-                n += 32;
-                p += 4;
-                ahead = (p + 4 <= end) ? load_raw32(p) : 0;
-                return;
-            }
-        }
-        while (n <= 56) {
-            unsigned b = 0;
-            if (p < end) {
-                b = *p;
-                if (b == 0xFF) {
-                    const unsigned nx = (p + 1 < end) ? p[1] : 0xD9u;
-                    if (nx == 0) p += 2;
-                    else b = 0;
-                } else {
-                    ++p;
+        const bool need = n <= 32;
+        const uint32_t w = ahead;                                          // byte order does not matter for the 0xFF test
+        const bool fast = need && (p + 4 <= end) && ((((~w) - 0x01010101u) & w & 0x80808080u) == 0);
+        acc = fast ? ((acc << 32) | be32(w)) : acc;                        // selects, not a branch: see decode_segment
+        n += fast ? 32 : 0;
+        p += fast ? 4 : 0;
+        if (need && !fast) {
+            while (n <= 56) {
+                unsigned b = 0;
+                if (p < end) {
+                    b = *p;
+                    if (b == 0xFF) {
+                        const unsigned nx = (p + 1 < end) ? p[1] : 0xD9u;
+                        if (nx == 0) p += 2;
+                        else b = 0;
+                    } else {
+                        ++p;
+                    }
                 }
+                acc = (acc << 8) | b;
+                n += 8;
             }
-            acc = (acc << 8) | b;
-            n += 8;
         }
-        ahead = (p + 4 <= end) ? load_raw32(p) : 0;
+        if (need) ahead = (p + 4 <= end) ? load_raw32(p) : 0;
     }
     SPN_JHD unsigned peek(int k) const { return (unsigned)((acc >> (n - k)) & ((1u << k) - 1u)); }
     SPN_JHD void skip(int k) { n -= k; }
@@ -141,11 +138,8 @@ SPN_JHD int decode_symbol(BitReader& br, const Huff& t, int* value) {
         }
     }
     const int s = sym & 15;
-    int v = 0;
-    if (s) {
-        v = (int)((w << len) >> (32 - s));
-        if (v < (1 << (s - 1))) v += 1 - (1 << s);
-    }
+    int v = (int)(((w << len) >> 1) >> (31 - s));                // s = 0: zero bits, v = 0 - no branch
+    v += (v < ((1 << s) >> 1)) ? 1 - (1 << s) : 0;
     *value = v;
     br.n -= len + s;
     return sym;
@@ -165,52 +159,51 @@ SPN_JHD int decode_segment(const Image& im, const Segment& sg, const uint8_t* by
     br.init(bytes + sg.byte_off, bytes + im.scan_off + im.scan_len);
     const int ncomp = im.ncomp, hs = im.hs, vs = im.vs, mcux = im.mcux;
     const int nb0 = hs * vs;                                   // luma blocks per MCU (chroma: one each)
-    int16_t* const c0 = coefs + im.coef_off[0];
-    int16_t* const c1 = coefs + im.coef_off[1];
-    int16_t* const c2 = coefs + im.coef_off[2];
-    const int bx0 = im.blocks_x[0], bx1 = im.blocks_x[1], bx2 = im.blocks_x[2];
+    const int stride0 = im.blocks_x[0] * 64;                   // elements per block row of the luma plane
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int mcu_left = sg.mcu_count;
-    int my = sg.mcu_first / mcux, mx = sg.mcu_first - my * mcux;
+    const int my0 = sg.mcu_first / mcux;
+    int mx = sg.mcu_first - my0 * mcux;
+    // first block of the current MCU in each component's coefficient plane; stepping to the next MCU is an addition (a luma MCU
+    // row is vs block rows: at the end of a row the pointer has advanced one block row by itself and skips vs - 1 more)
+    int16_t* mb0 = coefs + im.coef_off[0] + ((size_t)(my0 * vs) * im.blocks_x[0] + mx * hs) * 64;
+    int16_t* mb1 = coefs + im.coef_off[1] + ((size_t)my0 * im.blocks_x[1] + mx) * 64;
+    int16_t* mb2 = coefs + im.coef_off[2] + ((size_t)my0 * im.blocks_x[2] + mx) * 64;
+    const int row_skip0 = (vs - 1) * stride0;
     int c = 0, bi = 0, k = 0;                                  // component, block inside the MCU's component, coefficient index
-    int16_t* blk = c0 + ((size_t)(my * vs) * bx0 + mx * hs) * 64;
+    int16_t* blk = mb0;
+    // The body is written with selects instead of nested branches on purpose: every `if` of a divergent loop costs the wave a
+    // handful of exec-mask instructions whether or not a lane takes it, and instruction count is the price here (see decode_symbol).
     while (mcu_left > 0) {
         int v;
         const int sym = decode_symbol(br, tabs6[2 * c + (k != 0)], &v);
-        if (k == 0) {                                          // DC: the symbol is the magnitude category, v the difference
-            const int p = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + v;
-            if (c == 0) pred0 = p; else if (c == 1) pred1 = p; else pred2 = p;
-            blk[0] = (int16_t)p;
-            k = 1;
-        } else {
-            const int r = sym >> 4;
-            if ((sym & 15) == 0) {
-                k = (r == 15) ? k + 16 : 64;                   // ZRL : EOB
-            } else {
-                k += r;
-                if (k <= 63) blk[k] = (int16_t)v;
-                ++k;
-            }
-        }
-        if (k >= 64) {                                         // next block: inside the component, next component, next MCU
-            k = 0;
-            ++bi;
-            if (bi >= (c == 0 ? nb0 : 1)) {
-                bi = 0;
-                ++c;
-                if (c >= ncomp) {
-                    c = 0;
-                    --mcu_left;
-                    if (++mx == mcux) { mx = 0; ++my; }
-                }
-            }
-            if (c == 0) {
-                const int by = hs == 2 ? bi >> 1 : bi, bx = hs == 2 ? bi & 1 : 0;
-                blk = c0 + ((size_t)(my * vs + by) * bx0 + (mx * hs + bx)) * 64;
-            } else {
-                blk = (c == 1 ? c1 : c2) + ((size_t)my * (c == 1 ? bx1 : bx2) + mx) * 64;
-            }
-        }
+        const bool is_dc = k == 0;
+        const int r = sym >> 4, s = sym & 15;
+        const int pn = (c == 0 ? pred0 : (c == 1 ? pred1 : pred2)) + v;          // DC: the symbol is the category, v the difference
+        pred0 = (is_dc && c == 0) ? pn : pred0;
+        pred1 = (is_dc && c == 1) ? pn : pred1;
+        pred2 = (is_dc && c == 2) ? pn : pred2;
+        const int kk = is_dc ? 0 : k + r;                                           // AC: skip r zeros
+        if (is_dc || (s != 0 && kk <= 63)) blk[kk] = (int16_t)(is_dc ? pn : v);
+        const int kn = is_dc ? 1 : (s != 0 ? kk + 1 : (r == 15 ? k + 16 : 64));     // next index; ZRL : EOB
+        const bool adv = kn >= 64;                                                  // block finished
+        k = adv ? 0 : kn;
+        const int bi2 = bi + (adv ? 1 : 0);
+        const bool wb = bi2 >= (c == 0 ? nb0 : 1);                                  // component finished (only possible when adv)
+        bi = wb ? 0 : bi2;
+        const int cn = c + (wb ? 1 : 0);
+        const bool wc = cn >= ncomp;                                                // MCU finished
+        c = wc ? 0 : cn;
+        const int mxn = mx + (wc ? 1 : 0);
+        const bool wx = mxn == mcux;                                                // MCU row finished (only possible when wc)
+        mx = wx ? 0 : mxn;
+        mcu_left -= wc ? 1 : 0;
+        mb0 += (wc ? hs * 64 : 0) + (wx ? row_skip0 : 0);
+        mb1 += wc ? 64 : 0;
+        mb2 += wc ? 64 : 0;
+        const int by_off = (vs == 2 && (bi & 2)) ? stride0 : 0;                     // hs = vs = 2: block 2, 3 = second block row
+        const int bx_off = (hs == 2 && (bi & 1)) ? 64 : 0;
+        blk = c == 0 ? mb0 + by_off + bx_off : (c == 1 ? mb1 : mb2);
     }
     return 0;
 }
