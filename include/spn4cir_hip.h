@@ -517,6 +517,13 @@ int spn_avgpool_nhwc_bf16(const void* x, void* y, int B, int H, int W, int Cp, i
  * ff_w2[W,I] ff_b2 ff_ln_g ff_ln_b, [20] = layer size. */
 typedef struct {
     int B, L, S, W, H, layers, I, E, Dp, vocab, max_pos;
+    /* Packed text rows (0 = dense).  T > 0: only the T = sum of the caption lengths unmasked positions are materialised - a padded
+     * position influences neither the [ENC] feature nor any gradient, because its key is masked in every self-attention
+     * (med.py:686 extended_attention_mask) - and the `mask` argument of spn_fusion_fwd / spn_fusion_fwd_bank carries the prefix sums
+     * cu_seqlens int32 [B + 1] (cu[0] = 0, cu[B] = T; each length in 1..L; the tokenizer's right padding, blip.py:189-194) instead
+     * of the [B, L] mask.  ids stays the padded [B, L] array.  Needs L <= 128 and spn_fusion_packed_ok(cfg) != 0; activation and
+     * workspace sizes shrink with T (size them with T = 0 for a buffer that fits every batch of the shape). */
+    int T;
 } spn_fusion_cfg;
 
 typedef struct {
@@ -527,6 +534,9 @@ typedef struct {
 } spn_fusion_layout_t;
 
 int spn_fusion_layout(const spn_fusion_cfg* cfg, spn_fusion_layout_t* out);
+/* 1 when the shape supports packed text rows (cfg->T is ignored): head width 64, even head count, enc width a multiple of 128,
+ * S <= 640, L <= 128 - the absorbed cross-attention of csrc/xattn.hip, which addresses each sample's rows separately. */
+int spn_fusion_packed_ok(const spn_fusion_cfg* cfg);
 size_t spn_fusion_act_bytes(const spn_fusion_cfg* cfg);
 size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg);
 int spn_fusion_refresh_bf16(const spn_fusion_cfg* cfg, const float* params, void* weights_bf16, void* stream);

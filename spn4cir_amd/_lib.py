@@ -40,7 +40,7 @@ class VisionLayout(C.Structure):
 
 
 class FusionCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "L", "S", "W", "H", "layers", "I", "E", "Dp", "vocab", "max_pos")]
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "S", "W", "H", "layers", "I", "E", "Dp", "vocab", "max_pos", "T")]
 
 
 class FusionLayout(C.Structure):
@@ -159,6 +159,7 @@ _SIGS = {
     "spn_attnpool_attend_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
+    "spn_fusion_packed_ok": (i32, [C.POINTER(FusionCfg)]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_refresh_bf16": (i32, [C.POINTER(FusionCfg), vp, vp, vp]),

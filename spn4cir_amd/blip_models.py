@@ -285,7 +285,8 @@ class CIRPlus(nn.Module):
         ids = ids.to(self.device, torch.int32).clone()
         if self.enc_token_id is not None:
             ids[:, 0] = self.enc_token_id              # blip_cir.py:88
-        return ids.contiguous(), mask.to(self.device, torch.int32).contiguous()
+        # the mask stays where it came from: a host mask (the tokenizer's) lets the encoder drop the padded rows (FusionEncoder.forward)
+        return ids.contiguous(), mask.to(torch.int32).contiguous()
 
     def _fuse(self, r_image_embeds, text):
         ids, mask = self.tokenize(text)

@@ -498,7 +498,7 @@ static_assert(sizeof(spn_fusion_layout_t) == sizeof(FusionLayout), "spn_fusion_l
 static FusionCfg fc(const spn_fusion_cfg* c) {
     FusionCfg f;
     f.B = c->B; f.L = c->L; f.S = c->S; f.W = c->W; f.H = c->H; f.layers = c->layers; f.I = c->I; f.E = c->E;
-    f.Dp = c->Dp; f.vocab = c->vocab; f.max_pos = c->max_pos;
+    f.Dp = c->Dp; f.vocab = c->vocab; f.max_pos = c->max_pos; f.T = c->T;
     return f;
 }
 
@@ -508,6 +508,7 @@ int spn_fusion_layout(const spn_fusion_cfg* cfg, spn_fusion_layout_t* out) {
     return SPN_OK;
 }
 
+int spn_fusion_packed_ok(const spn_fusion_cfg* cfg) { return cfg ? fusion_packed_ok(fc(cfg)) : 0; }
 size_t spn_fusion_act_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_act_bytes(fc(cfg)) : 0; }
 size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_ws_bytes(fc(cfg)) : 0; }
 

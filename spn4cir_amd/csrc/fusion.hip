@@ -58,9 +58,24 @@ void fusion_layout(const FusionCfg& c, FusionLayout* t) {
     t->n_bf16 = t->bf16_proj_t + (int64_t)c.Dp * W;
 }
 
+// Cross-attention with the K/V projections absorbed into the query / output side (xattn.hip) whenever the shape allows it:
+// the activation and workspace carve-ups below depend on it, so it is a pure function of the configuration (+ SPN_XATTN_ABSORB).
+static bool fusion_absorb(const FusionCfg& c) { return xattn_absorb_ok(c.B, c.L, c.H, c.S, c.E, c.W); }
+// Text rows of the batch: B*L padded positions, or - packed (c.T > 0, the caller passes the prefix sums of the caption lengths
+// where the dense form takes the attention mask) - only the T unmasked ones.  A padded position influences neither the [ENC]
+// feature nor any gradient (its key is masked in every self-attention, med.py:686), so dropping the rows changes no result.
+static int fusion_rows(const FusionCfg& c) { return c.T > 0 ? c.T : c.B * c.L; }
+static size_t fusion_the(const FusionCfg& c) { return (size_t)fusion_rows(c) * c.H * c.E; }                // elements of [T, H, E]
+static size_t fusion_rsp(const FusionCfg& c) { return (size_t)fusion_rows(c) * c.H * xattn_sp(c.S); }      // elements of [T*H, SP]
+
+int fusion_packed_ok(const FusionCfg& c) { return c.L <= 128 && fusion_absorb(c) ? 1 : 0; }
+
 static int fusion_check(const FusionCfg& c) {
     if (c.B <= 0 || c.L <= 0 || c.S <= 0 || c.layers <= 0 || c.L > c.max_pos) return SPN_ERR_ARG;
     if (c.W % 64 || c.H * 64 != c.W || c.E % 64 || c.I % 64 || c.Dp % 64) return SPN_ERR_SHAPE;
+    if (c.T < 0 || (c.T > 0 && (c.T < c.B || (int64_t)c.T > (int64_t)c.B * c.L))) return SPN_ERR_ARG;
+    // packed rows: whole-head self-attention kernels (L <= 128) and the absorbed cross-attention (per-sample row ranges)
+    if (c.T > 0 && (c.L > 128 || !fusion_absorb(c))) return SPN_ERR_SHAPE;
     return SPN_OK;
 }
 
@@ -99,6 +114,7 @@ struct FusionLayerActs {
     float* x_in; bf16_t* xb_in;                 // layer input (previous LN output), fp32 + bf16
     bf16_t* qkv; float* lse1; bf16_t* ctx1; float* y1; float *mean1, *rstd1; float* x1; bf16_t* x1b;
     bf16_t* q2; bf16_t* kv2; float* lse2; bf16_t* ctx2; float* y2; float *mean2, *rstd2; float* x2; bf16_t* x2b;
+    bf16_t *qa, *pm, *oa;                       // absorbed cross-attention: Q' [T,H,E], P [B,R,SP], O' [T,H,E] (then kv2 = lse2 = null)
     bf16_t* pre; bf16_t* u; float* y3; float *mean3, *rstd3;
 };
 
@@ -106,6 +122,7 @@ struct FusionActs {
     float* key_bias;        // [B, L]   (1 - mask) * -10000
     int32_t* last;          // [B]      index of the last unmasked token (embedding backward)
     int32_t* zero_idx;      // [B]      zeros: row of the [ENC] token
+    int32_t *cu, *row_b, *row_l;   // packed: prefix sums [B+1] (cu[b] = the [ENC] row of sample b), sample / position of each row [T]
     bf16_t* enc_b;          // [B*S, E] bf16 copy of the image tokens
     float* emb;             // [T, W]   word + position (LN input)
     float *emb_mean, *emb_rstd;
@@ -116,19 +133,20 @@ struct FusionActs {
 };
 
 static size_t fusion_layer_act_bytes(const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W, I = c.I;
     size_t b = 0;
     b += fa(T * W * 4) + fa(T * W * 2);                                        // x_in, xb_in
     b += fa(T * 3 * W * 2) + fa((size_t)c.B * c.H * c.L * 4) + fa(T * W * 2);   // qkv, lse1, ctx1
     b += fa(T * W * 4) + 2 * fa(T * 4) + fa(T * W * 4) + fa(T * W * 2);         // y1, mean1, rstd1, x1, x1b
-    b += fa(T * W * 2) + fa(TS * 2 * W * 2) + fa((size_t)c.B * c.H * c.L * 4) + fa(T * W * 2);   // q2, kv2, lse2, ctx2
+    if (fusion_absorb(c)) b += fa(T * W * 2) + 2 * fa(fusion_the(c) * 2) + fa(fusion_rsp(c) * 2) + fa(T * W * 2);   // q2, qa, oa, pm, ctx2
+    else b += fa(T * W * 2) + fa(TS * 2 * W * 2) + fa((size_t)c.B * c.H * c.L * 4) + fa(T * W * 2);   // q2, kv2, lse2, ctx2
     b += fa(T * W * 4) + 2 * fa(T * 4) + fa(T * W * 4) + fa(T * W * 2);         // y2, mean2, rstd2, x2, x2b
     b += 2 * fa(T * I * 2) + fa(T * W * 4) + 2 * fa(T * 4);                     // pre, u, y3, mean3, rstd3
     return b;
 }
 
 static FusionLayerActs fusion_layer_acts_at(char* base, const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W, I = c.I;
     char* p = base;
     auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
     FusionLayerActs A;
@@ -136,7 +154,13 @@ static FusionLayerActs fusion_layer_acts_at(char* base, const FusionCfg& c) {
     A.qkv = (bf16_t*)take(T * 3 * W * 2); A.lse1 = (float*)take((size_t)c.B * c.H * c.L * 4); A.ctx1 = (bf16_t*)take(T * W * 2);
     A.y1 = (float*)take(T * W * 4); A.mean1 = (float*)take(T * 4); A.rstd1 = (float*)take(T * 4);
     A.x1 = (float*)take(T * W * 4); A.x1b = (bf16_t*)take(T * W * 2);
-    A.q2 = (bf16_t*)take(T * W * 2); A.kv2 = (bf16_t*)take(TS * 2 * W * 2); A.lse2 = (float*)take((size_t)c.B * c.H * c.L * 4);
+    A.q2 = (bf16_t*)take(T * W * 2);
+    A.kv2 = nullptr; A.lse2 = nullptr; A.qa = A.pm = A.oa = nullptr;
+    if (fusion_absorb(c)) {
+        A.qa = (bf16_t*)take(fusion_the(c) * 2); A.oa = (bf16_t*)take(fusion_the(c) * 2); A.pm = (bf16_t*)take(fusion_rsp(c) * 2);
+    } else {
+        A.kv2 = (bf16_t*)take(TS * 2 * W * 2); A.lse2 = (float*)take((size_t)c.B * c.H * c.L * 4);
+    }
     A.ctx2 = (bf16_t*)take(T * W * 2);
     A.y2 = (float*)take(T * W * 4); A.mean2 = (float*)take(T * 4); A.rstd2 = (float*)take(T * 4);
     A.x2 = (float*)take(T * W * 4); A.x2b = (bf16_t*)take(T * W * 2);
@@ -146,21 +170,26 @@ static FusionLayerActs fusion_layer_acts_at(char* base, const FusionCfg& c) {
 }
 
 size_t fusion_act_bytes(const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W;
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W;
     size_t b = fa(T * 4) + 2 * fa((size_t)c.B * 4) + fa(TS * c.E * 2) + fa(T * W * 4) + 2 * fa(T * 4);
+    if (c.T > 0) b += fa((size_t)(c.B + 1) * 4) + 2 * fa(T * 4);
     b += fusion_layer_act_bytes(c) * c.layers;
     b += fa(T * W * 4) + fa(T * W * 2) + fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2) + fa((size_t)c.B * c.Dp * 4);
     return b;
 }
 
 static FusionActs fusion_acts_at(char* base, const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W;
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W;
     char* p = base;
     auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
     FusionActs A;
     A.key_bias = (float*)take(T * 4);
     A.last = (int32_t*)take((size_t)c.B * 4);
     A.zero_idx = (int32_t*)take((size_t)c.B * 4);
+    A.cu = A.row_b = A.row_l = nullptr;
+    if (c.T > 0) {
+        A.cu = (int32_t*)take((size_t)(c.B + 1) * 4); A.row_b = (int32_t*)take(T * 4); A.row_l = (int32_t*)take(T * 4);
+    }
     A.enc_b = (bf16_t*)take(TS * c.E * 2);
     A.emb = (float*)take(T * W * 4);
     A.emb_mean = (float*)take(T * 4);
@@ -204,11 +233,11 @@ static int nt_resid(const bf16_t* A, const bf16_t* Bw, int M, int N, int K, cons
     return gemm_nt(A, Bw, M, N, K, K, K, GEMM_RESID, e, st);
 }
 
-static AttnArgs self_attn_args(const FusionCfg& c, const FusionLayerActs& A, const float* key_bias) {
+static AttnArgs self_attn_args(const FusionCfg& c, const FusionLayerActs& A, const float* key_bias, const int32_t* cu) {
     AttnArgs a;
     a.q = A.qkv; a.k = A.qkv + c.W; a.v = A.qkv + 2 * c.W;
     a.ldq = a.ldk = a.ldv = 3 * c.W;
-    a.o = A.ctx1; a.ldo = c.W; a.lse = A.lse1; a.key_bias = key_bias;
+    a.o = A.ctx1; a.ldo = c.W; a.lse = A.lse1; a.key_bias = cu ? nullptr : key_bias; a.cu = cu;
     a.B = c.B; a.H = c.H; a.Lq = c.L; a.Lk = c.L; a.causal = 0; a.scale = 0.125f;
     return a;
 }
@@ -229,15 +258,23 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     FusionLayout t;
     fusion_layout(c, &t);
     FusionActs A = fusion_acts_at(acts, c);
-    const int T = c.B * c.L, TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
-    hipLaunchKernelGGL(fusion_mask_kernel, dim3((c.B + 63) / 64), dim3(64), 0, st, mask, A.key_bias, A.last, A.zero_idx, c.B,
-                       c.L);
-    SPN_CHECK_LAUNCH();
+    const int T = fusion_rows(c), TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
+    const bool absorb = fusion_absorb(c);
+    const bool packed = c.T > 0;
+    if (packed) {
+        if (!mask) return SPN_ERR_ARG;                   // packed: the mask argument carries cu_seqlens int32 [B + 1]
+        SPN_TRYF(build_row_map(mask, A.row_b, A.row_l, A.last, c.B, st, A.cu));
+    } else {
+        hipLaunchKernelGGL(fusion_mask_kernel, dim3((c.B + 63) / 64), dim3(64), 0, st, mask, A.key_bias, A.last, A.zero_idx, c.B,
+                           c.L);
+        SPN_CHECK_LAUNCH();
+    }
     // image tokens of the batch as the bf16 A operand of the K/V projections: cast of a caller-gathered fp32 block, or gathered
     // here from a device-resident bf16 token bank (row = one image's S x E tokens; blip4cir/models.py:97-100)
     if (token_bank) SPN_TRYF(gather_bank_rows_bf16(token_bank, token_idx, bank_rows, A.enc_b, c.B, (size_t)c.S * E, st));
     else SPN_TRYF(cast_f32_bf16(enc, A.enc_b, (size_t)TS * E, st));
-    SPN_TRYF(embed_fwd(ids, params + t.word, params + t.pos, A.emb, c.B, c.L, W, c.vocab, st));
+    if (packed) SPN_TRYF(embed_fwd_packed(ids, A.row_b, A.row_l, params + t.word, params + t.pos, A.emb, T, c.L, W, c.vocab, st));
+    else SPN_TRYF(embed_fwd(ids, params + t.word, params + t.pos, A.emb, c.B, c.L, W, c.vocab, st));
     FusionLayerActs first = fusion_layer_acts_at(A.layers, c);
     SPN_TRYF(layernorm_fwd(A.emb, params + t.emb_ln_g, params + t.emb_ln_b, first.xb_in, first.x_in, A.emb_mean, A.emb_rstd, T,
                            W, 1e-12f, st));
@@ -255,13 +292,21 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         auto Bw = [&](int i) { return b + t.bf16_off[i]; };
         // self-attention (med.py BertSelfAttention + BertSelfOutput)
         SPN_TRYF(nt(a.xb_in, Bw(BO_SA_WQKV), T, 3 * W, W, P(LO_SA_BQKV), a.qkv, nullptr, st));
-        SPN_TRYF(attention_fwd(self_attn_args(c, a, A.key_bias), st));
+        SPN_TRYF(attention_fwd(self_attn_args(c, a, A.key_bias, A.cu), st));
         SPN_TRYF(nt_resid(a.ctx1, Bw(BO_SA_WO), T, W, W, P(LO_SA_BO), a.x_in, a.y1, st));
         SPN_TRYF(layernorm_fwd(a.y1, P(LO_SA_LNG), P(LO_SA_LNB), a.x1b, a.x1, a.mean1, a.rstd1, T, W, 1e-12f, st));
         // cross-attention over the image tokens
         SPN_TRYF(nt(a.x1b, Bw(BO_CA_WQ), T, W, W, P(LO_CA_BQ), a.q2, nullptr, st));
-        SPN_TRYF(nt(A.enc_b, Bw(BO_CA_WKV), TS, 2 * W, E, P(LO_CA_BKV), a.kv2, nullptr, st));
-        SPN_TRYF(attention_fwd(cross_attn_args(c, a), st));
+        if (absorb) {
+            // scores = (0.125 q_h Wk_h) X^T, ctx_h = (softmax X) Wv_h^T + bv_h: K and V are never formed (xattn.hip)
+            SPN_TRYF(xattn_head_expand(a.q2, W, Bw(BO_CA_WKV_T), 2 * W, 0, a.qa, T, c.H, E, 0.125f, st));
+            SPN_TRYF(xattn_scores_softmax(a.qa, A.enc_b, a.pm, c.B, c.L * c.H, c.S, E, st, A.cu, c.H));
+            SPN_TRYF(xattn_apply(a.pm, A.enc_b, a.oa, c.B, c.L * c.H, c.S, E, st, A.cu, c.H));
+            SPN_TRYF(xattn_head_contract(a.oa, Bw(BO_CA_WKV), W, P(LO_CA_BKV), a.ctx2, W, T, c.H, E, 1.0f, st));
+        } else {
+            SPN_TRYF(nt(A.enc_b, Bw(BO_CA_WKV), TS, 2 * W, E, P(LO_CA_BKV), a.kv2, nullptr, st));
+            SPN_TRYF(attention_fwd(cross_attn_args(c, a), st));
+        }
         SPN_TRYF(nt_resid(a.ctx2, Bw(BO_CA_WO), T, W, W, P(LO_CA_BO), a.x1, a.y2, st));
         SPN_TRYF(layernorm_fwd(a.y2, P(LO_CA_LNG), P(LO_CA_LNB), a.x2b, a.x2, a.mean2, a.rstd2, T, W, 1e-12f, st));
         // feed-forward (BertIntermediate exact GELU + BertOutput)
@@ -270,7 +315,8 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         SPN_TRYF(layernorm_fwd(a.y3, P(LO_FF_LNG), P(LO_FF_LNB), xb_out, x_out, a.mean3, a.rstd3, T, W, 1e-12f, st));
     }
     // text_proj of the [ENC] position (blip_cir.py:98); the L2-normalise is spn_combine_l2norm_fwd
-    SPN_TRYF(gather_rows_f32(A.x_final, A.zero_idx, A.h0, c.B, c.L, W, st));
+    if (packed) SPN_TRYF(gather_rows_abs(A.x_final, A.cu, A.h0, c.B, W, st));
+    else SPN_TRYF(gather_rows_f32(A.x_final, A.zero_idx, A.h0, c.B, c.L, W, st));
     SPN_TRYF(cast_f32_bf16(A.h0, A.h0b, (size_t)c.B * W, st));
     SPN_TRYF(nt(A.h0b, wb + t.bf16_proj, c.B, c.Dp, W, params + t.proj_b, nullptr, proj_out, st));
     return SPN_OK;
@@ -283,8 +329,10 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
 // the text rows as reduction (36 problems per launch), and the cross-attention K/V projection of all layers
 // (reduction over the B*S image tokens).  SPN_TN_GROUP=0: one split-K launch per product as before.
 static size_t fusion_defer_layer_bytes(const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
-    return 4 * fa(T * W * 2) + fa(T * I * 2) + fa(T * 3 * W * 2) + fa(TS * 2 * W * 2) +
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    // the K/V-projection operand: dkv2 [B*S, 2W], or - absorbed form - dQ' [T, H, E] and the cross-attention's dctx [T, W]
+    const size_t kvop = fusion_absorb(c) ? fa(fusion_the(c) * 2) + fa(T * W * 2) : fa(TS * 2 * W * 2);
+    return 4 * fa(T * W * 2) + fa(T * I * 2) + fa(T * 3 * W * 2) + kvop +
            3 * fa(layernorm_bwd_workspace_bytes((int)T, (int)W));     // + row partials of the three LayerNorm backward passes
 }
 
@@ -297,13 +345,14 @@ static bool fusion_tn_group_on() {
 }
 
 size_t fusion_ws_bytes(const FusionCfg& c) {
-    const size_t T = (size_t)c.B * c.L, TS = (size_t)c.B * c.S, W = c.W, I = c.I;
+    const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W, I = c.I;
     size_t b = 0;
     b += fa(T * W * 4) + fa(T * W * 4) + fa(T * W * 2);          // dx, dy, dyb
     b += fa(T * I * 2);                                          // dpre
     b += fa(T * W * 2);                                          // dctx
     b += fa(T * 3 * W * 2);                                      // dqkv (also dq2)
-    b += fa(TS * 2 * W * 2);                                     // dkv2
+    if (fusion_absorb(c)) b += 2 * fa(fusion_the(c) * 2) + fa(fusion_rsp(c) * 2);   // dO', dQ', dS
+    else b += fa(TS * 2 * W * 2);                                // dkv2
     b += fa((size_t)c.B * c.H * c.L * 4);                        // delta
     b += fa((size_t)c.B * c.Dp * 2) + fa((size_t)c.B * W * 4);   // dproj bf16, dh0
     // per-layer dY operands of the deferred weight gradients; only when that path is on (SPN_TN_GROUP != 0 and few
@@ -320,6 +369,7 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     mx(gemm_tn_workspace_bytes(c.B, c.Dp, (int)W));
     mx(gemm_tn_grouped_workspace_bytes((int)TS));
     mx(layernorm_bwd_workspace_bytes((int)T, (int)W));
+    if (c.T > 0) mx(embed_bwd_packed_ws_bytes(c.L, c.W));
     return b + fa(op);
 }
 
@@ -352,7 +402,7 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
     FusionLayout t;
     fusion_layout(c, &t);
     FusionActs A = fusion_acts_at(acts, c);
-    const int T = c.B * c.L, TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
+    const int T = fusion_rows(c), TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
     const size_t Ts = (size_t)T;
     char* p = ws;
     auto take = [&](size_t bytes) { char* r = p; p += fa(bytes); return r; };
@@ -362,7 +412,13 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
     bf16_t* dpre = (bf16_t*)take(Ts * I * 2);
     bf16_t* dctx = (bf16_t*)take(Ts * W * 2);
     bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
-    bf16_t* dkv2 = (bf16_t*)take((size_t)TS * 2 * W * 2);
+    const bool absorb = fusion_absorb(c);
+    bf16_t *dkv2 = nullptr, *doa = nullptr, *dqa = nullptr, *dsm = nullptr;
+    if (absorb) {
+        doa = (bf16_t*)take(fusion_the(c) * 2); dqa = (bf16_t*)take(fusion_the(c) * 2); dsm = (bf16_t*)take(fusion_rsp(c) * 2);
+    } else {
+        dkv2 = (bf16_t*)take((size_t)TS * 2 * W * 2);
+    }
     float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
     bf16_t* dprojb = (bf16_t*)take((size_t)c.B * c.Dp * 2);
     float* dh0 = (float*)take((size_t)c.B * W * 4);
@@ -393,7 +449,8 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         SPN_TRYF(gemm_tn(dprojb, A.h0b, c.B, c.Dp, W, c.Dp, W, grads + t.proj_w, W, 1.0f, 0, grads + t.proj_b, opws,
                          opws_bytes, st));
         SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, dh0, st));
-        SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
+        if (c.T > 0) SPN_TRYF(scatter_rows_abs(dh0, A.row_b, A.cu, dx, nullptr, T, W, st));
+        else SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
     }
 
     for (int l = (phases & 2) ? l_hi - 1 : -1; l >= l_lo; --l) {
@@ -406,12 +463,15 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         auto Bw = [&](int i) { return b + t.bf16_off[i]; };
         // the dY operands of this layer's weight gradients: buffers of its own when they are deferred
         bf16_t *dyb_ff = dyb, *dyb_ca = dyb, *dyb_sa = dyb, *dpre_l = dpre, *dq_ca = dqkv, *dqkv_sa = dqkv, *dkv2_l = dkv2;
+        bf16_t *dqa_l = dqa, *dctx_ca = dctx;
         float* ln_part = nullptr;
         if (grouped) {
             char* q = defer_base + defer_stride * l;
             auto tk = [&](size_t bytes) { char* r = q; q += fa(bytes); return (bf16_t*)r; };
             dyb_ff = tk(Ts * W * 2); dyb_ca = tk(Ts * W * 2); dyb_sa = tk(Ts * W * 2); dq_ca = tk(Ts * W * 2);
-            dpre_l = tk(Ts * I * 2); dqkv_sa = tk(Ts * 3 * W * 2); dkv2_l = tk((size_t)TS * 2 * W * 2);
+            dpre_l = tk(Ts * I * 2); dqkv_sa = tk(Ts * 3 * W * 2);
+            if (absorb) { dqa_l = tk(fusion_the(c) * 2); dctx_ca = tk(Ts * W * 2); }
+            else dkv2_l = tk((size_t)TS * 2 * W * 2);
             ln_part = (float*)q;
         }
         // LayerNorm backward: grouped mode leaves the [dgamma | dbeta] row partials in the layer's buffer (they are
@@ -445,18 +505,27 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         SPN_TRYF(nt_resid(dpre_l, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));        // dx = d/dx2
         // ---- cross-attention: x2 = LN(y2), y2 = x1 + attn(q(x1), kv(enc)) Wo^T + bo
         SPN_TRYF(ln_bwd(a.y2, LO_CA_LNG, LO_CA_LNB, a.mean2, a.rstd2, dyb_ca, 1));
-        SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx_ca, nullptr, st));
         SPN_TRYF(wgrad(dyb_ca, a.ctx2, T, W, W, G(LO_CA_WO), G(LO_CA_BO)));
-        {
+        if (absorb) {
+            const int R = c.L * c.H;
+            SPN_TRYF(xattn_delta(dctx_ca, a.ctx2, P(LO_CA_BKV) + W, delta, T, c.H, st));
+            SPN_TRYF(xattn_head_expand(dctx_ca, W, Bw(BO_CA_WKV_T), 2 * W, W, doa, T, c.H, E, 1.0f, st));          // dO' = dctx_h Wv_h
+            SPN_TRYF(xattn_dscores(doa, A.enc_b, a.pm, delta, dsm, c.B, R, c.S, E, st, A.cu, c.H));                // dS
+            SPN_TRYF(xattn_apply(dsm, A.enc_b, dqa_l, c.B, R, c.S, E, st, A.cu, c.H));                             // dQ' = dS X
+            SPN_TRYF(xattn_head_contract(dqa_l, Bw(BO_CA_WKV), 0, nullptr, dq_ca, W, T, c.H, E, 0.125f, st));     // dq_h
+            if (!grouped)
+                SPN_TRYF(xattn_wgrad(a.q2, 0, dqa_l, 0, dctx_ca, 0, a.oa, 0, G(LO_CA_WKV), G(LO_CA_BKV), 0, 1, T, W, c.H, E, 0.125f, st));
+        } else {
             AttnBwdArgs g;
             g.f = cross_attn_args(c, a);
-            g.d_o = dctx; g.lddo = W;
+            g.d_o = dctx_ca; g.lddo = W;
             g.dq = dq_ca; g.lddq = W;
             g.dk = dkv2_l; g.dv = dkv2_l + W; g.lddk = g.lddv = 2 * W;
             g.delta = delta;
             SPN_TRYF(attention_bwd(g, st));
+            SPN_TRYF(wgrad(dkv2_l, A.enc_b, TS, 2 * W, E, G(LO_CA_WKV), G(LO_CA_BKV)));
         }
-        SPN_TRYF(wgrad(dkv2_l, A.enc_b, TS, 2 * W, E, G(LO_CA_WKV), G(LO_CA_BKV)));
         SPN_TRYF(wgrad(dq_ca, a.x1b, T, W, W, G(LO_CA_WQ), G(LO_CA_BQ)));
         SPN_TRYF(nt_resid(dq_ca, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));         // dx = d/dx1
         // ---- self-attention: x1 = LN(y1), y1 = x_in + attn(qkv(x_in)) Wo^T + bo
@@ -465,7 +534,7 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         SPN_TRYF(wgrad(dyb_sa, a.ctx1, T, W, W, G(LO_SA_WO), G(LO_SA_BO)));
         {
             AttnBwdArgs g;
-            g.f = self_attn_args(c, a, A.key_bias);
+            g.f = self_attn_args(c, a, A.key_bias, A.cu);
             g.d_o = dctx; g.lddo = W;
             g.dq = dqkv_sa; g.dk = dqkv_sa + W; g.dv = dqkv_sa + 2 * W;
             g.lddq = g.lddk = g.lddv = 3 * W;
@@ -480,13 +549,28 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
     for (int i = 0; i < nT; i += TN_GROUP_MAX)
         SPN_TRYF(gemm_tn_grouped(qT + i, nT - i < TN_GROUP_MAX ? nT - i : TN_GROUP_MAX, T, opws, opws_bytes, st));
     if (nS) SPN_TRYF(gemm_tn_grouped(qS, nS, TS, opws, opws_bytes, st));
+    if (absorb && grouped && (phases & 2) && l_hi > l_lo) {
+        // absorbed K/V weight gradients of the layers [l_lo, l_hi) in one launch: the operands sit at constant strides
+        FusionLayerActs a0 = fusion_layer_acts_at(A.layers + A.layer_bytes * l_lo, c);
+        char* q = defer_base + defer_stride * l_lo;
+        q += 4 * fa(Ts * W * 2) + fa(Ts * I * 2) + fa(Ts * 3 * W * 2);          // the carve-up of the loop above
+        const bf16_t* dqa0 = (const bf16_t*)q;
+        const bf16_t* dctx0 = (const bf16_t*)(q + fa(fusion_the(c) * 2));
+        float* g0 = grads + t.layers + t.layer_size * l_lo;
+        SPN_TRYF(xattn_wgrad(a0.q2, A.layer_bytes / 2, dqa0, defer_stride / 2, dctx0, defer_stride / 2, a0.oa, A.layer_bytes / 2,
+                             g0 + t.layer_off[LO_CA_WKV], g0 + t.layer_off[LO_CA_BKV], (size_t)t.layer_size, l_hi - l_lo, T, W, c.H,
+                             E, 0.125f, st));
+    }
     SPN_TRYF(fold_flush());
     if (!(phases & 4)) return SPN_OK;
     // embeddings: x0 = LN(word[ids] + pos)
     SPN_TRYF(layernorm_bwd(nullptr, dx, A.emb, params + t.emb_ln_g, A.emb_mean, A.emb_rstd, dy, 0, nullptr, grads + t.emb_ln_g,
                            grads + t.emb_ln_b, 0, T, W, opws, opws_bytes, st));
     SPN_TRYF(zero_fill_f32(grads + t.word, (size_t)c.vocab * W, st));
-    SPN_TRYF(embed_bwd(ids, A.last, dy, grads + t.word, grads + t.pos, c.B, c.L, W, c.vocab, st));
+    if (c.T > 0)
+        SPN_TRYF(embed_bwd_packed(ids, A.row_b, A.row_l, A.cu, dy, grads + t.word, grads + t.pos, T, c.B, c.L, W, c.vocab, opws,
+                                  opws_bytes, st));
+    else SPN_TRYF(embed_bwd(ids, A.last, dy, grads + t.word, grads + t.pos, c.B, c.L, W, c.vocab, st));
     if (c.L < c.max_pos) {
         SPN_TRYF(zero_fill_f32(grads + t.pos + (size_t)c.L * W, (size_t)(c.max_pos - c.L) * W, st));
     }

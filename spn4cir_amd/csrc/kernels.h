@@ -187,6 +187,27 @@ struct AttnBwdArgs {
 };
 int attention_fwd(const AttnArgs& a, hipStream_t st);
 int attention_bwd(const AttnBwdArgs& a, hipStream_t st);
+
+// xattn.hip: cross-attention over frozen image tokens with the K/V projections absorbed into the query / output side
+// (rows of a sample r = l*H + h; R = L*H; SP = xattn_sp(S) columns in P / dS)
+bool xattn_absorb_ok(int B, int L, int H, int S, int E, int W);
+int xattn_sp(int S);
+int xattn_head_expand(const bf16_t* A, int lda, const bf16_t* Wt, int ldw, int col0, bf16_t* out, int T, int H, int E, float alpha,
+                      hipStream_t st);
+int xattn_head_contract(const bf16_t* A, const bf16_t* Wr, int row0, const float* bias, bf16_t* out, int ldo, int T, int H, int E,
+                        float alpha, hipStream_t st);
+// cu != null (packed text rows): sample b owns the rows cu[b]*H .. cu[b+1]*H; R = the longest sample's row count (grid only)
+int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st,
+                         const int32_t* cu = nullptr, int H = 0);
+int xattn_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const float* delta, bf16_t* dS, int B, int R, int S, int E,
+                  hipStream_t st, const int32_t* cu = nullptr, int H = 0);
+int xattn_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, hipStream_t st, const int32_t* cu = nullptr,
+                int H = 0);
+int xattn_delta(const bf16_t* dctx, const bf16_t* ctx, const float* bv, float* delta, int T, int H, hipStream_t st);
+int xattn_wgrad(const bf16_t* q, size_t q_stride, const bf16_t* dqa, size_t dqa_stride, const bf16_t* dctx, size_t dctx_stride,
+                const bf16_t* oa, size_t oa_stride, float* dW, float* dbias, size_t g_stride, int layers, int T, int W, int H, int E,
+                float scale, hipStream_t st);
+
 // attention_small.hip: whole-head kernels for Lq == Lk <= 128 (attention_fwd/bwd dispatch to them)
 bool attention_small_ok(const AttnArgs& a);
 int attention_small_fwd(const AttnArgs& a, hipStream_t st);

@@ -71,6 +71,7 @@ int vision_fwd(const VisionCfg& c, const float* params, const bf16_t* wb, const 
 
 struct FusionCfg {     // == spn_fusion_cfg
     int B, L, S, W, H, layers, I, E, Dp, vocab, max_pos;
+    int T;             // packed live text rows (sum of the caption lengths), 0 = dense B*L rows
 };
 
 struct FusionLayout {  // == spn_fusion_layout_t (element offsets)
@@ -81,6 +82,7 @@ struct FusionLayout {  // == spn_fusion_layout_t (element offsets)
 };
 
 void fusion_layout(const FusionCfg& c, FusionLayout* t);
+int fusion_packed_ok(const FusionCfg& c);
 size_t fusion_act_bytes(const FusionCfg& c);
 size_t fusion_ws_bytes(const FusionCfg& c);
 int fusion_refresh_bf16(const FusionCfg& c, const float* params, bf16_t* wb, hipStream_t st);

@@ -38,8 +38,20 @@ class FusionEncoder:
         self._acts = self._ws = self._key = self._last = None
         self._stale = True
 
-    def _cfg(self, B, L, S):
-        return _lib.FusionCfg(B, L, S, self.W, self.H, self.layers, self.I, self.E, self.Dp, self.vocab, self.max_pos)
+    def _cfg(self, B, L, S, T=0):
+        return _lib.FusionCfg(B, L, S, self.W, self.H, self.layers, self.I, self.E, self.Dp, self.vocab, self.max_pos, T)
+
+    @staticmethod
+    def _prefix_lengths(mask):
+        """Caption lengths of a HOST attention mask [B, L] if every row is ones-then-zeros with at least one 1 (the tokenizer's
+        right padding, blip.py:189-194), else None.  A device mask is never inspected (that would synchronise the step)."""
+        if mask is None or mask.is_cuda:
+            return None
+        m = mask.to(torch.int64)
+        lens = m.sum(1)
+        if int(lens.min()) < 1 or not bool((m == (torch.arange(m.shape[1])[None, :] < lens[:, None])).all()):
+            return None
+        return lens
 
     def spans(self):
         """[(BertModel key (+ text_proj.*), offset, shape)]; q/k/v rows of the packed weights are separate views."""
@@ -98,8 +110,12 @@ class FusionEncoder:
         (train_negplus.py:121-123) is noticed without a parameters_changed() call."""
         return self._stale or self.params._version != getattr(self, "_seen_version", -1)
 
-    def forward(self, ids, mask, enc=None, token_bank=None, token_idx=None):
-        """ids int32 [B,L], mask int32 [B,L] or None -> text_proj output fp32 [B,Dp].  The reference image tokens are either
+    def forward(self, ids, mask, enc=None, token_bank=None, token_idx=None, pack=None):
+        """ids int32 [B,L], mask int32 [B,L] or None -> text_proj output fp32 [B,Dp].
+        pack (default: on whenever possible): with a HOST mask of right-padded captions (what the tokenizer returns) only the
+        unmasked text rows are materialised (spn_fusion_cfg.T; same features and gradients - a padded position's key is masked in
+        every self-attention); a device mask, a shape spn_fusion_packed_ok rejects, or pack=False run the dense B x L rows.
+        The reference image tokens are either
         `enc` fp32 [B,S,E] (device; cast to bf16 inside) or - the resident-bank form of the training step - rows `token_idx`
         (int64 [B], device) of `token_bank` bf16 [N,S,E] on the device, gathered by the library straight into the K/V
         projections' operand (spn_fusion_fwd_bank; blip4cir/models.py:97-100)."""
@@ -116,17 +132,29 @@ class FusionEncoder:
             S = token_bank.shape[1]
         else:
             S = enc.shape[1]
-        cfg = self._cfg(B, L, S)
+        cfg0 = self._cfg(B, L, S)
+        lens = None
+        if pack is not False and L <= 128 and lib().spn_fusion_packed_ok(C.byref(cfg0)):
+            lens = self._prefix_lengths(mask)
+        if pack and lens is None:
+            raise ValueError("pack=True needs a host (CPU) attention mask of right-padded captions and a shape spn_fusion_packed_ok accepts")
+        if lens is not None:
+            cu = torch.zeros(B + 1, dtype=torch.int32)
+            cu[1:] = lens.cumsum(0)
+            cfg = self._cfg(B, L, S, int(cu[-1]))
+            mask = cu.pin_memory() if torch.cuda.is_available() else cu          # the mask slot carries cu_seqlens (spn4cir_hip.h)
+        else:
+            cfg = cfg0
         if self.is_stale():
             check(lib().spn_fusion_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()), "fusion_refresh")
             self._stale = False
             self._seen_version = self.params._version
-        if self._key != (B, L, S):
-            self._acts = ops.scratch_bytes(lib().spn_fusion_act_bytes(C.byref(cfg)), self.device)
-            self._ws = ops.scratch_bytes(lib().spn_fusion_ws_bytes(C.byref(cfg)), self.device)
+        if self._key != (B, L, S):                     # sized for the dense rows: fits every packed batch of the shape
+            self._acts = ops.scratch_bytes(lib().spn_fusion_act_bytes(C.byref(cfg0)), self.device)
+            self._ws = ops.scratch_bytes(lib().spn_fusion_ws_bytes(C.byref(cfg0)), self.device)
             self._key = (B, L, S)
         ids = ids.to(self.device, torch.int32).contiguous()
-        mask = None if mask is None else mask.to(self.device, torch.int32).contiguous()
+        mask = None if mask is None else mask.to(self.device, torch.int32, non_blocking=True).contiguous()
         out = torch.empty(B, self.Dp, dtype=torch.float32, device=self.device)
         if token_bank is not None:
             check(lib().spn_fusion_fwd_bank(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(mask), _p(token_bank),

@@ -413,3 +413,62 @@ def test_token_bank_gather_and_tau_grad(golden_dir):
     assert (l1 - l2).abs().item() < 1e-5 and (e1.params - e2.params).abs().max().item() < 1e-5
     assert abs(t1.tau.item() - t2.tau.item()) < 1e-7
     assert t1.tau.item() != 0.03                                    # the learnable temperature moved (models.py:29)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,E", [(70, 128), (300, 256)])
+def test_packed_text_rows_match_dense(S, E):
+    """spn_fusion_cfg.T (packed text rows: only the unmasked positions of right-padded captions are materialised, the absorbed
+    cross-attention of csrc/xattn.hip addresses each sample's row range) against the dense B x L rows of the same encoder:
+    same [ENC] features and the same gradient for every parameter (a padded position's key is masked in every self-attention,
+    med.py:686, so its row influences nothing).  Tolerance: fp32 summation order of the weight-gradient reductions only."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spn4cir_amd._lib import lib
+    from spn4cir_amd.fusion import FusionEncoder
+    import ctypes as C
+    g = torch.Generator().manual_seed(11)
+    B, L, W, H, layers, I, Dp, vocab = 5, 12, 128, 2, 2, 256, 64, 100
+    enc = FusionEncoder(W, layers, H, I, E, Dp, vocab, 40, "cuda")
+    assert lib().spn_fusion_packed_ok(C.byref(enc._cfg(B, L, S))) == 1
+    with torch.no_grad():
+        for k, v in enc.named_views().items():
+            if k.endswith("LayerNorm.weight"):
+                v.copy_((1.0 + 0.1 * torch.randn(v.shape, generator=g)).cuda())
+            else:
+                v.copy_((torch.randn(v.shape, generator=g) * (0.08 if v.dim() >= 2 else 0.02)).cuda())
+    enc.mark_stale()
+    lens = torch.tensor([12, 1, 7, 3, 12])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int32)                 # host mask, right padded
+    ids = torch.randint(1, vocab, (B, L), generator=g, dtype=torch.int32) * mask
+    tokens = torch.randn(B, S, E, generator=g).cuda()
+    dproj = torch.randn(B, Dp, generator=g).cuda()
+    out_d = enc.forward(ids, mask, tokens, pack=False).clone()
+    assert enc._last[1].T == 0
+    g_d = enc.backward(dproj).clone()
+    out_p = enc.forward(ids, mask, tokens).clone()                                    # default: packed with a host mask
+    assert enc._last[1].T == int(lens.sum())
+    g_p = enc.backward(dproj).clone()
+    assert torch.isfinite(out_p).all() and torch.isfinite(g_p).all()
+    assert (out_p - out_d).abs().max().item() <= 1e-5 * out_d.abs().max().item()
+    worst = 0.0
+    for key, off, shape in enc.spans():
+        n = int(np.prod(shape))
+        a, b = g_p[off:off + n].double(), g_d[off:off + n].double()
+        scale = b.norm().item()
+        if scale == 0.0:
+            assert a.norm().item() == 0.0, key
+            continue
+        worst = max(worst, ((a - b).norm() / scale).item())
+        assert (a - b).norm().item() <= 2e-5 * scale, (key, (a - b).norm().item() / scale)
+    print("packed vs dense: worst relative L2 gradient difference", worst)
+    # a device mask is never inspected (no synchronisation): dense rows; pack=True without a host mask is an error
+    enc.forward(ids, mask.cuda(), tokens)
+    assert enc._last[1].T == 0
+    with pytest.raises(ValueError):
+        enc.forward(ids, mask.cuda(), tokens, pack=True)
+    # left-padded / holey masks are not prefix masks: dense rows
+    holey = mask.clone()
+    holey[0, 3] = 0
+    enc.forward(ids, holey, tokens)
+    assert enc._last[1].T == 0
