@@ -21,6 +21,30 @@
 
 namespace spn {
 
+// Store a workgroup's 128 x 128 fp32 accumulator tile (4 waves, 2 x 2, each 4 x 4 MFMA tiles: row = lane & 15, 4 consecutive
+// columns at (lane >> 4) * 4) as bf16 rows of 256 contiguous bytes: through an LDS image with a 272-byte row pitch (8-byte
+// fragments land conflict-free), read back 16 bytes per lane - one instruction stores four whole 256-byte rows instead of sixteen
+// 32-byte pieces.  `stage` >= 128 * 272 bytes, free to overwrite (the caller has synchronised after its last operand read).
+static constexpr int OUT_PITCH = 272;
+__device__ __forceinline__ void store_tile_bf16(const f32x4 (&acc)[4][4], float alpha, char* stage, bf16_t* out, size_t ld,
+                                                int rows_valid, int wr, int wc, int lane, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        char* row = stage + (wr * 64 + i * 16 + (lane & 15)) * OUT_PITCH + (wc * 64 + (lane >> 4) * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc[i][j] * alpha;
+            *(bf16x4*)(row + j * 32) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 16 + (tid >> 4), c = tid & 15;              // 16 rows of 16 x 16 B per pass
+        if (r < rows_valid) *(u32x4*)(out + (size_t)r * ld + c * 8) = *(const u32x4*)(stage + r * OUT_PITCH + c * 16);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------------------
 // head_expand: out[t, h, :] = alpha * A[t, h*64 .. +64] . Wt[:, col0 + h*64 .. +64]^T     (K = 64: one k tile, store-bound)
 // A [T, lda] bf16; Wt [E, ldw] = the TRANSPOSED bf16 copy of the K/V weight; out [T, H, E] bf16.
@@ -28,8 +52,8 @@ namespace spn {
 __global__ __launch_bounds__(NTHREADS, 2) void xattn_head_expand_kernel(const bf16_t* __restrict__ A, int lda,
                                                                         const bf16_t* __restrict__ Wt, int ldw, int col0,
                                                                         bf16_t* __restrict__ out, int T, int H, int E, float alpha) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ __attribute__((aligned(16))) char smem[128 * OUT_PITCH];         // two operand tiles (32 KB), then the output image
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = E / BN, tiles_m = (T + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -60,17 +84,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_head_expand_kernel(const bf
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
-        if (m >= T) continue;
-        bf16_t* o = out + ((size_t)m * H + h) * E + n0 + wc * 64 + (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc[i][j] * alpha;
-            *(bf16x4*)(o + j * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        }
-    }
+    __syncthreads();                                                            // everyone has read its operand fragments
+    store_tile_bf16(acc, alpha, smem, out + ((size_t)m0 * H + h) * E + n0, (size_t)H * E, T - m0, wr, wc, lane, tid);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_head_contract_kernel(const 
                                                                           float alpha) {
     constexpr int A_BYTES = TILE_BYTES, STAGE = TILE_BYTES + TILE_BYTES / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int h = bid % H, m0 = (bid / H) * BM;
     const int lda = H * E;
@@ -146,17 +161,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_head_contract_kernel(const 
 // re-staged per column tile from L2), keeps the NT x 32 fp32 accumulators per lane, and normalises in registers.
 // P [B, R, NT*128] bf16, zero in the columns >= S (the K extent of the P X product).
 // ----------------------------------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(NTHREADS, 2) void xattn_scores_softmax_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ X,
-                                                                           bf16_t* __restrict__ P, int R, int S, int E,
-                                                                           const int32_t* __restrict__ cu, int H) {
-    constexpr int A_BYTES = TILE_BYTES / 2, STAGE = A_BYTES + TILE_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE, then 2 x 64 floats twice
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+template <int NT, int WM>          // WM x 2 waves, 32 * WM rows per workgroup
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softmax_kernel(const bf16_t* __restrict__ Q,
+                                                                                         const bf16_t* __restrict__ X,
+                                                                                         bf16_t* __restrict__ P, int R, int S, int E,
+                                                                                         const int32_t* __restrict__ cu, int H) {
+    constexpr int BMW = 32 * WM, NW = 2 * WM;
+    constexpr int A_BYTES = BMW * 128, STAGE = A_BYTES + TILE_BYTES;
+    constexpr int GROUPS = BMW / 8 + 16;                                 // 8-row groups of one stage (A rows, then the 128 B rows)
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE, then 2 x BMW floats
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int wr = wid >> 1, wc = wid & 1;
-    const int tiles_r = (R + 63) / 64;
+    const int tiles_r = (R + BMW - 1) / BMW;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = bid / tiles_r, m0 = (bid % tiles_r) * 64;
+    const int b = bid / tiles_r, m0 = (bid % tiles_r) * BMW;
     // packed rows: sample b owns the rows cu[b]*H .. cu[b+1]*H of Q / P (R = the longest sample, for the grid only)
     const size_t r0 = cu ? (size_t)cu[b] * H : (size_t)b * R;
     if (cu) R = (cu[b + 1] - cu[b]) * H;
@@ -171,44 +189,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_scores_softmax_kernel(const
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = E / BK, total = nk * NT;
+    const bool live = m0 + wr * 32 < R;         // a wave whose 32 rows lie beyond the sample's end only helps with the staging
     int s_t = 0, s_k = 0;                       // (column tile, k tile) of the next stage request
     auto stage_next = [&](int buf) {
         char* dst = smem + buf * STAGE;
-        nt_stage<2>(rsA, dst, m0, E, s_k * BK, wid, lane);
-        nt_stage<4>(rsB, dst + A_BYTES, s_t * BN, E, s_k * BK, wid, lane);
+#pragma unroll
+        for (int g = wid; g < GROUPS; g += NW) {        // wave-uniform: (GROUPS - wid + NW - 1) / NW requests per wave and stage
+            const bool isA = g < BMW / 8;
+            const int R0 = (isA ? g : g - BMW / 8) * 8;
+            const int r = R0 + (lane >> 3);
+            const int c = nt_swz(r, lane & 7);
+            const uint32_t off = ((uint32_t)((isA ? m0 : s_t * BN) + r) * (uint32_t)E + (uint32_t)(s_k * BK + c * 8)) * 2u;
+            glds16(isA ? rsA : rsB, dst + (isA ? 0 : A_BYTES) + R0 * 128, off);
+        }
         if (++s_k == nk) { s_k = 0; ++s_t; }
     };
+    constexpr int REQ_LO = GROUPS / NW;                 // requests per stage of the waves with wid >= GROUPS % NW
+    const bool more = wid < GROUPS % NW;                // ... the others issue one more
     stage_next(0);
     if (total > 1) stage_next(1);
     int buf = 0, s = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         for (int kt = 0; kt < nk; ++kt, ++s) {
-            if (s + 1 < total) wait_vmcnt<6>();
-            else wait_vmcnt<0>();
+            if (s + 1 < total) {
+                if (more) wait_vmcnt<REQ_LO + 1>();
+                else wait_vmcnt<REQ_LO>();
+            } else {
+                wait_vmcnt<0>();
+            }
             lds_barrier();
             if (s + 2 < total) stage_next(buf >= 1 ? buf - 1 : 2);
             const char* sA = smem + buf * STAGE;
             const char* sB = sA + A_BYTES;
+            if (live) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[2], bb[4];
-                const int c = ks * 4 + (lane >> 4);
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a[2], bb[4];
+                    const int c = ks * 4 + (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = nt_frag(sA, wr * 32 + i * 16 + (lane & 15), c);
+                    for (int i = 0; i < 2; ++i) a[i] = nt_frag(sA, wr * 32 + i * 16 + (lane & 15), c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bb[j] = nt_frag(sB, wc * 64 + j * 16 + (lane & 15), c);
+                    for (int j = 0; j < 4; ++j) bb[j] = nt_frag(sB, wc * 64 + j * 16 + (lane & 15), c);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][i][j] = mfma16(bb[j], a[i], acc[t][i][j]);
+                        for (int j = 0; j < 4; ++j) acc[t][i][j] = mfma16(bb[j], a[i], acc[t][i][j]);
+                }
             }
             buf = buf == 2 ? 0 : buf + 1;
         }
     }
     // softmax over the row: a lane holds, of row (wr*32 + i*16 + lane&15), the columns t*128 + wc*64 + j*16 + (lane>>4)*4 + e
-    float* red = (float*)(smem + 3 * STAGE);                             // [2 wc][64 rows]
-    float rmax[2], rsum[2];
+    float* red = (float*)(smem + 3 * STAGE);                             // [2 wc][BMW rows]
+    float rsum[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float mx = -INFINITY;
@@ -225,15 +259,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_scores_softmax_kernel(const
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        rmax[i] = mx;
-        if (lane < 16) red[wc * 64 + wr * 32 + i * 16 + lane] = mx;
+        if (lane < 16) red[wc * BMW + wr * 32 + i * 16 + lane] = mx;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = wr * 32 + i * 16 + (lane & 15);
-        const float mx = fmaxf(red[row], red[64 + row]);
-        rmax[i] = mx;
+        const float mx = fmaxf(red[row], red[BMW + row]);
         float sm = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -252,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_scores_softmax_kernel(const
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        if (lane < 16) red[wc * 64 + wr * 32 + i * 16 + lane] = rsum[i];
+        if (lane < 16) red[wc * BMW + wr * 32 + i * 16 + lane] = rsum[i];
     __syncthreads();
     const int SP = NT * BN;
 #pragma unroll
@@ -260,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_scores_softmax_kernel(const
         const int row = wr * 32 + i * 16 + (lane & 15);
         const int m = m0 + row;
         if (m >= R) continue;
-        const float inv = 1.0f / (red[row] + red[64 + row]);
+        const float inv = 1.0f / (red[row] + red[BMW + row]);
         bf16_t* o = P + (r0 + m) * SP + wc * 64 + (lane >> 4) * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_dscores_kernel(const bf16_t
                                                                     bf16_t* __restrict__ dS, int R, int S, int E, int SP,
                                                                     const int32_t* __restrict__ cu, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x 2 x TILE_BYTES
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = SP / BN, tiles_m = (R + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_apply_kernel(const bf16_t* 
                                                                   bf16_t* __restrict__ out, int R, int S, int E, int SP,
                                                                   const int32_t* __restrict__ cu, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x 2 x TILE_BYTES
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = E / BN, tiles_m = (R + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -397,15 +429,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_apply_kernel(const bf16_t* 
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bb[j], a[i], acc[i][j]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
-        if (m >= R) continue;
-        bf16_t* o = out + (r0 + m) * E + n0 + wc * 64 + (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *(bf16x4*)(o + j * 16) = bf16x4{f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3])};
-    }
+    __syncthreads();                                                            // the last k tile's fragments are read
+    store_tile_bf16(acc, 1.0f, smem, out + (r0 + m0) * E + n0, (size_t)E, R - m0, wr, wc, lane, tid);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------------
@@ -449,7 +474,7 @@ struct XattnWgradArgs {
 
 __global__ __launch_bounds__(NTHREADS, 1) void xattn_wgrad_kernel(XattnWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x 3 x TILE_BYTES
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
     const int wr = wid >> 1, wc = wid & 1;
     const int tiles_n = g.E / BN;
     const int kv = blockIdx.y, layer = blockIdx.z;
@@ -568,22 +593,27 @@ int xattn_head_contract(const bf16_t* A, const bf16_t* Wr, int row0, const float
     return SPN_OK;
 }
 
-int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st, const int32_t* cu,
-                         int H) {
-    constexpr int LDS = 3 * (TILE_BYTES / 2 + TILE_BYTES) + 2 * 64 * 4;
-    const int tiles = B * ((R + 63) / 64);
-    ProfScope prof(PK_ATTN_FWD, 2.0 * B * R * (double)S * E, st);
-    if (xattn_sp(S) == 256) {
-        static const int rc0 = xattn_lds(xattn_scores_softmax_kernel<2>, LDS);
-        if (rc0) return rc0;
-        hipLaunchKernelGGL(xattn_scores_softmax_kernel<2>, dim3(tiles), dim3(NTHREADS), LDS, st, Q, X, P, R, S, E, cu, H);
-    } else {
-        static const int rc0 = xattn_lds(xattn_scores_softmax_kernel<5>, LDS);
-        if (rc0) return rc0;
-        hipLaunchKernelGGL(xattn_scores_softmax_kernel<5>, dim3(tiles), dim3(NTHREADS), LDS, st, Q, X, P, R, S, E, cu, H);
-    }
+template <int NT, int WM>
+static int launch_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st,
+                                 const int32_t* cu, int H) {
+    constexpr int BMW = 32 * WM;
+    constexpr int LDS = 3 * (BMW * 128 + TILE_BYTES) + 2 * BMW * 4;
+    static const int rc0 = xattn_lds(xattn_scores_softmax_kernel<NT, WM>, LDS);
+    if (rc0) return rc0;
+    const int tiles = B * ((R + BMW - 1) / BMW);
+    hipLaunchKernelGGL((xattn_scores_softmax_kernel<NT, WM>), dim3(tiles), dim3(128 * WM), LDS, st, Q, X, P, R, S, E, cu, H);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
+}
+
+int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st, const int32_t* cu,
+                         int H) {
+    // Rows per workgroup: 64 (WM = 2: 4 waves, two workgroups per CU).  WM = 4 / 6 (128 / 192 rows, 8 / 12 waves, one workgroup per
+    // CU - the sample's X streamed once for two / three times the rows) measured the same or slower at config 4's shape:
+    // 123 / 127 / 137 us per launch (LABNOTES.md 5.8) - the k step is bound by the LDS round trips of a wave, not by the L2 stream.
+    ProfScope prof(PK_ATTN_FWD, 2.0 * B * R * (double)S * E, st);
+    if (xattn_sp(S) == 256) return launch_scores_softmax<2, 2>(Q, X, P, B, R, S, E, st, cu, H);
+    return launch_scores_softmax<5, 2>(Q, X, P, B, R, S, E, st, cu, H);
 }
 
 int xattn_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const float* delta, bf16_t* dS, int B, int R, int S, int E,
