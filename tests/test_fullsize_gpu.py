@@ -229,6 +229,13 @@ def test_blip_fusion_full_shape(enc_width, init):
             continue
         errs[k] = _rel(got, ref)
     _floor_gate(f"blip_{enc_width}" + ("_refinit" if init == "reference" else ""), errs, f"blip fusion enc_width {enc_width} ({init} init)")
+    # (6) the same B = 8 step on the unmasked text rows only (host mask -> spn_fusion_cfg.T): same queries, same gradients
+    g_dense = grads.clone()
+    proj_pk = enc_model.forward(ids[:b].contiguous(), mask[:b].contiguous(), enc_d[:b].contiguous())
+    assert enc_model._last[1].T == int(lens[:b].sum())
+    assert _rel(proj_pk, proj) < 1e-5
+    g_pk = enc_model.backward(ops.combine_l2norm_bwd(q, inv, dq))
+    assert _rel(g_pk, g_dense) < 1e-4
 
 
 def test_fp8_bank_trainer_step_100k():
