@@ -26,15 +26,12 @@ namespace spn {
 template <int MI>
 static constexpr int nt_v1_stages() { return MI == 2 ? 3 : 2; }
 
-// KT = 64-deep k tiles per pipeline stage.  KT = 2 (64-row tiles only, 144 KB, one workgroup per CU): for products with at most
-// one workgroup per CU anyway - a launch then lasts as long as ONE workgroup's k loop, whose steps cost a barrier, a counted DMA
-// wait and an LDS round trip each whatever they multiply; half as many, twice as deep steps shorten exactly that chain.
-template <int MODE, int ACT, int MI = 4, int KT = 1>
+template <int MODE, int ACT, int MI = 4>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A,
                                                               const bf16_t* __restrict__ B, int M, int N, int K,
                                                               int lda, int ldb, GemmEpilogue ep) {
     constexpr int BM = 32 * MI;
-    constexpr int A_BYTES = BM * 64 * 2, SUB = A_BYTES + TILE_BYTES, STAGE = KT * SUB;
+    constexpr int A_BYTES = BM * 64 * 2, STAGE = A_BYTES + TILE_BYTES;
     constexpr int NS = nt_v1_stages<MI>();
     extern __shared__ __attribute__((aligned(16))) char smem[];          // NS x STAGE
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -52,14 +49,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / (BK * KT);
+    const int nk = K / BK;
     auto stage = [&](int kt, int buf) {
-#pragma unroll
-        for (int sub = 0; sub < KT; ++sub) {
-            char* dst = smem + buf * STAGE + sub * SUB;
-            nt_stage<MI>(rsA, dst, m0, lda, (kt * KT + sub) * BK, wid, lane);
-            nt_stage<4>(rsB, dst + A_BYTES, n0, ldb, (kt * KT + sub) * BK, wid, lane);
-        }
+        char* dst = smem + buf * STAGE;
+        nt_stage<MI>(rsA, dst, m0, lda, kt * BK, wid, lane);
+        nt_stage<4>(rsB, dst + A_BYTES, n0, ldb, kt * BK, wid, lane);
     };
     stage(0, 0);
     if constexpr (NS == 3) {
@@ -68,7 +62,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = NS == 3 ? kt % 3 : (kt & 1);
         if constexpr (NS == 3) {
-            if (kt + 1 < nk) wait_vmcnt<KT * (MI + 4)>();   // tile kt is in; tile kt + 1 (MI + 4 DMA per wave and sub-tile) may still be in flight
+            if (kt + 1 < nk) wait_vmcnt<MI + 4>();      // tile kt is in; tile kt + 1 (MI + 4 DMA per wave) may still be in flight
             else wait_vmcnt<0>();
             lds_barrier();                               // raw barrier: __syncthreads() would drain the tile in flight (common.h)
             if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);   // = the buffer of tile kt - 1, read by everyone before this barrier
@@ -77,11 +71,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const bf16_t* __re
             __syncthreads();   // tile kt landed for every wave; everyone finished reading buf^1
             if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
         }
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2 * KT; ++ks2) {
-            const char* sA = smem + buf * STAGE + (ks2 >> 1) * SUB;
-            const char* sB = sA + A_BYTES;
-            const int ks = ks2 & 1;
+        for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[MI], b[4];
             const int c = ks * 4 + (lane >> 4);
 #pragma unroll
@@ -177,11 +170,11 @@ int gemm_cfg() {
     return cfg;
 }
 
-template <int MODE, int ACT, int MI, int KT = 1>
+template <int MODE, int ACT, int MI>
 static int launch_nt_v1(int tiles, hipStream_t st, const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int ldb,
                         const GemmEpilogue& ep) {
-    constexpr int LDS = nt_v1_stages<MI>() * KT * (32 * MI * 64 * 2 + TILE_BYTES);
-    auto kern = gemm_nt_kernel<MODE, ACT, MI, KT>;
+    constexpr int LDS = nt_v1_stages<MI>() * (32 * MI * 64 * 2 + TILE_BYTES);
+    auto kern = gemm_nt_kernel<MODE, ACT, MI>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -222,15 +215,11 @@ int gemm_nt(const bf16_t* A, const bf16_t* B, int M, int N, int K, int lda, int 
     static const int small_mi = [] { const char* e = spn_env("SPN_NT_SMALL_MI"); return e ? atoi(e) : 2; }();
     const bool half = small_mi == 2 && t128 < 256;
     const int tiles = ((M + (half ? 64 : BM) - 1) / (half ? 64 : BM)) * ((N + BN - 1) / BN);
-    // at most ~1.5 workgroups per CU: two k tiles per stage (SPN_NT_KT=1 keeps one; =2 forces two wherever the 64-row tile runs)
-    static const int kt_env = [] { const char* e = spn_env("SPN_NT_KT"); return e ? atoi(e) : 0; }();
-    const bool deep = half && K % (2 * BK) == 0 && (kt_env == 2 || (kt_env == 0 && tiles <= 384));
     ProfScope prof(PK_GEMM_NT, 2.0 * M * N * K, st);
 #define SPN_LAUNCH_NT(MODE_, ACT_)                                                                                       \
     do {                                                                                                                 \
-        const int rc_ = deep   ? launch_nt_v1<MODE_, ACT_, 2, 2>(tiles, st, A, B, M, N, K, lda, ldb, ep)                 \
-                        : half ? launch_nt_v1<MODE_, ACT_, 2>(tiles, st, A, B, M, N, K, lda, ldb, ep)                    \
-                               : launch_nt_v1<MODE_, ACT_, 4>(tiles, st, A, B, M, N, K, lda, ldb, ep);                   \
+        const int rc_ = half ? launch_nt_v1<MODE_, ACT_, 2>(tiles, st, A, B, M, N, K, lda, ldb, ep)                      \
+                             : launch_nt_v1<MODE_, ACT_, 4>(tiles, st, A, B, M, N, K, lda, ldb, ep);                     \
         if (rc_) return rc_;                                                                                             \
     } while (0)
     if (mode == GEMM_STORE) {
