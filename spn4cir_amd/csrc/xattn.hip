@@ -161,17 +161,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void xattn_head_contract_kernel(const 
 // re-staged per column tile from L2), keeps the NT x 32 fp32 accumulators per lane, and normalises in registers.
 // P [B, R, NT*128] bf16, zero in the columns >= S (the K extent of the P X product).
 // ----------------------------------------------------------------------------------------------------------------------------
-template <int NT, int WM>          // WM x 2 waves, 32 * WM rows per workgroup
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softmax_kernel(const bf16_t* __restrict__ Q,
-                                                                                         const bf16_t* __restrict__ X,
-                                                                                         bf16_t* __restrict__ P, int R, int S, int E,
-                                                                                         const int32_t* __restrict__ cu, int H) {
-    constexpr int BMW = 32 * WM, NW = 2 * WM;
+template <int NT, int WR, int WC, int MIW>     // WR x WC waves; a wave owns 16 * MIW rows and 128 / WC columns of every column tile
+__global__ __launch_bounds__(64 * WR * WC, 2) void xattn_scores_softmax_kernel(const bf16_t* __restrict__ Q,
+                                                                               const bf16_t* __restrict__ X,
+                                                                               bf16_t* __restrict__ P, int R, int S, int E,
+                                                                               const int32_t* __restrict__ cu, int H) {
+    constexpr int BMW = 16 * MIW * WR, NW = WR * WC, NJ = 8 / WC, WCOLS = 128 / WC;
     constexpr int A_BYTES = BMW * 128, STAGE = A_BYTES + TILE_BYTES;
     constexpr int GROUPS = BMW / 8 + 16;                                 // 8-row groups of one stage (A rows, then the 128 B rows)
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE, then 2 x BMW floats
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE, then WC x BMW floats
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar)
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WC, wc = wid % WC;
     const int tiles_r = (R + BMW - 1) / BMW;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = bid / tiles_r, m0 = (bid % tiles_r) * BMW;
@@ -181,15 +181,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softma
     if (m0 >= R) return;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(Q + r0 * E, (uint32_t)R * (uint32_t)E * 2u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(X + (size_t)b * S * E, (uint32_t)S * (uint32_t)E * 2u);
-    f32x4 acc[NT][2][4];
+    f32x4 acc[NT][MIW][NJ];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MIW; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = E / BK, total = nk * NT;
-    const bool live = m0 + wr * 32 < R;         // a wave whose 32 rows lie beyond the sample's end only helps with the staging
     int s_t = 0, s_k = 0;                       // (column tile, k tile) of the next stage request
     auto stage_next = [&](int buf) {
         char* dst = smem + buf * STAGE;
@@ -222,35 +221,33 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softma
             if (s + 2 < total) stage_next(buf >= 1 ? buf - 1 : 2);
             const char* sA = smem + buf * STAGE;
             const char* sB = sA + A_BYTES;
-            if (live) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 a[2], bb[4];
-                    const int c = ks * 4 + (lane >> 4);
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[MIW], bb[NJ];
+                const int c = ks * 4 + (lane >> 4);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a[i] = nt_frag(sA, wr * 32 + i * 16 + (lane & 15), c);
+                for (int i = 0; i < MIW; ++i) a[i] = nt_frag(sA, (wr * MIW + i) * 16 + (lane & 15), c);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bb[j] = nt_frag(sB, wc * 64 + j * 16 + (lane & 15), c);
+                for (int j = 0; j < NJ; ++j) bb[j] = nt_frag(sB, wc * WCOLS + j * 16 + (lane & 15), c);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MIW; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[t][i][j] = mfma16(bb[j], a[i], acc[t][i][j]);
-                }
+                    for (int j = 0; j < NJ; ++j) acc[t][i][j] = mfma16(bb[j], a[i], acc[t][i][j]);
             }
             buf = buf == 2 ? 0 : buf + 1;
         }
     }
-    // softmax over the row: a lane holds, of row (wr*32 + i*16 + lane&15), the columns t*128 + wc*64 + j*16 + (lane>>4)*4 + e
-    float* red = (float*)(smem + 3 * STAGE);                             // [2 wc][BMW rows]
-    float rsum[2];
+    // softmax over the row: a lane holds, of row ((wr*MIW + i)*16 + lane&15), the columns t*128 + wc*WCOLS + j*16 + (lane>>4)*4 + e
+    float* red = (float*)(smem + 3 * STAGE);                             // [WC][BMW rows]
+    float rsum[MIW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MIW; ++i) {
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = t * BN + wc * 64 + j * 16 + (lane >> 4) * 4;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = t * BN + wc * WCOLS + j * 16 + (lane >> 4) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (n + e >= S) acc[t][i][j][e] = -INFINITY;
@@ -259,18 +256,20 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softma
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (lane < 16) red[wc * BMW + wr * 32 + i * 16 + lane] = mx;
+        if (lane < 16) red[wc * BMW + (wr * MIW + i) * 16 + lane] = mx;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wr * 32 + i * 16 + (lane & 15);
-        const float mx = fmaxf(red[row], red[BMW + row]);
+    for (int i = 0; i < MIW; ++i) {
+        const int row = (wr * MIW + i) * 16 + (lane & 15);
+        float mx = red[row];
+#pragma unroll
+        for (int w = 1; w < WC; ++w) mx = fmaxf(mx, red[w * BMW + row]);
         float sm = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p = __expf(acc[t][i][j][e] - mx);
@@ -283,21 +282,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void xattn_scores_softma
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (lane < 16) red[wc * BMW + wr * 32 + i * 16 + lane] = rsum[i];
+    for (int i = 0; i < MIW; ++i)
+        if (lane < 16) red[wc * BMW + (wr * MIW + i) * 16 + lane] = rsum[i];
     __syncthreads();
     const int SP = NT * BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wr * 32 + i * 16 + (lane & 15);
+    for (int i = 0; i < MIW; ++i) {
+        const int row = (wr * MIW + i) * 16 + (lane & 15);
         const int m = m0 + row;
         if (m >= R) continue;
-        const float inv = 1.0f / (red[row] + red[BMW + row]);
-        bf16_t* o = P + (r0 + m) * SP + wc * 64 + (lane >> 4) * 4;
+        float sm = red[row];
+#pragma unroll
+        for (int w = 1; w < WC; ++w) sm += red[w * BMW + row];          // fixed order: every wave column gets the same sum
+        const float inv = 1.0f / sm;
+        bf16_t* o = P + (r0 + m) * SP + wc * WCOLS + (lane >> 4) * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const f32x4 v = acc[t][i][j] * inv;
                 *(bf16x4*)(o + t * BN + j * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             }
@@ -593,27 +595,27 @@ int xattn_head_contract(const bf16_t* A, const bf16_t* Wr, int row0, const float
     return SPN_OK;
 }
 
-template <int NT, int WM>
+template <int NT, int WR, int WC, int MIW>
 static int launch_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st,
                                  const int32_t* cu, int H) {
-    constexpr int BMW = 32 * WM;
-    constexpr int LDS = 3 * (BMW * 128 + TILE_BYTES) + 2 * BMW * 4;
-    static const int rc0 = xattn_lds(xattn_scores_softmax_kernel<NT, WM>, LDS);
+    constexpr int BMW = 16 * MIW * WR;
+    constexpr int LDS = 3 * (BMW * 128 + TILE_BYTES) + WC * BMW * 4;
+    static const int rc0 = xattn_lds(xattn_scores_softmax_kernel<NT, WR, WC, MIW>, LDS);
     if (rc0) return rc0;
     const int tiles = B * ((R + BMW - 1) / BMW);
-    hipLaunchKernelGGL((xattn_scores_softmax_kernel<NT, WM>), dim3(tiles), dim3(128 * WM), LDS, st, Q, X, P, R, S, E, cu, H);
+    hipLaunchKernelGGL((xattn_scores_softmax_kernel<NT, WR, WC, MIW>), dim3(tiles), dim3(64 * WR * WC), LDS, st, Q, X, P, R, S, E, cu, H);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
 
 int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st, const int32_t* cu,
                          int H) {
-    // Rows per workgroup: 64 (WM = 2: 4 waves, two workgroups per CU).  WM = 4 / 6 (128 / 192 rows, 8 / 12 waves, one workgroup per
-    // CU - the sample's X streamed once for two / three times the rows) measured the same or slower at config 4's shape:
-    // 123 / 127 / 137 us per launch (LABNOTES.md 5.8) - the k step is bound by the LDS round trips of a wave, not by the L2 stream.
+    // Rows per workgroup: 64 (2 x 2 waves of 32 x 64).  Measured alternatives at config 4's shape (LABNOTES.md 5.8): 128 / 192 rows
+    // (8 / 12 waves, one workgroup per CU, the sample's X streamed once for 2 / 3 x the rows) 127 / 137 us against 123; 48 rows
+    // (1 x 4 waves of 48 x 32, two exact rounds of 1 024 workgroups) 130 us dense / 103 packed against 121 / 108.
     ProfScope prof(PK_ATTN_FWD, 2.0 * B * R * (double)S * E, st);
-    if (xattn_sp(S) == 256) return launch_scores_softmax<2, 2>(Q, X, P, B, R, S, E, st, cu, H);
-    return launch_scores_softmax<5, 2>(Q, X, P, B, R, S, E, st, cu, H);
+    if (xattn_sp(S) == 256) return launch_scores_softmax<2, 2, 2, 2>(Q, X, P, B, R, S, E, st, cu, H);
+    return launch_scores_softmax<5, 2, 2, 2>(Q, X, P, B, R, S, E, st, cu, H);
 }
 
 int xattn_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const float* delta, bf16_t* dS, int B, int R, int S, int E,
