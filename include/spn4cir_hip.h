@@ -295,6 +295,12 @@ typedef struct {
      * under the causal mask (clip/model.py:330-336): they feed neither x[arange, argmax] (:356) nor any gradient,
      * so dropping them changes no output.  Use spn_text_fwd_packed(); the other calls take the same cfg. */
     int T;
+    /* pool != 0: the LAST block runs its row-wise half - out-projection, ln_2, MLP, and their backward with the three weight
+     * gradients - on the B pooled rows only.  clip/model.py:352-356 reads one row per caption (x[arange, argmax]) behind
+     * ln_final, so no other row of the last block's output reaches the feature or any gradient; the rows are computed by the
+     * same kernels, the result is that of the all-rows computation.  Forward and backward calls must agree on it; the token
+     * variants (spn_text_fwd_tokens / spn_text_bwd_tokens*), which need ln_final of every row, require 0. */
+    int pool;
 } spn_text_cfg;
 
 typedef struct {

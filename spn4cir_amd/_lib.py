@@ -18,7 +18,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 
 class TextCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "L", "L_ctx", "W", "H", "layers", "D", "vocab", "T")]
+    _fields_ = [(n, C.c_int) for n in ("B", "L", "L_ctx", "W", "H", "layers", "D", "vocab", "T", "pool")]
 
 
 class TextLayout(C.Structure):

@@ -331,7 +331,7 @@ int spn_topk_from_scores(const double* scores, int Nq, int Ng, int K, const int3
 static TextCfg tc(const spn_text_cfg* c) {
     TextCfg t;
     t.B = c->B; t.L = c->L; t.L_ctx = c->L_ctx; t.W = c->W; t.H = c->H; t.layers = c->layers; t.D = c->D;
-    t.vocab = c->vocab; t.T = c->T;
+    t.vocab = c->vocab; t.T = c->T; t.pool = c->pool;
     return t;
 }
 

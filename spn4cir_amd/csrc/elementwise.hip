@@ -794,6 +794,57 @@ int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_
     return SPN_OK;
 }
 
+// Pooled rows of the text tower's last block (tower.hip: text_last_block_fwd / _bwd): sample b's pooled row is
+// rows_abs[b] (packed layout) or b * L + eot[b] (dense).  gather: fp32 residual stream + bf16 attention output of those rows;
+// scatter: the two gradients back to their rows, zeros everywhere else (the [T, W] buffers are written completely).
+__global__ void gather_pool_rows_kernel(const float* __restrict__ x, const bf16_t* __restrict__ a, const int32_t* __restrict__ eot,
+                                        const int32_t* __restrict__ rows_abs, int L, float* __restrict__ xo,
+                                        bf16_t* __restrict__ ao, int W) {
+    const int b = blockIdx.x;
+    const size_t r = rows_abs ? (size_t)rows_abs[b] : (size_t)b * L + eot[b];
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
+        *(f32x4*)(xo + (size_t)b * W + c) = *(const f32x4*)(x + r * W + c);
+        *(bf16x4*)(ao + (size_t)b * W + c) = *(const bf16x4*)(a + r * W + c);
+    }
+}
+
+int gather_pool_rows(const float* x, const bf16_t* a, const int32_t* eot, const int32_t* rows_abs, int L, float* xo, bf16_t* ao,
+                     int B, int W, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_pool_rows_kernel, dim3(B), dim3(192), 0, st, x, a, eot, rows_abs, L, xo, ao, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
+__global__ void scatter_pool_rows_kernel(const float* __restrict__ de, const bf16_t* __restrict__ da, const int32_t* __restrict__ eot,
+                                         const int32_t* __restrict__ row_b, const int32_t* __restrict__ eot_row, int L,
+                                         float* __restrict__ dx, bf16_t* __restrict__ dattn, int T, int W) {
+    const int w4 = W >> 2;
+    const size_t total = (size_t)T * w4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / w4), c = (int)(i % w4) * 4;
+        const int b = row_b ? row_b[row] : row / L;
+        const bool hit = row_b ? row == eot_row[b] : row - b * L == eot[b];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bf16x4 g = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (hit) {
+            v = *(const f32x4*)(de + (size_t)b * W + c);
+            g = *(const bf16x4*)(da + (size_t)b * W + c);
+        }
+        *(f32x4*)(dx + (size_t)row * W + c) = v;
+        *(bf16x4*)(dattn + (size_t)row * W + c) = g;
+    }
+}
+
+int scatter_pool_rows(const float* de, const bf16_t* da, const int32_t* eot, const int32_t* row_b, const int32_t* eot_row, int L,
+                      float* dx, bf16_t* dattn, int T, int W, hipStream_t st) {
+    if (W % 4) return SPN_ERR_SHAPE;
+    hipLaunchKernelGGL(scatter_pool_rows_kernel, dim3(grid_for((size_t)T * (W / 4))), dim3(256), 0, st, de, da, eot, row_b, eot_row,
+                       L, dx, dattn, T, W);
+    SPN_CHECK_LAUNCH();
+    return SPN_OK;
+}
+
 // ---------------------------------------------------------------------------------- AdamW
 // torch.optim.AdamW semantics (decoupled weight decay), train_negplus.py:77-83.  g is
 // multiplied by inv_scale first (GradScaler unscale); the whole step is skipped when

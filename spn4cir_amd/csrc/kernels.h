@@ -148,6 +148,11 @@ int embed_bwd_packed(const int32_t* ids, const int32_t* row_b, const int32_t* ro
                      float* dtok, float* dpos, int T, int B, int L, int W, int vocab, float* ws, size_t ws_bytes,
                      hipStream_t st);
 int gather_rows_abs(const float* x, const int32_t* rows, float* out, int B, int W, hipStream_t st);
+// pooled rows of the text tower's last block: row(b) = rows_abs ? rows_abs[b] : b * L + eot[b]
+int gather_pool_rows(const float* x, const bf16_t* a, const int32_t* eot, const int32_t* rows_abs, int L, float* xo, bf16_t* ao,
+                     int B, int W, hipStream_t st);
+int scatter_pool_rows(const float* de, const bf16_t* da, const int32_t* eot, const int32_t* row_b, const int32_t* eot_row, int L,
+                      float* dx, bf16_t* dattn, int T, int W, hipStream_t st);
 int scatter_rows_abs(const float* src, const int32_t* row_b, const int32_t* eot_row, float* dx, bf16_t* dx_bf16, int T,
                      int W, hipStream_t st);
 int adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,

@@ -43,6 +43,7 @@ struct BlockActs {
 struct TextCfg {       // == spn_text_cfg
     int B, L, L_ctx, W, H, layers, D, vocab;
     int T;             // packed live rows (sum of the sequence lengths), 0 = dense B*L rows
+    int pool;          // != 0: the last block runs its out-projection / MLP on the B pooled (EOT) rows only (tower.hip)
 };
 
 struct TextLayout {    // == spn_text_layout_t (element offsets)

@@ -181,9 +181,11 @@ static int aux_grad_on() {
 // consuming LayerNorm overwrites in place: the out-projection's in A.h2, c_proj's in the NEXT block's h1 (y_out).
 //   x_prev != nullptr: A.h1 holds the previous block's c_proj result; x_in = x_prev + it is formed here.
 //   y_out  != nullptr: c_proj stores bf16 there instead of x_out = x_mid + result.
-int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st, const float* x_prev, bf16_t* y_out) {
+// first half of a block: ln_1 (+ the previous block's deferred residual), the qkv projection and the attention - everything
+// that mixes rows; what follows it (out-projection, ln_2, MLP) is row-wise
+static int block_fwd_attn(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st, const float* x_prev) {
     const int T = c.rows(), W = c.W;
-    if ((x_prev || y_out) && !c.fuse_resid) return SPN_ERR_ARG;
+    if (x_prev && !c.fuse_resid) return SPN_ERR_ARG;
     if (x_prev) SPN_TRY(layernorm_fwd_add(x_prev, A.h1, P.ln1_g, P.ln1_b, A.x_in, A.h1, A.mean1, A.rstd1, T, W, c.eps, st));
     else SPN_TRY(layernorm_fwd(A.x_in, P.ln1_g, P.ln1_b, A.h1, nullptr, A.mean1, A.rstd1, T, W, c.eps, st));
     {
@@ -200,6 +202,13 @@ int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipSt
         a.scale = 0.125f;
         SPN_TRY(attention_fwd(a, st));
     }
+    return SPN_OK;
+}
+
+int block_fwd(const BlockCfg& c, const BlockParams& P, const BlockActs& A, hipStream_t st, const float* x_prev, bf16_t* y_out) {
+    const int T = c.rows(), W = c.W;
+    if ((x_prev || y_out) && !c.fuse_resid) return SPN_ERR_ARG;
+    SPN_TRY(block_fwd_attn(c, P, A, st, x_prev));
     if (c.fuse_resid) {
         GemmEpilogue e;
         e.bias = P.b_o; e.out_bf16 = A.h2; e.ldc = W;
@@ -399,7 +408,24 @@ struct TextActs {
     float* e;
     float *mean_f, *rstd_f;
     bf16_t* ln_e;
+    float* pool_xin;           // [B, W] the last block's residual stream at the pooled rows (pooled last block)
+    bf16_t* pool_attn;         // [B, W] its attention output at the pooled rows
 };
+
+// Pooled last block (TextCfg.pool; SPN_POOL_LAST=0 switches it off whatever the caller asks for).  CLIP pools ONE row per
+// caption - x[arange, argmax(ids)] behind ln_final (clip/model.py:352-356) - so of the LAST block only that row's output is
+// ever read, and everything behind its attention is row-wise: the out-projection, ln_2 and the MLP (9 of the block's 12 W^2
+// multiply-adds per token, forward and backward, and their three weight gradients) run on the B pooled rows instead of the
+// B x L (or packed T) rows; the backward scatters the two gradients that re-enter the all-rows part (residual stream,
+// attention output) and continues there.  Same kernels on the same rows: the features and gradients are those of the
+// all-rows computation up to the summation order of the three weight gradients (B rows instead of T, of which T - B were zero).
+static bool text_pooled(const TextCfg& c) {
+    static const bool off = [] {
+        const char* e = spn_env("SPN_POOL_LAST");
+        return e && e[0] == '0';
+    }();
+    return c.pool != 0 && !off;
+}
 
 size_t text_act_bytes(const TextCfg& c) {
     const BlockCfg bc = text_block_cfg(c);
@@ -410,6 +436,7 @@ size_t text_act_bytes(const TextCfg& c) {
     b += align256((size_t)c.B * c.W * 4);
     b += 2 * align256((size_t)c.B * 4);
     b += align256((size_t)c.B * c.W * 2);
+    b += align256((size_t)c.B * c.W * 4) + align256((size_t)c.B * c.W * 2);      // pool_xin, pool_attn
     return b;
 }
 
@@ -431,6 +458,8 @@ static TextActs text_acts_at(char* base, const TextCfg& c) {
     A.mean_f = (float*)take((size_t)c.B * 4);
     A.rstd_f = (float*)take((size_t)c.B * 4);
     A.ln_e = (bf16_t*)take((size_t)c.B * c.W * 2);
+    A.pool_xin = (float*)take((size_t)c.B * c.W * 4);
+    A.pool_attn = (bf16_t*)take((size_t)c.B * c.W * 2);
     return A;
 }
 
@@ -487,6 +516,7 @@ size_t text_ws_bytes(const TextCfg& c) {
     b += align256((size_t)c.B * c.D * 2);    // dfeats bf16
     b += align256((size_t)c.B * c.W * 4);    // dln_e
     b += align256((size_t)c.B * c.W * 4);    // de
+    b += align256((size_t)c.B * 4 * c.W * 2) + 4 * align256((size_t)c.B * c.W * 2);   // pooled last block: dpre, de / dh / dx_mid / dattn (bf16, B rows)
     // per-layer dY operands of the deferred weight gradients (9 T W bf16 + LayerNorm partials per block: 3.3 GB for
     // ViT-L/14 text at B = 256, linear in the batch); absent when the deferred path is switched off (SPN_TN_GROUP=0:
     // spn_text_bwd_layer_deferred / spn_text_bwd_wgrad then return SPN_ERR_WORKSPACE, spn_text_bwd_layer needs none)
@@ -519,6 +549,34 @@ int text_refresh_bf16(const TextCfg& c, const float* params, bf16_t* wb, hipStre
     return SPN_OK;
 }
 
+// The last block with its row-wise half on the pooled rows only (text_pooled): A.e = the block output at the pooled rows.
+static int text_last_block_fwd(const TextCfg& c, const BlockCfg& bc, const BlockParams& P, const BlockActs& a, const TextActs& A,
+                               const float* x_prev, hipStream_t st) {
+    const int B = c.B, W = c.W;
+    SPN_TRY(block_fwd_attn(bc, P, a, st, x_prev));
+    SPN_TRY(gather_pool_rows(a.x_in, a.attn, A.eot, c.T > 0 ? A.eot_row : nullptr, c.L, A.pool_xin, A.pool_attn, B, W, st));
+    // from here on the first B rows of the block's own buffers (x_mid, h2, pre, u, mean2, rstd2) hold the pooled rows
+    if (bc.fuse_resid) {
+        GemmEpilogue e;
+        e.bias = P.b_o; e.out_bf16 = a.h2; e.ldc = W;
+        SPN_TRY(gemm_nt(A.pool_attn, P.w_o, B, W, W, W, W, GEMM_STORE, e, st));
+        SPN_TRY(layernorm_fwd_add(A.pool_xin, a.h2, P.ln2_g, P.ln2_b, a.x_mid, a.h2, a.mean2, a.rstd2, B, W, bc.eps, st));
+    } else {
+        GemmEpilogue e;
+        e.bias = P.b_o; e.resid = A.pool_xin; e.ldr = W; e.out_f32 = a.x_mid; e.ldc = W;
+        SPN_TRY(gemm_nt(A.pool_attn, P.w_o, B, W, W, W, W, GEMM_RESID, e, st));
+        SPN_TRY(layernorm_fwd(a.x_mid, P.ln2_g, P.ln2_b, a.h2, nullptr, a.mean2, a.rstd2, B, W, bc.eps, st));
+    }
+    {
+        GemmEpilogue e;
+        e.bias = P.b_fc; e.act = bc.act; e.aux_out = a.pre; e.aux_grad = aux_grad_on(); e.out_bf16 = a.u; e.ldc = 4 * W;
+        SPN_TRY(gemm_nt(a.h2, P.w_fc, B, 4 * W, W, W, W, GEMM_STORE, e, st));
+    }
+    GemmEpilogue e;
+    e.bias = P.b_proj; e.resid = a.x_mid; e.ldr = W; e.out_f32 = A.e; e.ldc = W;
+    return gemm_nt(a.u, P.w_proj, B, W, 4 * W, 4 * W, 4 * W, GEMM_RESID, e, st);
+}
+
 int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, const int32_t* cu_seqlens,
              char* acts, float* feats, hipStream_t st) {
     SPN_TRY(text_check(c));
@@ -539,6 +597,7 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
         SPN_TRY(embed_fwd(ids, params + t.tok, params + t.pos, first.x_in, c.B, c.L, c.W, c.vocab, st));
     }
     bc.fuse_resid = fuse_resid_on();
+    const bool pooled = text_pooled(c);
     const float* x_prev = nullptr;             // fuse_resid: the previous block's x_mid, its c_proj result waits in a.h1
     for (int l = 0; l < c.layers; ++l) {
         BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
@@ -546,12 +605,17 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
         BlockActs nxt = last ? a : block_acts_at(A.blocks + A.block_bytes * (l + 1), bc);
         a.x_out = last ? A.x_final : nxt.x_in;
         const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
+        if (last && pooled) {
+            SPN_TRY(text_last_block_fwd(c, bc, P, a, A, x_prev, st));
+            break;
+        }
         // the last block's c_proj keeps its fp32 residual epilogue: x_final is read row-wise by the pooling below
         SPN_TRY(block_fwd(bc, P, a, st, x_prev, (bc.fuse_resid && !last) ? nxt.h1 : nullptr));
         x_prev = (bc.fuse_resid && !last) ? a.x_mid : nullptr;
     }
     // ln_final is per-row, so pooling the EOT row first is identical to clip/model.py:352-356
-    if (c.T > 0) SPN_TRY(gather_rows_abs(A.x_final, A.eot_row, A.e, c.B, c.W, st));
+    if (pooled) {}                                    // A.e is the last block's output at the pooled rows already
+    else if (c.T > 0) SPN_TRY(gather_rows_abs(A.x_final, A.eot_row, A.e, c.B, c.W, st));
     else SPN_TRY(gather_rows_f32(A.x_final, A.eot, A.e, c.B, c.L, c.W, st));
     SPN_TRY(layernorm_fwd(A.e, params + t.lnf_g, params + t.lnf_b, A.ln_e, nullptr, A.mean_f, A.rstd_f, c.B, c.W, 1e-5f,
                           st));
@@ -566,7 +630,7 @@ int text_fwd(const TextCfg& c, const float* params, const bf16_t* wb, const int3
 // after the EOT token are live here.
 int text_fwd_tokens(const TextCfg& c, const float* params, const bf16_t* wb, const int32_t* ids, char* acts, float* feats,
                     float* tokens, bf16_t* tokens_bf16, float* tok_mean, float* tok_rstd, hipStream_t st) {
-    if (c.T > 0) return SPN_ERR_ARG;
+    if (c.T > 0 || c.pool) return SPN_ERR_ARG;      // ln_final of EVERY row: the last block cannot be pooled
     SPN_TRY(text_fwd(c, params, wb, ids, nullptr, acts, feats, st));
     TextLayout t;
     text_layout(c, &t);
@@ -585,6 +649,7 @@ struct TextBwdWs {
     size_t ws2_bytes;
     bf16_t* dfb;
     float *dln, *de;
+    bf16_t *p_dpre, *p_deb, *p_dh, *p_dxm, *p_dattn;      // pooled last block, B rows each
     char* defer;               // layers x text_defer_layer_bytes
     size_t defer_stride;
     float* opws;
@@ -619,6 +684,11 @@ static int text_bwd_ws(const TextCfg& c, char* ws, size_t ws_bytes, TextBwdWs* w
     w->dfb = (bf16_t*)take((size_t)c.B * c.D * 2);
     w->dln = (float*)take((size_t)c.B * c.W * 4);
     w->de = (float*)take((size_t)c.B * c.W * 4);
+    w->p_dpre = (bf16_t*)take((size_t)c.B * 4 * c.W * 2);
+    w->p_deb = (bf16_t*)take((size_t)c.B * c.W * 2);
+    w->p_dh = (bf16_t*)take((size_t)c.B * c.W * 2);
+    w->p_dxm = (bf16_t*)take((size_t)c.B * c.W * 2);
+    w->p_dattn = (bf16_t*)take((size_t)c.B * c.W * 2);
     w->defer_stride = text_defer_layer_bytes(bc);
     w->defer = tn_group_on() ? p : nullptr;
     p += w->defer_stride * (tn_group_on() ? c.layers : 0);
@@ -645,9 +715,79 @@ int text_bwd_head(const TextCfg& c, const float* params, const bf16_t* wb, char*
     }
     SPN_TRY(layernorm_bwd(nullptr, w.dln, A.e, params + t.lnf_g, A.mean_f, A.rstd_f, w.de, 0, nullptr, grads + t.lnf_g,
                           grads + t.lnf_b, 0, c.B, c.W, w.opws, w.opws_bytes, st));
+    if (text_pooled(c)) return SPN_OK;          // the last block takes w.de as it is (text_last_block_bwd scatters behind its MLP)
     if (c.T > 0) SPN_TRY(scatter_rows_abs(w.de, A.row_b, A.eot_row, w.dx, w.dxb, c.T, c.W, st));
     else SPN_TRY(scatter_rows_f32(w.de, A.eot, w.dx, w.dxb, c.B, c.L, c.W, st));
     return SPN_OK;
+}
+
+// Backward of text_last_block_fwd.  In: w.de = gradient w.r.t. the pooled rows of the block output [B, W].  The row-wise half
+// runs on the B pooled rows with its three weight gradients finished on the spot (reduction over B rows); then the residual and
+// attention-output gradients are scattered to their rows (zeros elsewhere) and the attention half runs over all rows.
+// `defer` != null: the qkv weight gradient and ln_1's parameter gradients are left to text_bwd_wgrad (dqkv and the row
+// partials stay in the layer's deferred buffers); dx_out = the bf16 gradient leaving the block.
+static int text_last_block_bwd(const TextCfg& c, const BlockCfg& bc, const BlockParams& P, const BlockActs& a, const BlockGrads& G,
+                               const TextActs& A, const TextBwdWs& w, const TextDeferBufs* defer, bf16_t* dx_out, hipStream_t st) {
+    const int B = c.B, W = c.W, T = bc.rows();
+    const size_t Ts = (size_t)T;
+    char* p = w.scratch;
+    auto take = [&](size_t bytes) { char* r = p; p += align256(bytes); return r; };
+    take(Ts * 4 * W * 2);                                     // dpre of the all-rows form: unused here
+    bf16_t* dh = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dattn = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
+    float* delta = (float*)take((size_t)c.B * c.H * c.L * 4);
+    if (defer) dqkv = defer->dqkv;
+    // ---- row-wise half on the pooled rows
+    SPN_TRY(cast_f32_bf16(w.de, w.p_deb, (size_t)B * W, st));
+    {
+        GemmEpilogue e;
+        e.aux_in = a.pre; e.aux_grad = aux_grad_on(); e.act = bc.act; e.out_bf16 = w.p_dpre; e.ldc = 4 * W;
+        SPN_TRY(gemm_nt(w.p_deb, P.w_proj_t, B, 4 * W, W, W, W, GEMM_DACT, e, st));
+    }
+    SPN_TRY(gemm_tn(w.p_deb, a.u, B, W, 4 * W, W, 4 * W, G.w_proj, 4 * W, 1.0f, 0, G.b_proj, w.opws, w.opws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_bf16 = w.p_dh; e.ldc = W;
+        SPN_TRY(gemm_nt(w.p_dpre, P.w_fc_t, B, W, 4 * W, 4 * W, 4 * W, GEMM_STORE, e, st));
+    }
+    SPN_TRY(gemm_tn(w.p_dpre, a.h2, B, 4 * W, W, 4 * W, W, G.w_fc, W, 1.0f, 0, G.b_fc, w.opws, w.opws_bytes, st));
+    SPN_TRY(layernorm_bwd(w.p_dh, nullptr, a.x_mid, P.ln2_g, a.mean2, a.rstd2, w.de, 1, w.p_dxm, G.ln2_g, G.ln2_b, 0, B, W, w.opws,
+                          w.opws_bytes, st));
+    {
+        GemmEpilogue e;
+        e.out_bf16 = w.p_dattn; e.ldc = W;
+        SPN_TRY(gemm_nt(w.p_dxm, P.w_o_t, B, W, W, W, W, GEMM_STORE, e, st));
+    }
+    SPN_TRY(gemm_tn(w.p_dxm, A.pool_attn, B, W, W, W, W, G.w_o, W, 1.0f, 0, G.b_o, w.opws, w.opws_bytes, st));
+    // ---- back to all rows
+    SPN_TRY(scatter_pool_rows(w.de, w.p_dattn, A.eot, c.T > 0 ? A.row_b : nullptr, A.eot_row, c.L, w.dx, dattn, T, W, st));
+    {
+        AttnBwdArgs g;
+        AttnArgs& q = g.f;
+        q.q = a.qkv; q.k = a.qkv + W; q.v = a.qkv + 2 * W;
+        q.ldq = q.ldk = q.ldv = 3 * W;
+        q.o = a.attn; q.ldo = W; q.lse = a.lse; q.key_bias = nullptr;
+        q.B = bc.B; q.H = bc.H; q.Lq = bc.L; q.Lk = bc.L; q.causal = bc.causal; q.cu = bc.cu;
+        q.scale = 0.125f;
+        g.d_o = dattn; g.lddo = W;
+        g.dq = dqkv; g.dk = dqkv + W; g.dv = dqkv + 2 * W;
+        g.lddq = g.lddk = g.lddv = 3 * W;
+        g.delta = delta;
+        SPN_TRY(attention_bwd(g, st));
+    }
+    {
+        GemmEpilogue e;
+        e.out_bf16 = dh; e.ldc = W;
+        SPN_TRY(gemm_nt(dqkv, P.w_qkv_t, T, W, 3 * W, 3 * W, 3 * W, GEMM_STORE, e, st));
+    }
+    const size_t lnp = layernorm_bwd_workspace_bytes(T, W);
+    if (defer)
+        return layernorm_bwd(dh, nullptr, a.x_in, P.ln1_g, a.mean1, a.rstd1, w.dx, 1, dx_out, G.ln1_g, G.ln1_b, 2, T, W,
+                             (float*)((char*)defer->ln_partials + lnp), lnp, st);
+    SPN_TRY(gemm_tn(dqkv, a.h1, T, 3 * W, W, 3 * W, W, G.w_qkv, W, 1.0f, 0, G.b_qkv, w.opws, w.opws_bytes, st));
+    return layernorm_bwd(dh, nullptr, a.x_in, P.ln1_g, a.mean1, a.rstd1, w.dx, 1, dx_out, G.ln1_g, G.ln1_b, 0, T, W, w.opws,
+                         w.opws_bytes, st);
 }
 
 // phase 2 (layers-1 .. 0): one residual block; its parameter gradients are final on return
@@ -665,12 +805,14 @@ int text_bwd_layer(const TextCfg& c, const float* params, const bf16_t* wb, char
     BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
     const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
+    if (l == c.layers - 1 && text_pooled(c)) return text_last_block_bwd(c, bc, P, a, G, A, w, nullptr, w.dxb, st);
     BwdOverlap ovs;
     const BwdOverlap* ov = bwd_overlap(w.dxb2, w.ws2, w.ws2_bytes, &ovs);
     return block_bwd(bc, P, a, G, w.dx, w.dxb, w.scratch, w.opws, w.opws_bytes, st, ov, w.dxb2);
 }
 
 // phase 2, deferred: the block's data path only; its four weight-gradient products are left to text_bwd_wgrad
+// (returns the number of problems written)
 static int text_defer_problems(const TextCfg& c, const TextBwdWs& w, const BlockCfg& bc, const TextActs& A, float* grads,
                                const TextLayout& t, int l, TnProblem* q) {
     const int W = c.W;
@@ -678,11 +820,15 @@ static int text_defer_problems(const TextCfg& c, const TextBwdWs& w, const Block
     const BlockActs a = block_acts_at(A.blocks + A.block_bytes * l, bc);
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
     const bf16_t* dx_in = (l == c.layers - 1) ? w.dxb : d.dx_in;
+    if (l == c.layers - 1 && text_pooled(c)) {        // the pooled last block owes the qkv product only
+        q[0] = TnProblem{d.dqkv, a.h1, G.w_qkv, G.b_qkv, 3 * W, W, 3 * W, W, W};
+        return 1;
+    }
     q[0] = TnProblem{dx_in, a.u, G.w_proj, G.b_proj, W, 4 * W, W, 4 * W, 4 * W};
     q[1] = TnProblem{d.dpre, a.h2, G.w_fc, G.b_fc, 4 * W, W, 4 * W, W, W};
     q[2] = TnProblem{d.dqkv, a.h1, G.w_qkv, G.b_qkv, 3 * W, W, 3 * W, W, W};
     q[3] = TnProblem{d.dx_mid, a.attn, G.w_o, G.b_o, W, W, W, W, W};
-    return SPN_OK;
+    return 4;
 }
 
 int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, float* grads, int l,
@@ -701,6 +847,8 @@ int text_bwd_layer_deferred(const TextCfg& c, const float* params, const bf16_t*
     const BlockParams P = block_params_at(params + t.blocks + t.block_size * l, wb + t.bf16_block_size * l, c.W);
     const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
     const TextDeferBufs d = text_defer_at(w, bc, l);
+    if (l == c.layers - 1 && text_pooled(c))
+        return text_last_block_bwd(c, bc, P, a, G, A, w, &d, l > 0 ? text_defer_at(w, bc, l - 1).dx_in : w.dxb2, st);
     TnProblem unused[4];
     BwdDefer df;
     df.dpre = d.dpre; df.dqkv = d.dqkv; df.dx_mid = d.dx_mid; df.ln_partials = d.ln_partials;
@@ -723,7 +871,7 @@ int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int 
     TextActs A = text_acts_at(acts, c);
     TnProblem q[TN_GROUP_MAX];
     int n = 0;
-    for (int l = l_end - 1; l >= l_begin; --l, n += 4) SPN_TRY(text_defer_problems(c, w, bc, A, grads, t, l, q + n));
+    for (int l = l_end - 1; l >= l_begin; --l) n += text_defer_problems(c, w, bc, A, grads, t, l, q + n);
     SPN_TRY(gemm_tn_grouped(q, n, bc.rows(), w.opws, w.opws_bytes, st));
     // the LayerNorm parameter gradients of the same blocks: one batched fold of their row partials ([dgamma | dbeta] are
     // adjacent in the flat gradient layout)
@@ -736,7 +884,9 @@ int text_bwd_wgrad(const TextCfg& c, char* acts, float* grads, int l_begin, int 
         const TextDeferBufs d = text_defer_at(w, bc, l);
         const BlockGrads G = block_grads_at(grads + t.blocks + t.block_size * l, c.W);
         if (G.ln2_b != G.ln2_g + c.W || G.ln1_b != G.ln1_g + c.W) return SPN_ERR_ARG;
-        fb.ws[fb.items] = d.ln_partials; fb.out[fb.items++] = G.ln2_g;
+        if (!(l == c.layers - 1 && text_pooled(c))) {          // the pooled last block finished ln_2's gradients itself
+            fb.ws[fb.items] = d.ln_partials; fb.out[fb.items++] = G.ln2_g;
+        }
         fb.ws[fb.items] = (const float*)((const char*)d.ln_partials + lnp); fb.out[fb.items++] = G.ln1_g;
         if (fb.items + 2 > FOLD_BATCH_MAX || l == l_begin) {
             SPN_TRY(fold_rows_batched(fb, st));
@@ -780,7 +930,7 @@ int text_bwd_tail(const TextCfg& c, const int32_t* ids, char* acts, float* grads
 int text_bwd_tokens_head(const TextCfg& c, const float* params, const bf16_t* wb, char* acts, const float* dfeats,
                          const float* dtokens, const float* tok_mean, const float* tok_rstd, float* grads, char* ws,
                          size_t ws_bytes, hipStream_t st) {
-    if (c.T > 0) return SPN_ERR_ARG;
+    if (c.T > 0 || c.pool) return SPN_ERR_ARG;
     SPN_TRY(text_bwd_head(c, params, wb, acts, dfeats, grads, ws, ws_bytes, st));
     TextBwdWs w;
     SPN_TRY(text_bwd_ws(c, ws, ws_bytes, &w));

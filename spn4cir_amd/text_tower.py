@@ -51,7 +51,10 @@ class TextTower:
 
     # ------------------------------------------------------------------ layout
     def _cfg(self, B, L, T=0):
-        return _lib.TextCfg(B, L, self.ctx, self.width, self.heads, self.layers, self.embed_dim, self.vocab, T)
+        # pool: the last block's row-wise half on the pooled (EOT) rows only (spn_text_cfg.pool) - on for the feature path
+        # (forward / backward*), off for forward_tokens, whose ln_final reads every row; a backward uses its forward's setting
+        return _lib.TextCfg(B, L, self.ctx, self.width, self.heads, self.layers, self.embed_dim, self.vocab, T,
+                            getattr(self, "_pool", 1))
 
     def spans(self):
         """[(clip state-dict key, offset, shape)] in flat-buffer order."""
@@ -156,6 +159,7 @@ class TextTower:
         if self.is_stale():
             self.refresh()
         T = int(total_rows) if cu_seqlens is not None else 0
+        self._pool = 1
         cfg = self._buffers(B, L, False, T)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         if cu_seqlens is not None:
@@ -204,6 +208,7 @@ class TextTower:
         B, L = ids.shape
         if self.is_stale():
             self.refresh()
+        self._pool = 0
         cfg = self._buffers(B, L, False, 0)
         feats = torch.empty(B, self.embed_dim, dtype=torch.float32, device=self.device)
         tokens = torch.empty(B, L, self.width, dtype=torch.float32, device=self.device)
