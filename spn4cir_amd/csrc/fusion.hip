@@ -68,6 +68,19 @@ static int fusion_rows(const FusionCfg& c) { return c.T > 0 ? c.T : c.B * c.L; }
 static size_t fusion_the(const FusionCfg& c) { return (size_t)fusion_rows(c) * c.H * c.E; }                // elements of [T, H, E]
 static size_t fusion_rsp(const FusionCfg& c) { return (size_t)fusion_rows(c) * c.H * xattn_sp(c.S); }      // elements of [T*H, SP]
 
+// Pooled last layer (SPN_POOL_LAST=0 switches it off): blip_cir.py:98 reads ONE row of the encoder output - the [ENC] position -
+// so of the LAST layer only that row is needed, and everything behind its self-attention is row-wise or attends over the image
+// tokens only: the self-attention output projection, the whole cross-attention (H query rows per sample), both LayerNorms and
+// the FFN run on the B [ENC] rows; the backward scatters the two gradients that re-enter the all-rows part (residual stream,
+// self-attention context) and continues there.  Needs the absorbed cross-attention (its kernels take any row count per sample).
+static bool fusion_pool_last(const FusionCfg& c) {
+    static const bool off = [] {
+        const char* e = spn_env("SPN_POOL_LAST");
+        return e && e[0] == '0';
+    }();
+    return !off && fusion_absorb(c);
+}
+
 int fusion_packed_ok(const FusionCfg& c) { return c.L <= 128 && fusion_absorb(c) ? 1 : 0; }
 
 static int fusion_check(const FusionCfg& c) {
@@ -129,6 +142,7 @@ struct FusionActs {
     char* layers; size_t layer_bytes;
     float* x_final; bf16_t* xb_final;           // output of the last layer
     float* h0; bf16_t* h0b;                     // [B, W] the [ENC] rows
+    float* pool_x; bf16_t* pool_ctx;            // [B, W] pooled last layer: residual stream / self-attention context at the [ENC] rows
     float* proj;                                // [B, Dp] text_proj output (pre-normalise)
 };
 
@@ -175,6 +189,7 @@ size_t fusion_act_bytes(const FusionCfg& c) {
     if (c.T > 0) b += fa((size_t)(c.B + 1) * 4) + 2 * fa(T * 4);
     b += fusion_layer_act_bytes(c) * c.layers;
     b += fa(T * W * 4) + fa(T * W * 2) + fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2) + fa((size_t)c.B * c.Dp * 4);
+    b += fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2);          // pool_x, pool_ctx
     return b;
 }
 
@@ -201,6 +216,8 @@ static FusionActs fusion_acts_at(char* base, const FusionCfg& c) {
     A.h0 = (float*)take((size_t)c.B * W * 4);
     A.h0b = (bf16_t*)take((size_t)c.B * W * 2);
     A.proj = (float*)take((size_t)c.B * c.Dp * 4);
+    A.pool_x = (float*)take((size_t)c.B * W * 4);
+    A.pool_ctx = (bf16_t*)take((size_t)c.B * W * 2);
     return A;
 }
 
@@ -259,7 +276,7 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
     fusion_layout(c, &t);
     FusionActs A = fusion_acts_at(acts, c);
     const int T = fusion_rows(c), TS = c.B * c.S, W = c.W, I = c.I, E = c.E;
-    const bool absorb = fusion_absorb(c);
+    const bool absorb = fusion_absorb(c), pool_last = fusion_pool_last(c);
     const bool packed = c.T > 0;
     if (packed) {
         if (!mask) return SPN_ERR_ARG;                   // packed: the mask argument carries cu_seqlens int32 [B + 1]
@@ -293,31 +310,45 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
         // self-attention (med.py BertSelfAttention + BertSelfOutput)
         SPN_TRYF(nt(a.xb_in, Bw(BO_SA_WQKV), T, 3 * W, W, P(LO_SA_BQKV), a.qkv, nullptr, st));
         SPN_TRYF(attention_fwd(self_attn_args(c, a, A.key_bias, A.cu), st));
-        SPN_TRYF(nt_resid(a.ctx1, Bw(BO_SA_WO), T, W, W, P(LO_SA_BO), a.x_in, a.y1, st));
-        SPN_TRYF(layernorm_fwd(a.y1, P(LO_SA_LNG), P(LO_SA_LNB), a.x1b, a.x1, a.mean1, a.rstd1, T, W, 1e-12f, st));
+        // from here on a layer is row-wise (or attends over the image tokens): the pooled last layer continues on the [ENC] rows,
+        // one per sample, in the first B rows of its own buffers
+        const bool pl = pool_last && l + 1 == c.layers;
+        const int Tn = pl ? c.B : T, Rn = pl ? c.H : c.L * c.H;
+        const int32_t* cun = pl ? nullptr : A.cu;
+        const float* x_in = a.x_in;
+        const bf16_t* ctx1 = a.ctx1;
+        if (pl) {
+            SPN_TRYF(gather_pool_rows(a.x_in, a.ctx1, A.zero_idx, packed ? A.cu : nullptr, c.L, A.pool_x, A.pool_ctx, c.B, W, st));
+            x_in = A.pool_x; ctx1 = A.pool_ctx;
+        }
+        SPN_TRYF(nt_resid(ctx1, Bw(BO_SA_WO), Tn, W, W, P(LO_SA_BO), x_in, a.y1, st));
+        SPN_TRYF(layernorm_fwd(a.y1, P(LO_SA_LNG), P(LO_SA_LNB), a.x1b, a.x1, a.mean1, a.rstd1, Tn, W, 1e-12f, st));
         // cross-attention over the image tokens
-        SPN_TRYF(nt(a.x1b, Bw(BO_CA_WQ), T, W, W, P(LO_CA_BQ), a.q2, nullptr, st));
+        SPN_TRYF(nt(a.x1b, Bw(BO_CA_WQ), Tn, W, W, P(LO_CA_BQ), a.q2, nullptr, st));
         if (absorb) {
             // scores = (0.125 q_h Wk_h) X^T, ctx_h = (softmax X) Wv_h^T + bv_h: K and V are never formed (xattn.hip)
-            SPN_TRYF(xattn_head_expand(a.q2, W, Bw(BO_CA_WKV_T), 2 * W, 0, a.qa, T, c.H, E, 0.125f, st));
-            SPN_TRYF(xattn_scores_softmax(a.qa, A.enc_b, a.pm, c.B, c.L * c.H, c.S, E, st, A.cu, c.H));
-            SPN_TRYF(xattn_apply(a.pm, A.enc_b, a.oa, c.B, c.L * c.H, c.S, E, st, A.cu, c.H));
-            SPN_TRYF(xattn_head_contract(a.oa, Bw(BO_CA_WKV), W, P(LO_CA_BKV), a.ctx2, W, T, c.H, E, 1.0f, st));
+            SPN_TRYF(xattn_head_expand(a.q2, W, Bw(BO_CA_WKV_T), 2 * W, 0, a.qa, Tn, c.H, E, 0.125f, st));
+            SPN_TRYF(xattn_scores_softmax(a.qa, A.enc_b, a.pm, c.B, Rn, c.S, E, st, cun, c.H));
+            SPN_TRYF(xattn_apply(a.pm, A.enc_b, a.oa, c.B, Rn, c.S, E, st, cun, c.H));
+            SPN_TRYF(xattn_head_contract(a.oa, Bw(BO_CA_WKV), W, P(LO_CA_BKV), a.ctx2, W, Tn, c.H, E, 1.0f, st));
         } else {
             SPN_TRYF(nt(A.enc_b, Bw(BO_CA_WKV), TS, 2 * W, E, P(LO_CA_BKV), a.kv2, nullptr, st));
             SPN_TRYF(attention_fwd(cross_attn_args(c, a), st));
         }
-        SPN_TRYF(nt_resid(a.ctx2, Bw(BO_CA_WO), T, W, W, P(LO_CA_BO), a.x1, a.y2, st));
-        SPN_TRYF(layernorm_fwd(a.y2, P(LO_CA_LNG), P(LO_CA_LNB), a.x2b, a.x2, a.mean2, a.rstd2, T, W, 1e-12f, st));
+        SPN_TRYF(nt_resid(a.ctx2, Bw(BO_CA_WO), Tn, W, W, P(LO_CA_BO), a.x1, a.y2, st));
+        SPN_TRYF(layernorm_fwd(a.y2, P(LO_CA_LNG), P(LO_CA_LNB), a.x2b, a.x2, a.mean2, a.rstd2, Tn, W, 1e-12f, st));
         // feed-forward (BertIntermediate exact GELU + BertOutput)
-        SPN_TRYF(nt(a.x2b, Bw(BO_FF_W1), T, I, W, P(LO_FF_B1), a.u, nullptr, st, ACT_GELU_ERF, a.pre));
-        SPN_TRYF(nt_resid(a.u, Bw(BO_FF_W2), T, W, I, P(LO_FF_B2), a.x2, a.y3, st));
-        SPN_TRYF(layernorm_fwd(a.y3, P(LO_FF_LNG), P(LO_FF_LNB), xb_out, x_out, a.mean3, a.rstd3, T, W, 1e-12f, st));
+        SPN_TRYF(nt(a.x2b, Bw(BO_FF_W1), Tn, I, W, P(LO_FF_B1), a.u, nullptr, st, ACT_GELU_ERF, a.pre));
+        SPN_TRYF(nt_resid(a.u, Bw(BO_FF_W2), Tn, W, I, P(LO_FF_B2), a.x2, a.y3, st));
+        SPN_TRYF(layernorm_fwd(a.y3, P(LO_FF_LNG), P(LO_FF_LNB), xb_out, x_out, a.mean3, a.rstd3, Tn, W, 1e-12f, st));
     }
     // text_proj of the [ENC] position (blip_cir.py:98); the L2-normalise is spn_combine_l2norm_fwd
-    if (packed) SPN_TRYF(gather_rows_abs(A.x_final, A.cu, A.h0, c.B, W, st));
-    else SPN_TRYF(gather_rows_f32(A.x_final, A.zero_idx, A.h0, c.B, c.L, W, st));
-    SPN_TRYF(cast_f32_bf16(A.h0, A.h0b, (size_t)c.B * W, st));
+    // pooled last layer: the first B rows of x_final ARE the [ENC] rows
+    if (!pool_last) {
+        if (packed) SPN_TRYF(gather_rows_abs(A.x_final, A.cu, A.h0, c.B, W, st));
+        else SPN_TRYF(gather_rows_f32(A.x_final, A.zero_idx, A.h0, c.B, c.L, W, st));
+    }
+    SPN_TRYF(cast_f32_bf16(pool_last ? A.x_final : A.h0, A.h0b, (size_t)c.B * W, st));
     SPN_TRYF(nt(A.h0b, wb + t.bf16_proj, c.B, c.Dp, W, params + t.proj_b, nullptr, proj_out, st));
     return SPN_OK;
 }
@@ -349,7 +380,7 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     size_t b = 0;
     b += fa(T * W * 4) + fa(T * W * 4) + fa(T * W * 2);          // dx, dy, dyb
     b += fa(T * I * 2);                                          // dpre
-    b += fa(T * W * 2);                                          // dctx
+    b += 2 * fa(T * W * 2);                                      // dctx, dctx2 (pooled last layer: scatter target)
     b += fa(T * 3 * W * 2);                                      // dqkv (also dq2)
     if (fusion_absorb(c)) b += 2 * fa(fusion_the(c) * 2) + fa(fusion_rsp(c) * 2);   // dO', dQ', dS
     else b += fa(TS * 2 * W * 2);                                // dkv2
@@ -411,8 +442,9 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
     bf16_t* dyb = (bf16_t*)take(Ts * W * 2);
     bf16_t* dpre = (bf16_t*)take(Ts * I * 2);
     bf16_t* dctx = (bf16_t*)take(Ts * W * 2);
+    bf16_t* dctx2 = (bf16_t*)take(Ts * W * 2);
     bf16_t* dqkv = (bf16_t*)take(Ts * 3 * W * 2);
-    const bool absorb = fusion_absorb(c);
+    const bool absorb = fusion_absorb(c), pool_last = fusion_pool_last(c);
     bf16_t *dkv2 = nullptr, *doa = nullptr, *dqa = nullptr, *dsm = nullptr;
     if (absorb) {
         doa = (bf16_t*)take(fusion_the(c) * 2); dqa = (bf16_t*)take(fusion_the(c) * 2); dsm = (bf16_t*)take(fusion_rsp(c) * 2);
@@ -448,8 +480,10 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         SPN_TRYF(cast_f32_bf16(dproj, dprojb, (size_t)c.B * c.Dp, st));
         SPN_TRYF(gemm_tn(dprojb, A.h0b, c.B, c.Dp, W, c.Dp, W, grads + t.proj_w, W, 1.0f, 0, grads + t.proj_b, opws,
                          opws_bytes, st));
-        SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, dh0, st));
-        if (c.T > 0) SPN_TRYF(scatter_rows_abs(dh0, A.row_b, A.cu, dx, nullptr, T, W, st));
+        // pooled last layer: its output rows ARE the B [ENC] rows - the gradient goes straight into the first B rows of dx
+        SPN_TRYF(nt(dprojb, wb + t.bf16_proj_t, c.B, W, c.Dp, nullptr, nullptr, pool_last ? dx : dh0, st));
+        if (pool_last) {}
+        else if (c.T > 0) SPN_TRYF(scatter_rows_abs(dh0, A.row_b, A.cu, dx, nullptr, T, W, st));
         else SPN_TRYF(scatter_rows_f32(dh0, A.zero_idx, dx, nullptr, c.B, c.L, W, st));
     }
 
@@ -465,6 +499,10 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         bf16_t *dyb_ff = dyb, *dyb_ca = dyb, *dyb_sa = dyb, *dpre_l = dpre, *dq_ca = dqkv, *dqkv_sa = dqkv, *dkv2_l = dkv2;
         bf16_t *dqa_l = dqa, *dctx_ca = dctx;
         float* ln_part = nullptr;
+        // pooled last layer: everything above its self-attention on the B [ENC] rows (first B rows of the buffers), its weight
+        // and LayerNorm gradients finished on the spot (their reductions run over B rows, not T)
+        const bool pl = pool_last && l + 1 == c.layers;
+        const int Tn = pl ? c.B : T;
         if (grouped) {
             char* q = defer_base + defer_stride * l;
             auto tk = [&](size_t bytes) { char* r = q; q += fa(bytes); return (bf16_t*)r; };
@@ -477,17 +515,18 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         // LayerNorm backward: grouped mode leaves the [dgamma | dbeta] row partials in the layer's buffer (they are
         // adjacent in the parameter layout) and queues their fold
         auto ln_bwd = [&](const float* xin, int lo_g, int lo_b, const float* mean, const float* rstd, bf16_t* out_b, int k) -> int {
-            if (grouped && G(lo_b) == G(lo_g) + W) {
+            if (grouped && !pl && G(lo_b) == G(lo_g) + W) {
                 float* part = (float*)((char*)ln_part + lnp * k);
                 SPN_TRYF(layernorm_bwd(nullptr, dx, xin, P(lo_g), mean, rstd, dy, 0, out_b, G(lo_g), G(lo_b), 2, T, W, part, lnp, st));
                 fb.ws[fb.items] = part; fb.out[fb.items++] = G(lo_g);
                 if (fb.items == FOLD_BATCH_MAX) SPN_TRYF(fold_flush());
                 return SPN_OK;
             }
-            return layernorm_bwd(nullptr, dx, xin, P(lo_g), mean, rstd, dy, 0, out_b, G(lo_g), G(lo_b), 0, T, W, opws, opws_bytes, st);
+            return layernorm_bwd(nullptr, dx, xin, P(lo_g), mean, rstd, dy, 0, out_b, G(lo_g), G(lo_b), 0, Tn, W, opws, opws_bytes, st);
         };
         auto wgrad = [&](const bf16_t* Aop, const bf16_t* Bop, int Kr, int N1, int N2, float* Cw, float* cb) -> int {
-            if (!grouped) return gemm_tn(Aop, Bop, Kr, N1, N2, N1, N2, Cw, N2, 1.0f, 0, cb, opws, opws_bytes, st);
+            if (!grouped || (Kr != T && Kr != TS))
+                return gemm_tn(Aop, Bop, Kr, N1, N2, N1, N2, Cw, N2, 1.0f, 0, cb, opws, opws_bytes, st);
             TnProblem pr{Aop, Bop, Cw, cb, N1, N2, N1, N2, N2};
             if (Kr == T) qT[nT++] = pr;
             else qS[nS++] = pr;
@@ -498,24 +537,25 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         {
             GemmEpilogue e;
             e.aux_in = a.pre; e.aux_grad = 1; e.act = ACT_GELU_ERF; e.out_bf16 = dpre_l; e.ldc = I;
-            SPN_TRYF(gemm_nt(dyb_ff, Bw(BO_FF_W2_T), T, I, W, W, W, GEMM_DACT, e, st));
+            SPN_TRYF(gemm_nt(dyb_ff, Bw(BO_FF_W2_T), Tn, I, W, W, W, GEMM_DACT, e, st));
         }
-        SPN_TRYF(wgrad(dyb_ff, a.u, T, W, I, G(LO_FF_W2), G(LO_FF_B2)));
-        SPN_TRYF(wgrad(dpre_l, a.x2b, T, I, W, G(LO_FF_W1), G(LO_FF_B1)));
-        SPN_TRYF(nt_resid(dpre_l, Bw(BO_FF_W1_T), T, W, I, nullptr, dy, dx, st));        // dx = d/dx2
+        SPN_TRYF(wgrad(dyb_ff, a.u, Tn, W, I, G(LO_FF_W2), G(LO_FF_B2)));
+        SPN_TRYF(wgrad(dpre_l, a.x2b, Tn, I, W, G(LO_FF_W1), G(LO_FF_B1)));
+        SPN_TRYF(nt_resid(dpre_l, Bw(BO_FF_W1_T), Tn, W, I, nullptr, dy, dx, st));        // dx = d/dx2
         // ---- cross-attention: x2 = LN(y2), y2 = x1 + attn(q(x1), kv(enc)) Wo^T + bo
         SPN_TRYF(ln_bwd(a.y2, LO_CA_LNG, LO_CA_LNB, a.mean2, a.rstd2, dyb_ca, 1));
-        SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), T, W, W, nullptr, dctx_ca, nullptr, st));
-        SPN_TRYF(wgrad(dyb_ca, a.ctx2, T, W, W, G(LO_CA_WO), G(LO_CA_BO)));
+        SPN_TRYF(nt(dyb_ca, Bw(BO_CA_WO_T), Tn, W, W, nullptr, dctx_ca, nullptr, st));
+        SPN_TRYF(wgrad(dyb_ca, a.ctx2, Tn, W, W, G(LO_CA_WO), G(LO_CA_BO)));
         if (absorb) {
-            const int R = c.L * c.H;
-            SPN_TRYF(xattn_delta(dctx_ca, a.ctx2, P(LO_CA_BKV) + W, delta, T, c.H, st));
-            SPN_TRYF(xattn_head_expand(dctx_ca, W, Bw(BO_CA_WKV_T), 2 * W, W, doa, T, c.H, E, 1.0f, st));          // dO' = dctx_h Wv_h
-            SPN_TRYF(xattn_dscores(doa, A.enc_b, a.pm, delta, dsm, c.B, R, c.S, E, st, A.cu, c.H));                // dS
-            SPN_TRYF(xattn_apply(dsm, A.enc_b, dqa_l, c.B, R, c.S, E, st, A.cu, c.H));                             // dQ' = dS X
-            SPN_TRYF(xattn_head_contract(dqa_l, Bw(BO_CA_WKV), 0, nullptr, dq_ca, W, T, c.H, E, 0.125f, st));     // dq_h
-            if (!grouped)
-                SPN_TRYF(xattn_wgrad(a.q2, 0, dqa_l, 0, dctx_ca, 0, a.oa, 0, G(LO_CA_WKV), G(LO_CA_BKV), 0, 1, T, W, c.H, E, 0.125f, st));
+            const int R = pl ? c.H : c.L * c.H;
+            const int32_t* cun = pl ? nullptr : A.cu;
+            SPN_TRYF(xattn_delta(dctx_ca, a.ctx2, P(LO_CA_BKV) + W, delta, Tn, c.H, st));
+            SPN_TRYF(xattn_head_expand(dctx_ca, W, Bw(BO_CA_WKV_T), 2 * W, W, doa, Tn, c.H, E, 1.0f, st));         // dO' = dctx_h Wv_h
+            SPN_TRYF(xattn_dscores(doa, A.enc_b, a.pm, delta, dsm, c.B, R, c.S, E, st, cun, c.H));                // dS
+            SPN_TRYF(xattn_apply(dsm, A.enc_b, dqa_l, c.B, R, c.S, E, st, cun, c.H));                             // dQ' = dS X
+            SPN_TRYF(xattn_head_contract(dqa_l, Bw(BO_CA_WKV), 0, nullptr, dq_ca, W, Tn, c.H, E, 0.125f, st));    // dq_h
+            if (!grouped || pl)
+                SPN_TRYF(xattn_wgrad(a.q2, 0, dqa_l, 0, dctx_ca, 0, a.oa, 0, G(LO_CA_WKV), G(LO_CA_BKV), 0, 1, Tn, W, c.H, E, 0.125f, st));
         } else {
             AttnBwdArgs g;
             g.f = cross_attn_args(c, a);
@@ -526,30 +566,38 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
             SPN_TRYF(attention_bwd(g, st));
             SPN_TRYF(wgrad(dkv2_l, A.enc_b, TS, 2 * W, E, G(LO_CA_WKV), G(LO_CA_BKV)));
         }
-        SPN_TRYF(wgrad(dq_ca, a.x1b, T, W, W, G(LO_CA_WQ), G(LO_CA_BQ)));
-        SPN_TRYF(nt_resid(dq_ca, Bw(BO_CA_WQ_T), T, W, W, nullptr, dy, dx, st));         // dx = d/dx1
+        SPN_TRYF(wgrad(dq_ca, a.x1b, Tn, W, W, G(LO_CA_WQ), G(LO_CA_BQ)));
+        SPN_TRYF(nt_resid(dq_ca, Bw(BO_CA_WQ_T), Tn, W, W, nullptr, dy, dx, st));         // dx = d/dx1
         // ---- self-attention: x1 = LN(y1), y1 = x_in + attn(qkv(x_in)) Wo^T + bo
         SPN_TRYF(ln_bwd(a.y1, LO_SA_LNG, LO_SA_LNB, a.mean1, a.rstd1, dyb_sa, 2));
-        SPN_TRYF(nt(dyb_sa, Bw(BO_SA_WO_T), T, W, W, nullptr, dctx, nullptr, st));
-        SPN_TRYF(wgrad(dyb_sa, a.ctx1, T, W, W, G(LO_SA_WO), G(LO_SA_BO)));
+        SPN_TRYF(nt(dyb_sa, Bw(BO_SA_WO_T), Tn, W, W, nullptr, dctx, nullptr, st));
+        SPN_TRYF(wgrad(dyb_sa, pl ? A.pool_ctx : a.ctx1, Tn, W, W, G(LO_SA_WO), G(LO_SA_BO)));
+        const bf16_t* dctx_sa = dctx;
+        const float* dres = dy;                                  // gradient of the residual stream at the layer input
+        if (pl) {
+            // back to all rows: d/dy1 [B, W] (dy) -> dx at the [ENC] rows, d/dctx1 [B, W] -> dctx2 at the [ENC] rows, zeros elsewhere
+            SPN_TRYF(scatter_pool_rows(dy, dctx, A.zero_idx, c.T > 0 ? A.row_b : nullptr, A.cu, c.L, dx, dctx2, T, W, st));
+            dctx_sa = dctx2; dres = dx;
+        }
         {
             AttnBwdArgs g;
             g.f = self_attn_args(c, a, A.key_bias, A.cu);
-            g.d_o = dctx; g.lddo = W;
+            g.d_o = dctx_sa; g.lddo = W;
             g.dq = dqkv_sa; g.dk = dqkv_sa + W; g.dv = dqkv_sa + 2 * W;
             g.lddq = g.lddk = g.lddv = 3 * W;
             g.delta = delta;
             SPN_TRYF(attention_bwd(g, st));
         }
         SPN_TRYF(wgrad(dqkv_sa, a.xb_in, T, 3 * W, W, G(LO_SA_WQKV), G(LO_SA_BQKV)));
-        SPN_TRYF(nt_resid(dqkv_sa, Bw(BO_SA_WQKV_T), T, W, 3 * W, nullptr, dy, dx, st));  // dx = d/dx_in
+        SPN_TRYF(nt_resid(dqkv_sa, Bw(BO_SA_WQKV_T), T, W, 3 * W, nullptr, dres, dx, st));  // dx = d/dx_in
     }
     // the deferred weight gradients: everything with the text rows as reduction (<= 48 problems per launch), then the
     // cross-attention K/V projections of all layers (reduction over the image tokens)
     for (int i = 0; i < nT; i += TN_GROUP_MAX)
         SPN_TRYF(gemm_tn_grouped(qT + i, nT - i < TN_GROUP_MAX ? nT - i : TN_GROUP_MAX, T, opws, opws_bytes, st));
     if (nS) SPN_TRYF(gemm_tn_grouped(qS, nS, TS, opws, opws_bytes, st));
-    if (absorb && grouped && (phases & 2) && l_hi > l_lo) {
+    const int l_hi_def = (pool_last && l_hi == c.layers) ? l_hi - 1 : l_hi;      // the pooled last layer finished its own
+    if (absorb && grouped && (phases & 2) && l_hi_def > l_lo) {
         // absorbed K/V weight gradients of the layers [l_lo, l_hi) in one launch: the operands sit at constant strides
         FusionLayerActs a0 = fusion_layer_acts_at(A.layers + A.layer_bytes * l_lo, c);
         char* q = defer_base + defer_stride * l_lo;
@@ -558,7 +606,7 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
         const bf16_t* dctx0 = (const bf16_t*)(q + fa(fusion_the(c) * 2));
         float* g0 = grads + t.layers + t.layer_size * l_lo;
         SPN_TRYF(xattn_wgrad(a0.q2, A.layer_bytes / 2, dqa0, defer_stride / 2, dctx0, defer_stride / 2, a0.oa, A.layer_bytes / 2,
-                             g0 + t.layer_off[LO_CA_WKV], g0 + t.layer_off[LO_CA_BKV], (size_t)t.layer_size, l_hi - l_lo, T, W, c.H,
+                             g0 + t.layer_off[LO_CA_WKV], g0 + t.layer_off[LO_CA_BKV], (size_t)t.layer_size, l_hi_def - l_lo, T, W, c.H,
                              E, 0.125f, st));
     }
     SPN_TRYF(fold_flush());
