@@ -844,6 +844,11 @@ def main():
             "loss_last": round(loss_val, 5),
             "step_model_tflops": round(tps * FLOP_PER_TRIPLET / 1e12 / world, 1),
             "step_frac_of_bf16_peak": round(tps * FLOP_PER_TRIPLET / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+            "step_flop_note": "step_model_tflops prices the step at the REFERENCE's arithmetic (SURVEY 8d: every one of the 77 rows "
+                              "through all 12 blocks).  The path executes less since round 5: the last block's out-projection / "
+                              "MLP (forward, data and weight gradients) run on the B pooled EOT rows only (spn_text_cfg.pool; "
+                              "clip/model.py:352-356 reads one row per caption) - 9/12 of one block of 12, i.e. ~0.94 of that "
+                              "arithmetic; `roofline.achieved` counts the flops of the launches actually made",
             "roofline": roof,
             # every SPN_* variable the library saw when it was loaded (its A/B switches read that snapshot only): a stray
             # one that changes a kernel is visible next to the number

@@ -29,8 +29,10 @@ def main(fetch, write, out, tag):
     layers = 12
     per_layer = [gemm(T, 3 * W, W, 2), gemm(T, W, W, 2), gemm(T, 4 * W, W, 4), gemm(T, 4 * W, W, 2, T * 4 * W * 2),
                  gemm(T, W, 4 * W, 2), gemm(T, W, W, 2), gemm(T, W, 3 * W, 2)]
-    cproj_bf16, cproj_resid = gemm(T, W, 4 * W, 2), gemm(T, W, 4 * W, 4, T * W * 4)
-    algo = (layers * sum(per_layer) + (layers - 1) * cproj_bf16 + cproj_resid) / (8 * layers)
+    cproj_bf16 = gemm(T, W, 4 * W, 2)
+    # round 5 (pooled last block): the last block keeps only its qkv projection and that projection's data gradient on all T
+    # rows; its other six products run on the B pooled rows through the 128 x 128 kernel and are not in this kernel class
+    algo = ((layers - 1) * (sum(per_layer) + cproj_bf16) + per_layer[0] + per_layer[6]) / (8 * (layers - 1) + 2)
     j = {"kernel": "gemm_nt2_kernel (all epilogue variants, launch-weighted)",
          "launches_fetch_pass": nf, "launches_write_pass": nw,
          "fetch_size_kb_raw_per_launch": round(f, 1), "write_size_kb_per_launch": round(w, 1),
