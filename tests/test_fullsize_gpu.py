@@ -230,6 +230,10 @@ def test_blip_fusion_full_shape(enc_width, init):
         errs[k] = _rel(got, ref)
     _floor_gate(f"blip_{enc_width}" + ("_refinit" if init == "reference" else ""), errs, f"blip fusion enc_width {enc_width} ({init} init)")
     # (6) the same B = 8 step on the unmasked text rows only (host mask -> spn_fusion_cfg.T): same queries, same gradients
+    import ctypes
+    from spn4cir_amd._lib import lib
+    if not lib().spn_fusion_packed_ok(ctypes.byref(enc_model._cfg(b, L, S))):
+        return                                          # SPN_XATTN_ABSORB=0 (A/B switch): the K/V-projection form has dense rows only
     g_dense = grads.clone()
     proj_pk = enc_model.forward(ids[:b].contiguous(), mask[:b].contiguous(), enc_d[:b].contiguous())
     assert enc_model._last[1].T == int(lens[:b].sum())
