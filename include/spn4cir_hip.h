@@ -576,6 +576,25 @@ int spn_fusion_bwd(const spn_fusion_cfg* cfg, const float* params, const void* w
 int spn_fusion_bwd_phase(const spn_fusion_cfg* cfg, const float* params, const void* weights_bf16, const int32_t* ids,
                          void* acts, const float* dproj, float* grads, void* ws, size_t ws_bytes, int phase, int l_lo, int l_hi,
                          void* stream);
+/* ---------------------------------------------------------------- cross-attention over FROZEN tokens, absorbed form
+ * BertSelfAttention with is_cross_attention (blip4cir/med.py:97-181, 196-234): K = X Wk^T + bk and V = X Wv^T + bv are projections of
+ * the SAME image tokens X_b [S, E] for all H heads (head width 64), and X carries no gradient (blip4cir/models.py:97-100).  Hence
+ *     scores_h = (scale q_h Wk_h) X^T        (bk shifts every score of a query equally: softmax-invariant)
+ *     ctx_h    = (softmax(scores_h) X) Wv_h^T + bv_h        (rows of the softmax sum to 1)
+ * and K, V [B*S, 2W] are never formed.  q / ctx / dq / dctx: bf16 [rows, W = H*64]; wkv: bf16 [2W, E] (K rows, then V rows), wkv_t its
+ * transpose [E, 2W]; bkv fp32 [2W]; x bf16 [B, S, E].  Rows: dense B*L (cu == NULL; row b*L + l) or packed (cu int32 [B+1] prefix
+ * sums on the device, T = cu[B] rows, sample b = rows cu[b]..cu[b+1]-1, each length in 1..L).  Caller-provided buffers, kept from
+ * forward to backward: qa, oa bf16 [rows, H, E]; p bf16 [rows*H, spn_xattn_sp(S)].  Backward scratch: doa, dqa like qa; ds like p;
+ * delta fp32 [rows*H].  Backward writes dq, dwkv fp32 [2W, E] and dbkv fp32 [2W] (the K half of dbkv is exactly zero).
+ * spn_xattn_ok: head count even, E % 128 == 0, 1 <= S <= 640 (else SPN_ERR_SHAPE: use K/V projections + spn_attention_*). */
+int spn_xattn_ok(int B, int L, int H, int S, int E);
+int spn_xattn_sp(int S);
+int spn_xattn_fwd(const void* q, const void* wkv, const void* wkv_t, const float* bkv, const void* x, const int32_t* cu, void* qa,
+                  void* p, void* oa, void* ctx, int B, int L, int H, int S, int E, int T, float scale, void* stream);
+int spn_xattn_bwd(const void* dctx, const void* ctx, const void* q, const void* wkv, const void* wkv_t, const float* bkv,
+                  const void* x, const int32_t* cu, const void* p, const void* oa, void* doa, void* ds, void* dqa, float* delta,
+                  void* dq, float* dwkv, float* dbkv, int B, int L, int H, int S, int E, int T, float scale, void* stream);
+
 /* out[b, :D] = bf16(x[b, :] * s), out[b, D:ldo] = 0, s = *scale_dev or 1 / *scale_dev (reciprocal != 0): the query scaled by
  * a DEVICE-resident temperature (blip4cir/models.py:29 keeps tau as an nn.Parameter; logits = (q / tau) . bank with the bank
  * calls at inv_tau = 1 - no host read of tau inside a step). */

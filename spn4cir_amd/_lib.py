@@ -160,6 +160,10 @@ _SIGS = {
     "spn_inbatch_grad_t": (i32, [vp, vp, i32, vp, i32, i32, f32, f32, vp, vp]),
     "spn_fusion_layout": (i32, [C.POINTER(FusionCfg), C.POINTER(FusionLayout)]),
     "spn_fusion_packed_ok": (i32, [C.POINTER(FusionCfg)]),
+    "spn_xattn_ok": (i32, [i32, i32, i32, i32, i32]),
+    "spn_xattn_sp": (i32, [i32]),
+    "spn_xattn_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "spn_xattn_bwd": (i32, [vp] * 17 + [i32, i32, i32, i32, i32, i32, f32, vp]),
     "spn_fusion_act_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_ws_bytes": (sz, [C.POINTER(FusionCfg)]),
     "spn_fusion_refresh_bf16": (i32, [C.POINTER(FusionCfg), vp, vp, vp]),

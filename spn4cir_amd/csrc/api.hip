@@ -508,6 +508,45 @@ int spn_fusion_layout(const spn_fusion_cfg* cfg, spn_fusion_layout_t* out) {
     return SPN_OK;
 }
 
+// ------------------------------------------------------------------------- absorbed cross-attention (xattn.hip)
+int spn_xattn_ok(int B, int L, int H, int S, int E) { return xattn_absorb_ok(B, L, H, S, E, H * 64) ? 1 : 0; }
+int spn_xattn_sp(int S) { return xattn_sp(S); }
+
+int spn_xattn_fwd(const void* q, const void* wkv, const void* wkv_t, const float* bkv, const void* x, const int32_t* cu, void* qa,
+                  void* p, void* oa, void* ctx, int B, int L, int H, int S, int E, int T, float scale, void* stream) {
+    if (!q || !wkv || !wkv_t || !bkv || !x || !qa || !p || !oa || !ctx) return SPN_ERR_ARG;
+    const int W = H * 64;
+    if (!xattn_absorb_ok(B, L, H, S, E, W)) return SPN_ERR_SHAPE;
+    const int rows = cu ? T : B * L;
+    if (rows <= 0 || (cu && (T < B || (int64_t)T > (int64_t)B * L))) return SPN_ERR_ARG;
+    hipStream_t st = ST(stream);
+    int rc = xattn_head_expand(CBF(q), W, CBF(wkv_t), 2 * W, 0, BF(qa), rows, H, E, scale, st);
+    if (rc == SPN_OK) rc = xattn_scores_softmax(CBF(qa), CBF(x), BF(p), B, L * H, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_apply(CBF(p), CBF(x), BF(oa), B, L * H, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_head_contract(CBF(oa), CBF(wkv), W, bkv, BF(ctx), W, rows, H, E, 1.0f, st);
+    return rc;
+}
+
+int spn_xattn_bwd(const void* dctx, const void* ctx, const void* q, const void* wkv, const void* wkv_t, const float* bkv,
+                  const void* x, const int32_t* cu, const void* p, const void* oa, void* doa, void* ds, void* dqa, float* delta,
+                  void* dq, float* dwkv, float* dbkv, int B, int L, int H, int S, int E, int T, float scale, void* stream) {
+    if (!dctx || !ctx || !q || !wkv || !wkv_t || !bkv || !x || !p || !oa || !doa || !ds || !dqa || !delta || !dq || !dwkv || !dbkv)
+        return SPN_ERR_ARG;
+    const int W = H * 64;
+    if (!xattn_absorb_ok(B, L, H, S, E, W)) return SPN_ERR_SHAPE;
+    const int rows = cu ? T : B * L, R = L * H;
+    if (rows <= 0 || (cu && (T < B || (int64_t)T > (int64_t)B * L))) return SPN_ERR_ARG;
+    hipStream_t st = ST(stream);
+    int rc = xattn_delta(CBF(dctx), CBF(ctx), bkv + W, delta, rows, H, st);
+    if (rc == SPN_OK) rc = xattn_head_expand(CBF(dctx), W, CBF(wkv_t), 2 * W, W, BF(doa), rows, H, E, 1.0f, st);
+    if (rc == SPN_OK) rc = xattn_dscores(CBF(doa), CBF(x), CBF(p), delta, BF(ds), B, R, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_apply(CBF(ds), CBF(x), BF(dqa), B, R, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_head_contract(CBF(dqa), CBF(wkv), 0, nullptr, BF(dq), W, rows, H, E, scale, st);
+    if (rc == SPN_OK)
+        rc = xattn_wgrad(CBF(q), 0, CBF(dqa), 0, CBF(dctx), 0, CBF(oa), 0, dwkv, dbkv, 0, 1, rows, W, H, E, scale, st);
+    return rc;
+}
+
 int spn_fusion_packed_ok(const spn_fusion_cfg* cfg) { return cfg ? fusion_packed_ok(fc(cfg)) : 0; }
 size_t spn_fusion_act_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_act_bytes(fc(cfg)) : 0; }
 size_t spn_fusion_ws_bytes(const spn_fusion_cfg* cfg) { return cfg ? fusion_ws_bytes(fc(cfg)) : 0; }

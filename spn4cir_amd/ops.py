@@ -454,6 +454,54 @@ def tau_grad(q, dqk, tau_dev, dtau_out=None, alpha=1.0, scale_dev=None):
     return inv
 
 
+def xattn_fwd(q, wkv, bkv, x, heads, cu=None, L=None, scale=0.125, wkv_t=None):
+    """Cross-attention over frozen tokens in the absorbed form (spn_xattn_fwd; blip4cir/med.py:97-181, 196-234): q bf16 [rows, W],
+    wkv bf16 [2W, E] (key rows, then value rows), bkv fp32 [2W], x bf16 [B, S, E] -> (ctx bf16 [rows, W], saved) where `saved` goes
+    to xattn_bwd.  Dense rows = B * L (cu None) or packed (cu int32 [B + 1] device prefix sums, L = the longest length)."""
+    _req(q, torch.bfloat16, "q")
+    _req(wkv, torch.bfloat16, "wkv")
+    _req(x, torch.bfloat16, "x")
+    _req(bkv, torch.float32, "bkv")
+    B, S, E = x.shape
+    rows, W = q.shape
+    H = int(heads)
+    if cu is None:
+        if rows % B:
+            raise ValueError("dense rows must be B * L")
+        L = rows // B
+    elif L is None:
+        raise ValueError("packed rows need L (the longest caption)")
+    if W != H * 64 or tuple(wkv.shape) != (2 * W, E) or not lib().spn_xattn_ok(B, L, H, S, E):
+        raise ValueError("shape not supported by the absorbed cross-attention (spn_xattn_ok)")
+    wkv_t = wkv.t().contiguous() if wkv_t is None else wkv_t
+    SP = lib().spn_xattn_sp(S)
+    qa = torch.empty(rows, H, E, dtype=torch.bfloat16, device=q.device)
+    oa = torch.empty_like(qa)
+    p = torch.empty(rows * H, SP, dtype=torch.bfloat16, device=q.device)
+    ctx = torch.empty(rows, W, dtype=torch.bfloat16, device=q.device)
+    check(lib().spn_xattn_fwd(_p(q), _p(wkv), _p(wkv_t), _p(bkv), _p(x), _p(cu), _p(qa), _p(p), _p(oa), _p(ctx), B, L, H, S, E,
+                              rows if cu is not None else 0, float(scale), _stream()), "xattn_fwd")
+    return ctx, dict(q=q, wkv=wkv, wkv_t=wkv_t, bkv=bkv, x=x, cu=cu, qa=qa, p=p, oa=oa, ctx=ctx, B=B, L=L, H=H, S=S, E=E, rows=rows,
+                     scale=float(scale))
+
+
+def xattn_bwd(saved, dctx):
+    """Backward of xattn_fwd: dctx bf16 [rows, W] -> (dq bf16 [rows, W], dwkv fp32 [2W, E], dbkv fp32 [2W])."""
+    _req(dctx, torch.bfloat16, "dctx")
+    s = saved
+    dev = dctx.device
+    W = s["H"] * 64
+    doa, dqa, ds = torch.empty_like(s["qa"]), torch.empty_like(s["qa"]), torch.empty_like(s["p"])
+    delta = torch.empty(s["rows"] * s["H"], dtype=torch.float32, device=dev)
+    dq = torch.empty(s["rows"], W, dtype=torch.bfloat16, device=dev)
+    dwkv = torch.empty(2 * W, s["E"], dtype=torch.float32, device=dev)
+    dbkv = torch.empty(2 * W, dtype=torch.float32, device=dev)
+    check(lib().spn_xattn_bwd(_p(dctx), _p(s["ctx"]), _p(s["q"]), _p(s["wkv"]), _p(s["wkv_t"]), _p(s["bkv"]), _p(s["x"]), _p(s["cu"]),
+                              _p(s["p"]), _p(s["oa"]), _p(doa), _p(ds), _p(dqa), _p(delta), _p(dq), _p(dwkv), _p(dbkv), s["B"], s["L"],
+                              s["H"], s["S"], s["E"], s["rows"] if s["cu"] is not None else 0, s["scale"], _stream()), "xattn_bwd")
+    return dq, dwkv, dbkv
+
+
 def token_bank_bf16(bank, device, chunk=512):
     """fp32 / bf16 [N, S, E] token bank (host or device) -> contiguous bf16 [N, S, E] on `device`, uploaded and converted in
     chunks of `chunk` images (a 30 000 x 577 x 768 bank is 53 GB in fp32: never two copies of it anywhere)."""
