@@ -479,6 +479,12 @@ def test_packed_text_rows_match_dense(S, E):
         if k == "embeddings.position_embeddings.weight":
             got, ref = got[:L], ref[:L]
         assert (got - ref).norm().item() <= 5e-2 * ref.norm().item() + 1e-6, (k, (got - ref).norm().item() / ref.norm().item())
+    # the phased backward of the data-parallel trainer (head, layer groups with their weight gradients, tail) on the packed rows:
+    # the deferred absorbed weight-gradient launch and the pooled last layer are cut differently, the gradient is the same
+    spans = []
+    enc.forward(ids, mask, tokens)
+    g_ph = enc.backward_phased(dproj, lambda a, b: spans.append((a, b)), groups=[1, 1]).clone()
+    assert len(spans) == 2 + layers and (g_ph - g_p).abs().max().item() <= 1e-6 * g_p.abs().max().item()
     # a device mask is never inspected (no synchronisation): dense rows; pack=True without a host mask is an error
     enc.forward(ids, mask.cuda(), tokens)
     assert enc._last[1].T == 0
