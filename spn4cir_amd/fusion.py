@@ -142,7 +142,10 @@ class FusionEncoder:
             cu = torch.zeros(B + 1, dtype=torch.int32)
             cu[1:] = lens.cumsum(0)
             cfg = self._cfg(B, L, S, int(cu[-1]))
-            mask = cu.pin_memory() if torch.cuda.is_available() else cu          # the mask slot carries cu_seqlens (spn4cir_hip.h)
+            # the mask slot carries cu_seqlens (spn4cir_hip.h).  A fresh pinned tensor per step on purpose: torch's caching host
+            # allocator holds the block until the asynchronous upload below has run, so a host that enqueues several steps ahead
+            # never overwrites prefix sums a queued copy has yet to read (a reused buffer would need an event per step)
+            mask = cu.pin_memory() if torch.cuda.is_available() else cu
         else:
             cfg = cfg0
         if self.is_stale():
