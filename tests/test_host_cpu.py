@@ -64,3 +64,26 @@ def test_shard_range_partitions_exactly():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         sizes = [e - b for b, e in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_fusion_prefix_lengths_host_logic():
+    """FusionEncoder._prefix_lengths: what decides whether a BLIP batch runs on its unmasked text rows only (spn_fusion_cfg.T).
+    Only a HOST mask of right-padded captions (ones, then zeros, at least one 1 per row - what the tokenizer returns,
+    blip4cir/blip.py:189-194) qualifies; anything else keeps the dense rows."""
+    import torch
+    from spn4cir_amd.fusion import FusionEncoder
+    f = FusionEncoder._prefix_lengths
+    m = torch.tensor([[1, 1, 1, 0], [1, 0, 0, 0], [1, 1, 1, 1]], dtype=torch.int32)
+    assert f(m).tolist() == [3, 1, 4]
+    assert f(m.to(torch.int64)).tolist() == [3, 1, 4] and f(m.bool()).tolist() == [3, 1, 4]
+    assert f(None) is None
+    assert f(torch.tensor([[1, 0, 1, 0], [1, 1, 0, 0]])) is None                 # a hole: not a prefix mask
+    assert f(torch.tensor([[0, 1, 1, 1], [1, 1, 1, 1]])) is None                 # left padding
+    assert f(torch.tensor([[0, 0, 0, 0], [1, 1, 0, 0]])) is None                 # an empty caption
+    # BERT WordPiece batches from the package's own tokenizer are right padded
+    from spn4cir_amd.bert_tokenizer import BertWordPieceTokenizer
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "red", "dress", "with", "long", "sleeves", "##s", "is", "shorter"]
+    tok = BertWordPieceTokenizer(vocab=vocab)
+    out = tok(["a red dress", "a red dress with long sleeves is shorter", "dress"], padding="longest", return_tensors="pt")
+    lens = f(out["attention_mask"])
+    assert lens is not None and lens.tolist() == out["attention_mask"].sum(1).tolist() and int(lens.max()) == out["input_ids"].shape[1]
