@@ -528,7 +528,8 @@ typedef struct {
      * (med.py:686 extended_attention_mask) - and the `mask` argument of spn_fusion_fwd / spn_fusion_fwd_bank carries the prefix sums
      * cu_seqlens int32 [B + 1] (cu[0] = 0, cu[B] = T; each length in 1..L; the tokenizer's right padding, blip.py:189-194) instead
      * of the [B, L] mask.  ids stays the padded [B, L] array.  Needs L <= 128 and spn_fusion_packed_ok(cfg) != 0; activation and
-     * workspace sizes shrink with T (size them with T = 0 for a buffer that fits every batch of the shape). */
+     * workspace sizes for T = 0 (the dense rows) reserve the packed form's index arrays and scratch as well, so a buffer sized with
+     * T = 0 fits every batch of the shape, packed or dense, up to and including T = B * L (equal-length captions, B = 1). */
     int T;
 } spn_fusion_cfg;
 

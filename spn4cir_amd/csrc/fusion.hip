@@ -186,7 +186,9 @@ static FusionLayerActs fusion_layer_acts_at(char* base, const FusionCfg& c) {
 size_t fusion_act_bytes(const FusionCfg& c) {
     const size_t T = (size_t)fusion_rows(c), TS = (size_t)c.B * c.S, W = c.W;
     size_t b = fa(T * 4) + 2 * fa((size_t)c.B * 4) + fa(TS * c.E * 2) + fa(T * W * 4) + 2 * fa(T * 4);
-    if (c.T > 0) b += fa((size_t)(c.B + 1) * 4) + 2 * fa(T * 4);
+    // cu / row_b / row_l of the packed form.  The dense size (T = 0) reserves them for the largest packed batch (T = B * L) too, so
+    // that an arena sized with T = 0 really fits EVERY batch of the shape: each other term is monotone in the row count
+    b += fa((size_t)(c.B + 1) * 4) + 2 * fa(T * 4);
     b += fusion_layer_act_bytes(c) * c.layers;
     b += fa(T * W * 4) + fa(T * W * 2) + fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2) + fa((size_t)c.B * c.Dp * 4);
     b += fa((size_t)c.B * W * 4) + fa((size_t)c.B * W * 2);          // pool_x, pool_ctx
@@ -400,7 +402,7 @@ size_t fusion_ws_bytes(const FusionCfg& c) {
     mx(gemm_tn_workspace_bytes(c.B, c.Dp, (int)W));
     mx(gemm_tn_grouped_workspace_bytes((int)TS));
     mx(layernorm_bwd_workspace_bytes((int)T, (int)W));
-    if (c.T > 0) mx(embed_bwd_packed_ws_bytes(c.L, c.W));
+    mx(embed_bwd_packed_ws_bytes(c.L, c.W));              // packed embedding backward: reserved in the dense size too (see fusion_act_bytes)
     return b + fa(op);
 }
 

@@ -152,10 +152,15 @@ class FusionEncoder:
             check(lib().spn_fusion_refresh_bf16(C.byref(cfg), _p(self.params), _p(self.wbf16), _stream()), "fusion_refresh")
             self._stale = False
             self._seen_version = self.params._version
-        if self._key != (B, L, S):                     # sized for the dense rows: fits every packed batch of the shape
-            self._acts = ops.scratch_bytes(lib().spn_fusion_act_bytes(C.byref(cfg0)), self.device)
-            self._ws = ops.scratch_bytes(lib().spn_fusion_ws_bytes(C.byref(cfg0)), self.device)
+        if self._key != (B, L, S):
+            # one arena per shape, sized for the worst batch of that shape: the dense rows AND the fullest packed batch (T = B * L -
+            # all captions of equal length, or B = 1 - whose index arrays come on top of the dense rows)
+            full = self._cfg(B, L, S, B * L)
+            self._acts = ops.scratch_bytes(max(lib().spn_fusion_act_bytes(C.byref(c)) for c in (cfg0, full)), self.device)
+            self._ws = ops.scratch_bytes(max(lib().spn_fusion_ws_bytes(C.byref(c)) for c in (cfg0, full)), self.device)
             self._key = (B, L, S)
+        if lib().spn_fusion_act_bytes(C.byref(cfg)) > self._acts.numel() or lib().spn_fusion_ws_bytes(C.byref(cfg)) > self._ws.numel():
+            raise RuntimeError("fusion arena smaller than this batch needs")          # cannot happen; never write past the arena
         ids = ids.to(self.device, torch.int32).contiguous()
         mask = None if mask is None else mask.to(self.device, torch.int32, non_blocking=True).contiguous()
         out = torch.empty(B, self.Dp, dtype=torch.float32, device=self.device)

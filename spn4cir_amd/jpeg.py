@@ -239,21 +239,34 @@ def _pil_rgb(data):
     return np.array(Image.open(io.BytesIO(bytes(data))).convert("RGB"), dtype=np.uint8)
 
 
-def decode_batch(files, device="cuda"):
-    """files: list of bytes-like JPEG files -> list of uint8 [H, W, 3] tensors on `device` (views of one batch buffer),
-    equal to `np.asarray(PIL.Image.open(f).convert("RGB"))`.  Files outside the kernels' scope are decoded by Pillow on the host
-    and uploaded (the second return value lists their positions)."""
+RGB_BUDGET = 1 << 30        # bytes of decoded RGB per kernel batch (coefficients + planes add up to ~3x that on the device)
+
+
+def split_by_pixels(sizes, budget=None):
+    """[(width, height)] -> [[positions]]: consecutive runs whose decoded RGB stays under `budget` bytes (a single larger image
+    gets a run of its own).  Keeps a chunk of a few thousand web photos (CIRR / NLVR2: several megapixels each) inside the
+    kernels' 32-bit offsets and a bounded device footprint; the reference's per-image PIL path has no such limit
+    (data_utils_negplus.py:298-304)."""
+    budget = RGB_BUDGET if budget is None else budget
+    runs, cur, acc = [], [], 0
+    for k, (w, h) in enumerate(sizes):
+        nb = 3 * int(w) * int(h)
+        if cur and acc + nb > budget:
+            runs.append(cur)
+            cur, acc = [], 0
+        cur.append(k)
+        acc += nb
+    if cur:
+        runs.append(cur)
+    return runs
+
+
+def _decode_group(good, idx, out, fallback, device):
+    """One kernel batch: `good` files at output positions `idx`; files a per-batch check rejects move to `fallback`."""
     from . import ops
     from ._lib import check, lib
-    device = torch.device(device)
-    out, fallback, good, idx = [None] * len(files), [], [], []
-    for i, f in enumerate(files):
-        try:
-            parse_header(f)
-            good.append(f)
-            idx.append(i)
-        except Unsupported:
-            fallback.append(i)
+    good, idx = list(good), list(idx)
+    b = None
     while good:
         try:
             b = Batch(good)
@@ -268,19 +281,47 @@ def decode_batch(files, device="cuda"):
                     break
             else:
                 raise
-    if good:
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        d_bytes, d_img, d_seg, d_huff, d_qt = up(b.bytes), up(b.images.view(np.int32)), up(b.segs.view(np.int32)), up(b.huff), \
-            up(b.qt.view(np.int16))
-        coefs = torch.empty(b.coef_elems, dtype=torch.int16, device=device)
-        planes = torch.empty(max(b.plane_bytes, 16), dtype=torch.uint8, device=device)
-        rgb = torch.empty(b.rgb_bytes, dtype=torch.uint8, device=device)
-        check(lib().spn_jpeg_decode_batch(ops._p(d_bytes), ops._p(d_img), b.n, ops._p(d_seg), b.segs.shape[0], ops._p(d_huff),
-                                          ops._p(d_qt), ops._p(coefs), b.coef_elems, ops._p(planes), ops._p(rgb), b.max_blocks,
-                                          b.max_pixels, ops._stream()), "jpeg_decode_batch")
-        for k, i in enumerate(idx):
-            H, W = b.sizes[k]
-            out[i] = rgb[b.rgb_off[k]:b.rgb_off[k] + H * W * 3].view(H, W, 3)
+        except ValueError:                       # 32-bit offsets exhausted although the pixel budget held (odd sampling): halve
+            if len(good) == 1:
+                fallback.append(idx[0])
+                return
+            h = len(good) // 2
+            _decode_group(good[:h], idx[:h], out, fallback, device)
+            _decode_group(good[h:], idx[h:], out, fallback, device)
+            return
+    if not good:
+        return
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    d_bytes, d_img, d_seg, d_huff, d_qt = up(b.bytes), up(b.images.view(np.int32)), up(b.segs.view(np.int32)), up(b.huff), \
+        up(b.qt.view(np.int16))
+    coefs = torch.empty(b.coef_elems, dtype=torch.int16, device=device)
+    planes = torch.empty(max(b.plane_bytes, 16), dtype=torch.uint8, device=device)
+    rgb = torch.empty(b.rgb_bytes, dtype=torch.uint8, device=device)
+    check(lib().spn_jpeg_decode_batch(ops._p(d_bytes), ops._p(d_img), b.n, ops._p(d_seg), b.segs.shape[0], ops._p(d_huff),
+                                      ops._p(d_qt), ops._p(coefs), b.coef_elems, ops._p(planes), ops._p(rgb), b.max_blocks,
+                                      b.max_pixels, ops._stream()), "jpeg_decode_batch")
+    for k, i in enumerate(idx):
+        H, W = b.sizes[k]
+        out[i] = rgb[b.rgb_off[k]:b.rgb_off[k] + H * W * 3].view(H, W, 3)
+
+
+def decode_batch(files, device="cuda", rgb_budget=None):
+    """files: list of bytes-like JPEG files -> list of uint8 [H, W, 3] tensors on `device` (views of a few batch buffers),
+    equal to `np.asarray(PIL.Image.open(f).convert("RGB"))`.  Files outside the kernels' scope are decoded by Pillow on the host
+    and uploaded (the second return value lists their positions).  The list is cut into kernel batches of at most `rgb_budget`
+    bytes of decoded RGB (split_by_pixels), so any number of files of any size may be passed."""
+    device = torch.device(device)
+    out, fallback, good, idx, sizes = [None] * len(files), [], [], [], []
+    for i, f in enumerate(files):
+        try:
+            hd = parse_header(f)
+            good.append(f)
+            idx.append(i)
+            sizes.append((hd["width"], hd["height"]))
+        except Unsupported:
+            fallback.append(i)
+    for run in split_by_pixels(sizes, rgb_budget):
+        _decode_group([good[k] for k in run], [idx[k] for k in run], out, fallback, device)
     for i in fallback:
         out[i] = torch.from_numpy(_pil_rgb(files[i])).to(device)
     return out, sorted(fallback)

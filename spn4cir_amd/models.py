@@ -340,6 +340,8 @@ class CIRPlus(nn.Module):
     def element_wise_sum(self, refer_image_feats, text_feats):
         return refer_image_feats + text_feats        # models_negplus.py:48-50
 
+    element_wise_sum._spn_fused_sum = True           # validate._predict: this Combiner has a fused kernel (spn_combine_l2norm_fwd)
+
     # ------------------------------------------------------------------------------ step
     def _refer_rows(self, indexs, refer_indexs):
         idx = refer_indexs if self.plus else indexs      # models_negplus.py:132-135

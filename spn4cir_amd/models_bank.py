@@ -24,5 +24,7 @@ class CIRPlus(_m.CIRPlus):
             text_feats = torch.nn.functional.normalize(text_feats)
         return refer_image_feats + text_feats
 
+    element_wise_sum._spn_fused_sum = True            # with the default need_norm=False it IS the plain sum (validate._predict)
+
     def forward(self, refer_image, text, target_image, indexs, target_indexs, refer_indexs, grad_ckpt=False):
         return super().forward(text, indexs, target_indexs, refer_indexs)

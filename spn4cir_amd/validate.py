@@ -67,7 +67,14 @@ def _predict(model, captions, ref_idx, index_features):
     tower, and a bf16 training forward here would overwrite the activations of a pending backward."""
     with torch.no_grad():
         text = model.encode_text(captions)
-    q, _, _ = ops.combine_l2norm_fwd(index_features, ref_idx, text.float().contiguous())
+        fn = getattr(model, "combining_function", None)
+        if fn is None or getattr(getattr(fn, "__func__", fn), "_spn_fused_sum", False):
+            # the built-in element-wise sum (models_negplus.py:48-50): gather + add + normalise in ONE launch
+            q, _, _ = ops.combine_l2norm_fwd(index_features, ref_idx, text.float().contiguous())
+            return q
+        # any other Combiner a user put on the model (validate.py:92,206 call the attribute): run it, then F.normalize
+        mixed = fn(index_features[ref_idx], text)
+        q, _, _ = ops.combine_l2norm_fwd(None, None, mixed.to(index_features.device, torch.float32).contiguous())
     return q
 
 

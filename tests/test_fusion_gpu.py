@@ -495,3 +495,53 @@ def test_packed_text_rows_match_dense(S, E):
     holey[0, 3] = 0
     enc.forward(ids, holey, tokens)
     assert enc._last[1].T == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(1, 8), (4, 9)])
+def test_packed_full_batch_stays_inside_the_arena(B, L, monkeypatch):
+    """T == B * L (an all-ones host mask: B = 1, or captions that tokenise to equal length under padding='longest') is the
+    one packed batch whose arena is LARGER than the dense one (the index arrays come on top of the same rows).  The encoder's
+    buffers carry a guard band here; forward + backward must leave it untouched and match the dense rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from spn4cir_amd import fusion as fusion_mod, ops
+    from spn4cir_amd._lib import lib
+    GUARD = 1 << 16
+    made = []
+
+    def guarded(nbytes, device):
+        buf = torch.full((int(nbytes) + GUARD,), 0xA5, dtype=torch.uint8, device=device)
+        made.append((buf, int(nbytes)))
+        return buf[:int(nbytes)]
+    monkeypatch.setattr(ops, "scratch_bytes", guarded)
+    monkeypatch.setattr(fusion_mod.ops, "scratch_bytes", guarded)
+    g = torch.Generator().manual_seed(5)
+    W, H, layers, I, E, Dp, vocab, S = 128, 2, 2, 256, 128, 64, 100, 70
+    enc = fusion_mod.FusionEncoder(W, layers, H, I, E, Dp, vocab, 40, "cuda")
+    if lib().spn_fusion_packed_ok(C.byref(enc._cfg(B, L, S))) != 1:
+        pytest.skip("SPN_XATTN_ABSORB=0: dense rows only")
+    with torch.no_grad():
+        for k, v in enc.named_views().items():
+            v.copy_(((1.0 if k.endswith("LayerNorm.weight") else 0.0) + 0.05 * torch.randn(v.shape, generator=g)).cuda())
+    enc.mark_stale()
+    mask = torch.ones(B, L, dtype=torch.int32)
+    ids = torch.randint(1, vocab, (B, L), generator=g, dtype=torch.int32)
+    tokens = torch.randn(B, S, E, generator=g).cuda()
+    dproj = torch.randn(B, Dp, generator=g).cuda()
+    out_p = enc.forward(ids, mask, tokens).clone()
+    assert enc._last[1].T == B * L
+    g_p = enc.backward(dproj).clone()
+    torch.cuda.synchronize()
+    # the C-side sizes: the dense figure now covers the fullest packed batch as well
+    assert lib().spn_fusion_act_bytes(C.byref(enc._cfg(B, L, S))) >= lib().spn_fusion_act_bytes(C.byref(enc._cfg(B, L, S, B * L)))
+    assert lib().spn_fusion_ws_bytes(C.byref(enc._cfg(B, L, S))) >= lib().spn_fusion_ws_bytes(C.byref(enc._cfg(B, L, S, B * L)))
+    arenas = [(b, n) for b, n in made if n > 1]
+    assert len(arenas) >= 2
+    for buf, n in arenas:
+        assert bool((buf[n:] == 0xA5).all()), f"write past a {n}-byte arena"
+    out_d = enc.forward(ids, mask, tokens, pack=False).clone()
+    g_d = enc.backward(dproj).clone()
+    assert (out_p - out_d).abs().max().item() <= 1e-5 * out_d.abs().max().item()
+    assert (g_p - g_d).norm().item() <= 2e-5 * g_d.norm().item()

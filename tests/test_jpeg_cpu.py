@@ -113,3 +113,19 @@ def test_out_of_scope_files_are_refused():
     for name, data in cases.items():
         with pytest.raises(jpeg.Unsupported):
             jpeg.parse_header(data)
+
+
+def test_large_photo_chunks_are_split_by_pixel_budget():
+    """A decode chunk of the bank builders is 1 024 dataset items = 2 048 images; CIRR / NLVR2 web photos are several megapixels.
+    The list is cut into kernel batches by decoded bytes, so neither the 32-bit offsets of the batch description nor the device
+    footprint depend on how many files a caller passes (the reference's per-image path has no limit: data_utils_negplus.py:298-304)."""
+    from spn4cir_amd import jpeg
+    sizes = [(4000, 3000)] * 2048                                  # 36 MB of RGB each: 73.7 GB in one batch would overflow
+    runs = jpeg.split_by_pixels(sizes)
+    assert [k for r in runs for k in r] == list(range(2048))       # order kept, nothing lost
+    per = [sum(3 * sizes[k][0] * sizes[k][1] for k in r) for r in runs]
+    assert max(per) <= jpeg.RGB_BUDGET < 2 ** 31 and len(runs) > 64
+    # one image larger than the budget still gets a run of its own; small files share one
+    runs = jpeg.split_by_pixels([(100, 100), (30000, 20000), (100, 100), (50, 50)], budget=1 << 20)
+    assert runs == [[0], [1], [2, 3]]
+    assert jpeg.split_by_pixels([]) == []

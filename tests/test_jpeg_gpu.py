@@ -40,6 +40,9 @@ def test_decode_batch_matches_pillow_bit_for_bit():
     # a second call on the same stream reuses nothing of the first (fresh scratch): same bits
     out2, _ = jpeg.decode_batch(files[:9], "cuda")
     assert all(torch.equal(a, b) for a, b in zip(out[:9], out2))
+    # a tiny pixel budget cuts the list into many kernel batches (what large-photo datasets hit at the default budget): same bits
+    out3, fb3 = jpeg.decode_batch(files, "cuda", rgb_budget=40000)
+    assert fb3 == [5] and all(torch.equal(a, b) for a, b in zip(out, out3))
 
 
 def test_deferred_preprocessing_equals_host_decode(tmp_path):

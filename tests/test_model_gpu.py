@@ -180,6 +180,41 @@ def test_recall_metrics_match_reference(golden_dir):
     assert np.allclose(pred.cpu().numpy(), z["pred"], atol=1e-6)
 
 
+def test_validation_calls_the_combiner_seam(golden_dir):
+    """validate.py:92,206 call `model.combining_function` - the Combiner API the reference's scripts rely on.  The fused
+    gather + sum + normalise kernel is only a fast path for the built-in element-wise sum; any other callable put on the
+    attribute (here zscir/models_bank.py:49-54's need_norm=True variant) must be what validation runs."""
+    _need_gpu()
+    import functools
+    from spn4cir_amd import validate
+    from spn4cir_amd.models_bank import CIRPlus
+    z = np.load(os.path.join(golden_dir, "recall.npz"))
+    names = json.loads(str(z["names"]))
+    gallery = torch.from_numpy(z["gallery"]).cuda()
+    text = torch.from_numpy(z["text_feats"]).cuda()
+    ref_idx, tgt_idx = z["ref_idx"], z["tgt_idx"]
+    rows = [(names[r], names[t], [f"cap a {i}.", f"cap b {i}?"]) for i, (r, t) in enumerate(zip(ref_idx, tgt_idx))]
+    calls = []
+
+    class Swapped(_StubModel):
+        def combining_function(self, ref, txt):
+            calls.append(ref.shape[0])
+            return CIRPlus.element_wise_sum(self, ref, txt, need_norm=True)
+    pred, _, _ = validate.generate_fiq_val_predictions(Swapped(text, 64), rows, names, gallery)
+    assert sum(calls) == len(rows)
+    g, t = torch.from_numpy(z["gallery"]), torch.from_numpy(z["text_feats"])
+    F = torch.nn.functional
+    want = F.normalize(F.normalize(g[torch.from_numpy(ref_idx).long()]) + F.normalize(t), dim=-1)
+    assert np.allclose(pred.cpu().numpy(), want.numpy(), atol=1e-6)
+    assert not np.allclose(want.numpy(), z["pred"], atol=1e-3)                  # it really is a different Combiner
+    # the built-in sums keep the fused kernel and the reference's numbers; a bound method with the default need_norm too
+    stub = _StubModel(text, 64)
+    stub.combining_function = functools.partial(CIRPlus.element_wise_sum, stub)  # not marked: goes through the seam, same result
+    pred2, _, _ = validate.generate_fiq_val_predictions(stub, rows, names, gallery)
+    assert np.allclose(pred2.cpu().numpy(), z["pred"], atol=1e-6)
+    assert getattr(CIRPlus.element_wise_sum, "_spn_fused_sum", False)
+
+
 def test_vision_tower_matches_reference(golden_dir):
     """CLIP.encode_image through the HIP kernels vs the reference's fp32 CPU output (tiny ViT, patch 16)."""
     _need_gpu()
