@@ -522,7 +522,7 @@ int spn_xattn_fwd(const void* q, const void* wkv, const void* wkv_t, const float
     hipStream_t st = ST(stream);
     int rc = xattn_head_expand(CBF(q), W, CBF(wkv_t), 2 * W, 0, BF(qa), rows, H, E, scale, st);
     if (rc == SPN_OK) rc = xattn_scores_softmax(CBF(qa), CBF(x), BF(p), B, L * H, S, E, st, cu, H);
-    if (rc == SPN_OK) rc = xattn_apply(CBF(p), CBF(x), BF(oa), B, L * H, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_apply(CBF(p), CBF(x), BF(oa), B, L * H, S, E, st, cu, H, (int64_t)rows * H);
     if (rc == SPN_OK) rc = xattn_head_contract(CBF(oa), CBF(wkv), W, bkv, BF(ctx), W, rows, H, E, 1.0f, st);
     return rc;
 }
@@ -540,7 +540,7 @@ int spn_xattn_bwd(const void* dctx, const void* ctx, const void* q, const void* 
     int rc = xattn_delta(CBF(dctx), CBF(ctx), bkv + W, delta, rows, H, st);
     if (rc == SPN_OK) rc = xattn_head_expand(CBF(dctx), W, CBF(wkv_t), 2 * W, W, BF(doa), rows, H, E, 1.0f, st);
     if (rc == SPN_OK) rc = xattn_dscores(CBF(doa), CBF(x), CBF(p), delta, BF(ds), B, R, S, E, st, cu, H);
-    if (rc == SPN_OK) rc = xattn_apply(CBF(ds), CBF(x), BF(dqa), B, R, S, E, st, cu, H);
+    if (rc == SPN_OK) rc = xattn_apply(CBF(ds), CBF(x), BF(dqa), B, R, S, E, st, cu, H, (int64_t)rows * H);
     if (rc == SPN_OK) rc = xattn_head_contract(CBF(dqa), CBF(wkv), 0, nullptr, BF(dq), W, rows, H, E, scale, st);
     if (rc == SPN_OK)
         rc = xattn_wgrad(CBF(q), 0, CBF(dqa), 0, CBF(dctx), 0, CBF(oa), 0, dwkv, dbkv, 0, 1, rows, W, H, E, scale, st);

@@ -331,7 +331,7 @@ int fusion_fwd(const FusionCfg& c, const float* params, const bf16_t* wb, const 
             // scores = (0.125 q_h Wk_h) X^T, ctx_h = (softmax X) Wv_h^T + bv_h: K and V are never formed (xattn.hip)
             SPN_TRYF(xattn_head_expand(a.q2, W, Bw(BO_CA_WKV_T), 2 * W, 0, a.qa, Tn, c.H, E, 0.125f, st));
             SPN_TRYF(xattn_scores_softmax(a.qa, A.enc_b, a.pm, c.B, Rn, c.S, E, st, cun, c.H));
-            SPN_TRYF(xattn_apply(a.pm, A.enc_b, a.oa, c.B, Rn, c.S, E, st, cun, c.H));
+            SPN_TRYF(xattn_apply(a.pm, A.enc_b, a.oa, c.B, Rn, c.S, E, st, cun, c.H, (int64_t)Tn * c.H));
             SPN_TRYF(xattn_head_contract(a.oa, Bw(BO_CA_WKV), W, P(LO_CA_BKV), a.ctx2, W, Tn, c.H, E, 1.0f, st));
         } else {
             SPN_TRYF(nt(A.enc_b, Bw(BO_CA_WKV), TS, 2 * W, E, P(LO_CA_BKV), a.kv2, nullptr, st));
@@ -554,7 +554,7 @@ static int fusion_bwd_impl(const FusionCfg& c, const float* params, const bf16_t
             SPN_TRYF(xattn_delta(dctx_ca, a.ctx2, P(LO_CA_BKV) + W, delta, Tn, c.H, st));
             SPN_TRYF(xattn_head_expand(dctx_ca, W, Bw(BO_CA_WKV_T), 2 * W, W, doa, Tn, c.H, E, 1.0f, st));         // dO' = dctx_h Wv_h
             SPN_TRYF(xattn_dscores(doa, A.enc_b, a.pm, delta, dsm, c.B, R, c.S, E, st, cun, c.H));                // dS
-            SPN_TRYF(xattn_apply(dsm, A.enc_b, dqa_l, c.B, R, c.S, E, st, cun, c.H));                             // dQ' = dS X
+            SPN_TRYF(xattn_apply(dsm, A.enc_b, dqa_l, c.B, R, c.S, E, st, cun, c.H, (int64_t)Tn * c.H));                            // dQ' = dS X
             SPN_TRYF(xattn_head_contract(dqa_l, Bw(BO_CA_WKV), 0, nullptr, dq_ca, W, Tn, c.H, E, 0.125f, st));    // dq_h
             if (!grouped || pl)
                 SPN_TRYF(xattn_wgrad(a.q2, 0, dqa_l, 0, dctx_ca, 0, a.oa, 0, G(LO_CA_WKV), G(LO_CA_BKV), 0, 1, Tn, W, c.H, E, 0.125f, st));

@@ -206,8 +206,16 @@ int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int
                          const int32_t* cu = nullptr, int H = 0);
 int xattn_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const float* delta, bf16_t* dS, int B, int R, int S, int E,
                   hipStream_t st, const int32_t* cu = nullptr, int H = 0);
+// total_rows: sum of the samples' rows (packed: T * H; 0 = dense, B * R) - picks the row tile of the apply kernel
 int xattn_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, hipStream_t st, const int32_t* cu = nullptr,
-                int H = 0);
+                int H = 0, int64_t total_rows = 0);
+// xattn2.hip: the 8-wave second generation of the three large products (SPN_XATTN_V2=0: first generation)
+bool xattn2_on();
+bool xattn2_apply_ok(int E);
+int xattn2_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int R, int S, int E, hipStream_t st, const int32_t* cu, int H);
+int xattn2_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const float* delta, bf16_t* dS, int B, int R, int S, int E,
+                   hipStream_t st, const int32_t* cu, int H);
+int xattn2_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, hipStream_t st, const int32_t* cu, int H);
 int xattn_delta(const bf16_t* dctx, const bf16_t* ctx, const float* bv, float* delta, int T, int H, hipStream_t st);
 int xattn_wgrad(const bf16_t* q, size_t q_stride, const bf16_t* dqa, size_t dqa_stride, const bf16_t* dctx, size_t dctx_stride,
                 const bf16_t* oa, size_t oa_stride, float* dW, float* dbias, size_t g_stride, int layers, int T, int W, int H, int E,

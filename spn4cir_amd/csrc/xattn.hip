@@ -14,6 +14,7 @@
 // All kernels are built from the 128 x 128 x 64 tile primitives of gemm_v1_tiles.h; the per-sample operands are addressed through
 // buffer descriptors over exactly one sample, so the ragged S = 577 (rows 577..639 of a tile) reads as zero.
 // Rows of a sample are r = l * H + h (the memory order of [T, H, E]); R = L * H; SP = S rounded up to 128.
+#include <math.h>
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -614,6 +615,7 @@ int xattn_scores_softmax(const bf16_t* Q, const bf16_t* X, bf16_t* P, int B, int
     // (8 / 12 waves, one workgroup per CU, the sample's X streamed once for 2 / 3 x the rows) 127 / 137 us against 123; 48 rows
     // (1 x 4 waves of 48 x 32, two exact rounds of 1 024 workgroups) 130 us dense / 103 packed against 121 / 108.
     ProfScope prof(PK_ATTN_FWD, 2.0 * B * R * (double)S * E, st);
+    if (xattn2_on()) return xattn2_scores_softmax(Q, X, P, B, R, S, E, st, cu, H);
     if (xattn_sp(S) == 256) return launch_scores_softmax<2, 2, 2, 2>(Q, X, P, B, R, S, E, st, cu, H);
     return launch_scores_softmax<5, 2, 2, 2>(Q, X, P, B, R, S, E, st, cu, H);
 }
@@ -626,17 +628,27 @@ int xattn_dscores(const bf16_t* dO, const bf16_t* X, const bf16_t* P, const floa
     const int SP = xattn_sp(S);
     const int tiles = B * ((R + BM - 1) / BM) * (SP / BN);
     ProfScope prof(PK_ATTN_BWD, 2.0 * B * R * (double)S * E, st);
+    if (xattn2_on()) return xattn2_dscores(dO, X, P, delta, dS, B, R, S, E, st, cu, H);
     hipLaunchKernelGGL(xattn_dscores_kernel, dim3(tiles), dim3(NTHREADS), LDS, st, dO, X, P, delta, dS, R, S, E, SP, cu, H);
     SPN_CHECK_LAUNCH();
     return SPN_OK;
 }
 
-int xattn_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, hipStream_t st, const int32_t* cu, int H) {
+int xattn_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, hipStream_t st, const int32_t* cu, int H,
+                int64_t total_rows) {
     constexpr int LDS = 4 * TILE_BYTES;
     static const int rc0 = xattn_lds(xattn_apply_kernel, LDS);
     if (rc0) return rc0;
     const int tiles = B * ((R + BM - 1) / BM) * (E / BN);
     ProfScope prof(PK_ATTN_FWD, 2.0 * B * R * (double)S * E, st);
+    // 192-row tiles of the 8-wave kernel against the 128-row tiles here: ragged samples (packed rows) waste the tail of their last
+    // tile, so the kernel is picked by the row slots each would run for the AVERAGE sample, weighted by the measured time per
+    // slot (0.88, B = 128 dense: 65.4 against 74.6 us; profiles/r06_xattn_ab.txt)
+    if (xattn2_on() && xattn2_apply_ok(E)) {
+        const double avg = cu && total_rows > 0 ? (double)total_rows / B : (double)R;
+        const double slots2 = ceil(avg / 192.0) * 192.0 * 0.88, slots1 = ceil(avg / 128.0) * 128.0;
+        if (slots2 <= slots1) return xattn2_apply(A, X, out, B, R, S, E, st, cu, H);
+    }
     hipLaunchKernelGGL(xattn_apply_kernel, dim3(tiles), dim3(NTHREADS), LDS, st, A, X, out, R, S, E, xattn_sp(S), cu, H);
     SPN_CHECK_LAUNCH();
     return SPN_OK;

@@ -1111,8 +1111,11 @@ def test_gemm_tn_grouped(ops, Kr, shapes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,E,packed", [(70, 128, False), (197, 256, True), (577, 128, False), (577, 256, True)])
-def test_xattn_absorbed_matches_torch(S, E, packed):
+@pytest.mark.parametrize("S,E,packed,L,H", [(70, 128, False, 9, 2), (197, 256, True, 9, 2), (577, 128, False, 9, 2), (577, 256, True, 9, 2),
+                                            # several row tiles of the 8-wave kernels (96 rows; apply: 192 rows x 384 / 256 columns),
+                                            # ragged last tiles, both column-tile widths of the apply kernel
+                                            (577, 384, True, 70, 4), (577, 768, False, 25, 4), (130, 512, True, 40, 6)])
+def test_xattn_absorbed_matches_torch(S, E, packed, L, H):
     """spn_xattn_fwd / spn_xattn_bwd (cross-attention over frozen tokens with the K/V projections absorbed into the query and
     output side, csrc/xattn.hip) against the textbook form in fp32 torch: K = X Wk^T + bk, V = X Wv^T + bv, softmax(q K^T / 8) V
     per head (blip4cir/med.py:196-234), autograd for dq, dWkv, dbkv.  Dense and packed rows, both column-tile instantiations."""
@@ -1120,9 +1123,9 @@ def test_xattn_absorbed_matches_torch(S, E, packed):
         pytest.skip("no GPU")
     from spn4cir_amd import ops
     g = torch.Generator().manual_seed(S + E)
-    B, L, H = 5, 9, 2
+    B = 5
     W = H * 64
-    lens = torch.tensor([9, 1, 4, 9, 6]) if packed else torch.full((B,), L)
+    lens = torch.tensor([L, 1, (4 * L) // 9, L, (2 * L) // 3]) if packed else torch.full((B,), L)
     rows = int(lens.sum())
     bf = torch.bfloat16
     q = (torch.randn(rows, W, generator=g)).to(bf)
