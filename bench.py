@@ -38,7 +38,17 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
-FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 2MD + projection
+FLOP_PER_TRIPLET = 40.0e9     # 3 x 13.30 G (tower) + 2 x 2MD + projection (the REFERENCE's arithmetic)
+# What the path EXECUTES per triplet: since round 5 the last block's out-projection + MLP (90.8 + 726.7 MFLOP forward per 77-row
+# sequence) run on the pooled EOT row only - forward, data gradient and weight gradient lose 76 / 77 of that
+# (spn_text_cfg.pool; SPN_POOL_LAST=0 computes every row again)
+POOLED_SAVING = 3 * (90.8e6 + 726.7e6) * 76.0 / 77.0
+
+
+def executed_flop_per_triplet():
+    from spn4cir_amd import _lib
+    off = (_lib.env("SPN_POOL_LAST") or "").strip() == "0"
+    return FLOP_PER_TRIPLET - (0.0 if off else POOLED_SAVING)
 
 # attention at L = 77, head_dim 64 has 39 flop per byte of q/k/v/o traffic (ridge: 312): it is bounded by HBM, and is
 # priced on its algorithmic bytes (fwd: read qkv, write o = 8 W B per token; bwd: read qkv, o, dO, write dqkv = 16 W B)
@@ -256,8 +266,10 @@ def blip_config4_block(args, dev):
             res[rows] = {"value": round(B / dt, 1), "unit": "triplets/sec", "ms_per_step": round(dt * 1e3, 3),
                          "loss_last": round(float(loss.item()), 5)}
             if rows == "dense":
-                res[rows].update({"model_tflops": round(alg / dt / 1e12, 1),
-                                  "frac_of_bf16_peak": round(alg / dt / 1e12 / PEAK_BF16_TFLOPS, 4)})
+                # priced at the REFERENCE's arithmetic (K/V-projection form, every text row through all 12 layers); the path executes
+                # less: absorbed cross-attention (204 instead of 369 GFLOP per layer) and a pooled last layer
+                res[rows].update({"reference_arith_tflops": round(alg / dt / 1e12, 1),
+                                  "frac_of_bf16_peak_reference_arith": round(alg / dt / 1e12 / PEAK_BF16_TFLOPS, 4)})
             else:
                 res[rows]["text_rows_live"] = f"{int(lens.sum())} of {B * L}"
         out[f"enc_width_{E}"] = res
@@ -646,13 +658,31 @@ def main():
 
     trainer.pack = False
     # N > 1: the other bank mode, measured briefly with the same barrier / max-over-ranks protocol (not the headline)
+    extras_dead = [False]
+
     def guarded(fn):
-        """An extra measurement must never cost the headline: a failure (the same on every rank: the code path is) is reported in
-        the JSON line instead of raised."""
+        """An extra measurement must never cost the headline: a failure is reported in the JSON line instead of raised.  N > 1: a
+        rank that failed alone has left its peers inside a collective or will skip the next one - the ranks agree on an error flag
+        after every extra (MAX all-reduce), and once any rank failed, no further extra (each of them enters collectives) is started
+        on any rank."""
+        if extras_dead[0]:
+            return {"error": "skipped: an earlier extra measurement failed on some rank"}
+        err = None
         try:
-            return fn()
+            res = fn()
         except Exception as exc:          # noqa: BLE001
-            return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            err = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        if world > 1:
+            try:
+                flag = torch.tensor([1.0 if err else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0:
+                    extras_dead[0] = True
+                    err = err or {"error": "another rank failed in this measurement"}
+            except Exception as exc:      # noqa: BLE001  (the group itself is broken: nothing collective can follow)
+                extras_dead[0] = True
+                err = err or {"error": f"error-flag exchange failed: {exc}"[:300]}
+        return err if err else res
 
     alt = None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
@@ -678,7 +708,7 @@ def main():
     # N > 1: two more brief measurements with the same protocol, so that the first multi-GPU run settles what DESIGN.md section 6
     # only predicts - (a) STRONG scaling: config 3's B_global = 256 split over the ranks (256 / N per GPU; SURVEY 8d asks for
     # both regimes), (b) the gradient buckets exchanged as bf16 (all-to-all + fp32 rank-order sum + all-gather) at the weak shape
-    strong, comm16, comm_direct, collectives = None, None, None, None
+    strong, comm16, comm_direct, collectives, zero1, zero1_strong = None, None, None, None, None, None
     if (world > 1 or force_dp) and not args.no_alt_bank_mode:
         def brief(tr, ids_, ridx_, labels_, host_, bglob):
             for _ in range(max(2, args.warmup)):
@@ -694,16 +724,17 @@ def main():
                 dist.all_reduce(d_, op=dist.ReduceOp.MAX)
             return {"value": round(bglob * n_ / d_.item(), 1), "unit": "triplets/sec", "ms_per_step": round(d_.item() / n_ * 1e3, 3),
                     "steps": n_}
-        def measure_strong():
+        def measure_strong(**kw):
             bs = 256 // world
             ids_s = synthetic.token_ids(256, seed=1)
             ridx_s, lab_s = synthetic.triplet_indices(256, args.bank, seed=4)
             sl_s = slice(rank * bs, (rank + 1) * bs)
-            tr3 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False)
+            tr3 = Stage2Trainer(model, lr=2e-5, group=group, bank_mode=args.bank_mode, pack=False, **kw)
             tr3.set_banks(refer, target)
             host_s = ids_s[sl_s].contiguous() if ids_host is not None else None
             r = brief(tr3, ids_s[sl_s].to(dev), ridx_s[sl_s].to(dev), lab_s[sl_s].to(dev), host_s, 256)
             r.update(scaling="strong", global_batch=256, batch_per_gpu=bs, bank_mode=args.bank_mode)
+            r.update(kw)
             return r
 
         def measure_comm(**kw):
@@ -768,6 +799,13 @@ def main():
                 out_["overlap_fraction"] = round(max(0.0, min(1.0, hidden)), 3)
             return out_
         collectives = guarded(measure_collectives)
+        # sharded optimizer step (ZeRO-1 shape, Stage2Trainer(optim="sharded")): the direct exchange's reduced chunk is updated by
+        # its owner and the masters are all-gathered - beside the replicated update of the headline, at both scaling shapes
+        zero1 = guarded(lambda: measure_comm(optim="sharded"))
+        zero1["note"] = ("weak-scaling shape; AdamW runs on each rank's 1 / G slice of every bucket, the updated fp32 masters are "
+                         "all-gathered instead of the reduced gradients (same link bytes as grad_comm_direct_fp32)")
+        if 256 % world == 0 and 256 // world >= 8:
+            zero1_strong = guarded(lambda: measure_strong(optim="sharded"))
         comm_direct = guarded(lambda: measure_comm(grad_comm_algo="direct"))
         comm_direct["note"] = ("weak-scaling shape; fp32 buckets through all-to-all + rank-order sum + all-gather (every xGMI link at "
                                "once) instead of RCCL's all-reduce")
@@ -842,13 +880,16 @@ def main():
                        "global_batch": B_global, "seq_len": 77, "bank_rows": args.bank, "embed_dim": D,
                        "parallelism": f"dp{world}" + (f"+bank-{args.bank_mode}" if world > 1 else "")},
             "loss_last": round(loss_val, 5),
-            "step_model_tflops": round(tps * FLOP_PER_TRIPLET / 1e12 / world, 1),
-            "step_frac_of_bf16_peak": round(tps * FLOP_PER_TRIPLET / 1e12 / world / PEAK_BF16_TFLOPS, 4),
-            "step_flop_note": "step_model_tflops prices the step at the REFERENCE's arithmetic (SURVEY 8d: every one of the 77 rows "
-                              "through all 12 blocks).  The path executes less since round 5: the last block's out-projection / "
-                              "MLP (forward, data and weight gradients) run on the B pooled EOT rows only (spn_text_cfg.pool; "
-                              "clip/model.py:352-356 reads one row per caption) - 9/12 of one block of 12, i.e. ~0.94 of that "
-                              "arithmetic; `roofline.achieved` counts the flops of the launches actually made",
+            # primary: the flops the path EXECUTES (dense 77-row captions; the pooled last block runs on B rows)
+            "step_model_tflops": round(tps * executed_flop_per_triplet() / 1e12 / world, 1),
+            "step_frac_of_bf16_peak": round(tps * executed_flop_per_triplet() / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+            # the same step priced at the reference's arithmetic (every one of the 77 rows through all 12 blocks)
+            "step_reference_arith_tflops": round(tps * FLOP_PER_TRIPLET / 1e12 / world, 1),
+            "step_frac_of_bf16_peak_reference_arith": round(tps * FLOP_PER_TRIPLET / 1e12 / world / PEAK_BF16_TFLOPS, 4),
+            "step_flop_note": f"executed = {executed_flop_per_triplet() / 1e9:.2f} GFLOP per triplet against the reference's "
+                              f"{FLOP_PER_TRIPLET / 1e9:.1f}: the last block's out-projection / MLP (forward, data and weight "
+                              "gradients) run on the B pooled EOT rows only (spn_text_cfg.pool; clip/model.py:352-356 reads one row "
+                              "per caption); `roofline.achieved` counts the flops of the launches actually made",
             "roofline": roof,
             # every SPN_* variable the library saw when it was loaded (its A/B switches read that snapshot only): a stray
             # one that changes a kernel is visible next to the number
@@ -865,6 +906,10 @@ def main():
             out["grad_comm_bf16"] = comm16
         if comm_direct:
             out["grad_comm_direct_fp32"] = comm_direct
+        if zero1:
+            out["optim_sharded"] = zero1
+        if zero1_strong:
+            out["optim_sharded_strong"] = zero1_strong
         if collectives:
             out["collectives"] = collectives
         if world == 1 and not args.no_recall:     # checker legs run at N = 1 only: the other ranks would sit in the exit barrier
@@ -875,6 +920,25 @@ def main():
                 out["recall"] = rec
         if world == 1 and not args.no_extra_configs:
             del trainer
+            torch.cuda.empty_cache()
+
+            def dropin_block():
+                """What a maintainer who only swaps the import sees: the reference's OWN loop bodies
+                (train_negplus.py:107-123, blip4cir/train.py:110-129) on the drop-in CIRPlus objects - caption strings tokenised
+                on the host every step, autograd backward, GradScaler, a host read of the loss per step - with torch.optim.AdamW
+                and with the one-line switch to spn4cir_amd.optim.AdamW.  tools/dropin_step.py, tools/dropin_blip_step.py."""
+                import importlib.util
+                res = {}
+                for key, fname, kw in (("clip_config2", "dropin_step.py", {}), ("blip_config4", "dropin_blip_step.py", {"images": 2000})):
+                    spec = importlib.util.spec_from_file_location("spn_" + key, os.path.join(ROOT, "tools", fname))
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    res[key] = [mod.run(fused_optim=f, steps=8, warmup=2, **kw) for f in (False, True)]
+                    torch.cuda.empty_cache()
+                res["note"] = ("strings in, loss read on the host every step (as the reference formats it), packed rows (the default for "
+                               "host ids / masks); compare with packed_eot (CLIP) and blip_config4.*.packed (fused trainers, no host sync)")
+                return res
+            out["dropin_loop"] = guarded(dropin_block)
             torch.cuda.empty_cache()
             out["blip_config4"] = guarded(lambda: blip_config4_block(args, dev))       # extras never cost the headline line
             torch.cuda.empty_cache()

@@ -232,11 +232,14 @@ class BertWordPieceTokenizer:
             texts = [texts]
         rows = [self.encode(t) for t in texts]
         L = max((len(r) for r in rows), default=0)
-        ids = torch.full((len(rows), L), self.pad_token_id, dtype=torch.int64)
-        mask = torch.zeros((len(rows), L), dtype=torch.int64)
-        for i, r in enumerate(rows):
-            ids[i, :len(r)] = torch.tensor(r, dtype=torch.int64)
-            mask[i, :len(r)] = 1
+        if not rows or L == 0:
+            return torch.zeros((len(rows), L), dtype=torch.int64), torch.zeros((len(rows), L), dtype=torch.int64)
+        # one tensor construction for the whole batch: a per-row slice assignment costs ~15 us of host time each, 2 ms per
+        # 128-caption step in front of every device launch of the step (the reference loop syncs on the loss every step)
+        pad = self.pad_token_id
+        ids = torch.tensor([r + [pad] * (L - len(r)) for r in rows], dtype=torch.int64)
+        lens = torch.tensor([len(r) for r in rows], dtype=torch.int64)
+        mask = (torch.arange(L, dtype=torch.int64)[None, :] < lens[:, None]).to(torch.int64)
         return ids, mask
 
     def __call__(self, texts, padding="longest", return_tensors="pt", **unused):

@@ -312,20 +312,27 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_rows_kernel(const bf16_t
 
 // ----------------------------------------------------------------------------------------------------------------------------
 // apply: out[b, r, :] = A[b, r, 0..SPA) . X[b, 0..S, :]   (A = P or dS, k-contiguous; X reduction-major).  Tile 192 rows x
-// NJ * 64 columns (NJ = 6: 384, NJ = 4: 256), waves 2 x 4, wave tile 96 x NJ * 16.  k steps of 32 rows of X, three LDS stages:
+// NJ * 64 columns (NJ = 6: 384, NJ = 4: 256), waves 2 x 4, wave tile 96 x NJ * 16.  k steps of 32 rows of X, FOUR LDS stages:
 // A image [192][32 k] (12 KB) + NJ / 2 panels of [32 k][128 n] (8 KB each).
+// A k step is two phases of 3 x NJ MFMA (row tiles 0-2, then 3-5 of the wave) with the next phase's fragments prefetched:
+//     phase 1: MFMA rows 0-2 (a0, b)  ||  read a1 = A rows 3-5 of stage s          requests: second half of stage s + 3
+//     counted vmcnt wait (stage s + 1 landed), lgkmcnt(0), barrier                 -> buffer of stage s free, stage s + 1 visible
+//     phase 2: MFMA rows 3-5 (a1, b)  ||  read b', a0 of stage s + 1               requests: first half of stage s + 4
+// (b double-buffered across steps).  Requests go out one per MFMA group, as in the rows kernel.
 // ----------------------------------------------------------------------------------------------------------------------------
 template <int NJ>
 __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_apply_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ X,
                                                                     bf16_t* __restrict__ out, int R, int S, int E, int SPA,
                                                                     const int32_t* __restrict__ cu, int H) {
-    constexpr int MI = 6, BMA = 192, BNA = NJ * 64, PANELS = BNA / 128;
-    constexpr int GA = BMA / 16, GB = PANELS * 8, G = GA + GB;           // 1 KB DMA instructions per stage
+    constexpr int BMA = 192, BNA = NJ * 64, PANELS = BNA / 128, NST = 4;
+    constexpr int GA = BMA / 16, GB = PANELS * 8, G = GA + GB;           // 1 KB DMA requests per stage
     constexpr int A_BYTES = BMA * 64, STAGE = A_BYTES + PANELS * 8192;
     constexpr int REQ_HI = (G + X2_WAVES - 1) / X2_WAVES, REQ_LO = G / X2_WAVES;
+    constexpr int REQ_P2 = (REQ_HI + 1) / 2;                             // requests 0 .. REQ_P2 - 1 go out in phase 2, the rest in phase 1
     constexpr int PITCH = BNA * 2 + 16;
-    static_assert(96 * PITCH <= 3 * STAGE, "the output image (one row half at a time) aliases the operand stages");
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x STAGE
+    static_assert(96 * PITCH <= NST * STAGE, "the output image (one row half at a time) aliases the operand stages");
+    static_assert(G % X2_WAVES != 0 && REQ_P2 <= REQ_LO && REQ_P2 <= 3 && REQ_HI - REQ_P2 <= 3, "request bookkeeping below");
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // NST x STAGE
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int tiles_n = E / BNA, tiles_m = (R + BMA - 1) / BMA;
@@ -360,18 +367,14 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_apply_kernel(const bf16_
             else glds16(rsB, dst, voff[i] + (uint32_t)kt * (uint32_t)(X2_BK * 2) * (uint32_t)E);
         }
     };
-    auto stage = [&](int kt, int buf) {
+    f32x4 acc[6][NJ];
 #pragma unroll
-        for (int i = 0; i < REQ_HI; ++i) stage_one(i, kt, buf);
-    };
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint32_t offA[MI], offB[NJ][2];
+    uint32_t offA[6], offB[NJ][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) offA[i] = x2_frag_off(wr * 96 + i * 16 + (lane & 15), lane >> 4);
+    for (int i = 0; i < 6; ++i) offA[i] = x2_frag_off(wr * 96 + i * 16 + (lane & 15), lane >> 4);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int col = wc * NJ * 16 + j * 16, panel = col >> 7, cb = col & 127;
@@ -382,45 +385,98 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_apply_kernel(const bf16_
             offB[j][h] = A_BYTES + panel * 8192 + krow * 256 + p32 * 32 + (lane & 3) * 8;
         }
     }
-    const int nk = SPA / X2_BK;                                          // rows >= S of X read as zero through the descriptor
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
+    const int nk = SPA / X2_BK;                                          // rows >= S of X read as zero through the descriptor; nk >= 8
+    bf16x8 fa[2][3];                                                     // [0]: row tiles 0-2 of a step, [1]: row tiles 3-5
+    TnFrag fb[2][NJ];                                                    // b fragments of step parity 0 / 1
+    auto read_a = [&](auto half_, int buf) {
+        constexpr int HF = decltype(half_)::value;
+        const char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fa[HF][i] = *(const bf16x8*)(s + offA[HF * 3 + i]);
+    };
+    auto read_b = [&](auto par_, int buf) {
+        constexpr int P = decltype(par_)::value;
+        const char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            fb[P][j].h[0] = lds_tr16_b64_asm(s + offB[j][0]);
+            fb[P][j].h[1] = lds_tr16_b64_asm(s + offB[j][1]);
+        }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    // prologue: stages 0 .. 2 and the phase-2 half of stage 3
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int i = 0; i < REQ_HI; ++i) stage_one(i, st, st);
+#pragma unroll
+    for (int i = 0; i < REQ_P2; ++i) stage_one(i, 3, 3);
+    if (more) wait_vmcnt<2 * REQ_HI + REQ_P2>();
+    else wait_vmcnt<2 * REQ_LO + REQ_P2>();
+    __builtin_amdgcn_s_barrier();
+    read_b(C0{}, 0);
+    read_a(C0{}, 0);
+    int b0 = 0, b1 = 1, b3 = 3;                                          // buffers of stages s, s + 1, s + 3 (= s - 1)
+    auto step = [&](auto par_, int s) {
+        constexpr int P = decltype(par_)::value;
+        // ---- phase 1: rows 0-2 against b[P]; a1 of this stage arrives behind them
+        read_a(C1{}, b0);
+        wait_lgkm<3>();                                                  // everything but the three a1 reads just issued: b[P], a0 are in
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            lds_tie(fb[P][j].h[0]);
+            lds_tie(fb[P][j].h[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 bb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bb[j] = tn_tie(fb[P][j]);
+        const bool st1 = s + 3 < nk;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(bb[j], fa[0][i], acc[i][j]);
+            if (REQ_P2 + i < REQ_HI) {                                   // second half of stage s + 3 -> the buffer stage s - 1 left
+                __builtin_amdgcn_sched_barrier(0);
+                if (st1) stage_one(REQ_P2 + i, s + 3, b3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // stage s + 1 has landed once at most the requests of stages s + 2 and s + 3 are outstanding
+        if (s + 3 < nk) {
+            if (more) wait_vmcnt<2 * REQ_HI>();
+            else wait_vmcnt<2 * REQ_LO>();
+        } else if (s + 2 < nk) {
             if (more) wait_vmcnt<REQ_HI>();
             else wait_vmcnt<REQ_LO>();
         } else {
             wait_vmcnt<0>();
         }
-        lds_barrier();
-        const bool do_stage = kt + 2 < nk;
-        const int bfill = buf >= 1 ? buf - 1 : 2;
-        const char* s = smem + buf * STAGE;
-        TnFrag tb[NJ];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): a1 has arrived
+        __builtin_amdgcn_s_barrier();                                    // stage s + 1 visible to all; nobody reads buffer b0 any more
+        // ---- phase 2: rows 3-5 against b[P]; b[1 - P] and a0 of the next stage arrive behind them
+        read_b(std::integral_constant<int, 1 - P>{}, b1);                // (the last step reads a stale buffer and drops it)
+        read_a(C0{}, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool st2 = s + 4 < nk;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            tb[j].h[0] = lds_tr16_b64_asm(s + offB[j][0]);
-            tb[j].h[1] = lds_tr16_b64_asm(s + offB[j][1]);
-        }
-        bf16x8 a[MI], bb[NJ];
+        for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(s + offA[i]);
-        wait_lgkm<0>();
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bb[j] = tn_tie(tb[j]);
-        static_assert(REQ_HI <= MI, "one request per MFMA group");
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(bb[j], a[i], acc[i][j]);
-            if (i < REQ_HI) {                                            // one LDS-DMA request per MFMA group (see the rows kernel)
+            for (int j = 0; j < NJ; ++j) acc[3 + i][j] = mfma16(bb[j], fa[1][i], acc[3 + i][j]);
+            if (i < REQ_P2) {                                            // first half of stage s + 4 -> the buffer of stage s
                 __builtin_amdgcn_sched_barrier(0);
-                if (do_stage) stage_one(i, kt + 2, bfill);
+                if (st2) stage_one(i, s + 4, b0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        b3 = b0;
+        b0 = b1;
+        b1 = b1 == NST - 1 ? 0 : b1 + 1;
+    };
+    for (int s = 0; s < nk; s += 2) {                                    // SPA / 32 is even
+        step(C0{}, s);
+        step(C1{}, s + 1);
     }
     // the two row halves leave one after the other through a [96][BNA] bf16 image: whole 2 * BNA-byte row pieces per instruction
     constexpr int UPR = BNA / 8;
@@ -430,7 +486,7 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_apply_kernel(const bf16_
         __syncthreads();                                                 // k loop / the previous half's readers are done with LDS
         if (wr == half) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+            for (int i = 0; i < 6; ++i) {
                 char* o = img + (i * 16 + (lane & 15)) * PITCH + (wc * NJ * 16 + (lane >> 4) * 4) * 2;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -504,7 +560,7 @@ template <int NJ>
 static int launch_apply(const bf16_t* A, const bf16_t* X, bf16_t* out, int B, int R, int S, int E, int SPA, hipStream_t st,
                         const int32_t* cu, int H) {
     constexpr int BNA = NJ * 64;
-    constexpr int LDS = 3 * (192 * 64 + (BNA / 128) * 8192);
+    constexpr int LDS = 4 * (192 * 64 + (BNA / 128) * 8192);
     static const int rc0 = x2_lds(xattn2_apply_kernel<NJ>, LDS);
     if (rc0) return rc0;
     const int tiles = B * ((R + 191) / 192) * (E / BNA);

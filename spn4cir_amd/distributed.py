@@ -269,6 +269,7 @@ class SparseRowReducer:
 class _HipExchangeKernels:
     """The three elementwise passes of the bf16 gradient exchange on the library's kernels (spn_cast_f32_bf16,
     spn_sum_ranks_bf16, spn_cast_bf16_f32), on torch's current stream."""
+    ALIGN = 4        # elements: the kernels move 16-byte vectors, a slice must start on a 4-element boundary of the flat buffer
 
     @staticmethod
     def to_bf16(src_f32, dst_bf16):
@@ -329,9 +330,23 @@ class GradBucketReducer:
     that produced it carry rounding of the same size).  The passes run on a dedicated stream between the two collectives; the
     host never blocks.  `kernels` = the elementwise passes (the HIP kernels by default; CPU tests inject torch ones)."""
 
-    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20, comm_dtype="fp32", kernels=None, algo=None):
+    def __init__(self, flat_grads, group=None, bucket_elems=8 << 20, comm_dtype="fp32", kernels=None, algo=None,
+                 shard_update=None, flat_params=None):
         if comm_dtype not in ("fp32", "bf16"):
             raise ValueError(comm_dtype)
+        # Sharded optimizer step (ZeRO-1 shape; Stage2Trainer(optim="sharded")): after the first half of the direct exchange
+        # (all-to-all + rank-order sum) rank r holds the REDUCED chunk r of a bucket.  Instead of all-gathering the reduced
+        # gradients and letting every rank update all parameters, `shard_update(lo, hi, grad_f32)` updates flat_params[lo:hi]
+        # on the owner only, and the second collective all-gathers the updated fp32 MASTERS into flat_params[s:e] - the same
+        # link bytes, 1 / G of the optimizer's HBM traffic per rank.  Every replica takes the owner's bits: identical by
+        # construction.  Buckets the direct exchange cannot take (length not a multiple of 4 * world, unaligned start) fall
+        # back to an all-reduce; `sharded_spans` lists what WAS updated, the caller updates the complement itself.
+        if shard_update is not None and flat_params is None:
+            raise ValueError("shard_update needs flat_params")
+        self.shard_update, self.flat_params = shard_update, flat_params
+        self.sharded_spans = []
+        if shard_update is not None:
+            algo = "direct"
         # algo "ring" = one RCCL all-reduce per bucket (fp32 only); "direct" = all-to-all + rank-order sum + all-gather: every
         # rank exchanges one S / G chunk with every other rank over its own xGMI link, all links at once (SURVEY section 5's
         # one-shot reduce-scatter + all-gather, from RCCL's point-to-point collectives).  bf16 implies direct.
@@ -344,6 +359,7 @@ class GradBucketReducer:
         self.world, self.rank = _world(group)
         self.comm_dtype = comm_dtype
         self.kernels = kernels or _HipExchangeKernels
+        self._align = getattr(self.kernels, "ALIGN", 1)
         self._comm_stream = None
         self._pending = []      # [(start, end)] contiguous-or-not spans waiting for a bucket
         self._works = []
@@ -363,9 +379,11 @@ class GradBucketReducer:
             comm = self._comm_stream
             comm.wait_stream(torch.cuda.current_stream())          # the slice is final at this point of the compute stream
         with self._on(comm):
-            # padding behind element n (the tail of the last chunk) stays uninitialised: whatever it sums to lands behind
-            # element n of `full`, which is never read
+            # padding behind element n (the tail of the last chunk): zeros - it is summed and gathered like everything else
+            # (never read back, but uninitialised bf16 can be NaN, and a NaN that travels is a trap for the next change here)
             send = torch.empty(G * m, dtype=torch.bfloat16, device=self.flat.device)
+            if G * m > n:
+                send[n:].zero_()
             self.kernels.to_bf16(self.flat[s:e], send[:n])
             recv = torch.empty(G * m, dtype=torch.bfloat16, device=self.flat.device)
             w1 = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
@@ -398,6 +416,54 @@ class GradBucketReducer:
             w2 = dist.all_gather_into_tensor(self.flat[s:e], red, group=self.group, async_op=True)
         return _Bf16Work(self, s, e, None, w2, comm)
 
+    def _exchange_sharded(self, s, e):
+        """all-to-all (fp32 or bf16 payload) -> rank-order sum -> optimizer on the owned chunk -> all-gather of the updated
+        masters.  None when the bucket does not split into `world` 16-byte aligned chunks (the caller all-reduces it and the
+        trainer updates it on every rank)."""
+        G, n = self.world, e - s
+        if n % (4 * G) or s % self._align:
+            return None
+        m = n // G
+        dev = self.flat.device
+        comm = None
+        if self.flat.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            comm = self._comm_stream
+            comm.wait_stream(torch.cuda.current_stream())          # gradients of [s, e) final; nobody reads its parameters any more
+        with self._on(comm):
+            red = torch.empty(m, dtype=torch.float32, device=dev)
+            if self.comm_dtype == "bf16":
+                send = torch.empty(n, dtype=torch.bfloat16, device=dev)
+                self.kernels.to_bf16(self.flat[s:e], send)
+                recv = torch.empty(n, dtype=torch.bfloat16, device=dev)
+                dist.all_to_all_single(recv, send, group=self.group, async_op=True).wait()
+                red_b = torch.empty(m, dtype=torch.bfloat16, device=dev)
+                self.kernels.sum_ranks(recv, G, red_b)
+                self.kernels.to_f32(red_b, red)
+            else:
+                recv = torch.empty(n, dtype=torch.float32, device=dev)
+                dist.all_to_all_single(recv, self.flat[s:e], group=self.group, async_op=True).wait()
+                self.kernels.sum_ranks_f32(recv, G, red)
+            lo = s + self.rank * m
+            self.shard_update(lo, lo + m, red)
+            own = self.flat_params[lo:lo + m].clone()              # (gloo has no in-place all-gather; S / G elements)
+            w2 = dist.all_gather_into_tensor(self.flat_params[s:e], own, group=self.group, async_op=True)
+        self.sharded_spans.append((s, e))
+        return _Bf16Work(self, s, e, None, w2, comm)
+
+    def complement_spans(self, total):
+        """[0, total) minus the spans the sharded update handled since the last call: what the caller updates on every rank."""
+        out, pos = [], 0
+        for s, e in sorted(self.sharded_spans):
+            if s > pos:
+                out.append((pos, s))
+            pos = max(pos, e)
+        if pos < total:
+            out.append((pos, total))
+        self.sharded_spans = []
+        return out
+
     def _flush(self):
         if not self._pending:
             return
@@ -411,10 +477,14 @@ class GradBucketReducer:
                 merged.append([s, e])
         for s, e in merged:
             work = None
-            if self.comm_dtype == "bf16":
-                work = self._exchange_bf16(s, e)
+            if self.shard_update is not None:
+                work = self._exchange_sharded(s, e)
+            elif self.comm_dtype == "bf16":
+                # the cast / sum kernels move 16-byte vectors: a span that does not start on a 4-element boundary (no tower
+                # here has one) takes the ring all-reduce instead of failing inside wait()
+                work = self._exchange_bf16(s, e) if s % self._align == 0 else None
             elif self.algo == "direct":
-                work = self._exchange_f32(s, e)
+                work = self._exchange_f32(s, e) if s % self._align == 0 else None
             if work is None:
                 work = dist.all_reduce(self.flat[s:e], group=self.group, async_op=True)
             self._works.append((s, e, work))
@@ -426,6 +496,21 @@ class GradBucketReducer:
         self._pending.append((start, end))
         if sum(e - s for s, e in self._pending) >= self.bucket_elems:
             self._flush()
+
+    def finish_unsharded(self):
+        """Sharded-update mode: wait for the fallback all-reduces only; returns the handles of the sharded exchanges (their
+        wait() = the gathered masters are in flat_params and the compute stream is ordered behind them)."""
+        if _skip(self.world):
+            return []
+        self._flush()
+        works, self._works = self._works, []
+        kept = []
+        for _, _, w in works:
+            if isinstance(w, _Bf16Work):
+                kept.append(w)
+            else:
+                w.wait()
+        return kept
 
     def finish(self, keep_span=None):
         """Make the compute stream wait for the all-reduces.  keep_span = (start, end) leaves the all-reduces of

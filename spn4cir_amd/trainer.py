@@ -42,7 +42,8 @@ def wgrad_groups(layers, world):
 
 class Stage2Trainer:
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="replicated", check_finite=False, pack=True, grad_comm_dtype="fp32", grad_comm_algo=None):
+                 bank_mode="replicated", check_finite=False, pack=True, grad_comm_dtype="fp32", grad_comm_algo=None,
+                 optim="replicated"):
         self.model, self.tower = model, model.tower
         # pack (default): when step() gets the ids on the host too (ids_host=), the text tower computes only the rows up to each
         # caption's EOT token - same features bit for bit, same loss and gradients.  The prefix sums are built on the host and go
@@ -62,12 +63,34 @@ class Stage2Trainer:
         # grad_comm_dtype="bf16": the dense gradient buckets cross the links as bf16 (all-to-all + fp32 sum in rank order +
         # all-gather; distributed.GradBucketReducer) - half the bytes, replicas still bit-identical
         # grad_comm_algo="direct" (fp32): the same exchange with fp32 payloads instead of RCCL's ring all-reduce
-        self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype, algo=grad_comm_algo)
+        # optim="sharded" (data parallel; ZeRO-1 shape): a bucket's reduced gradient chunk is consumed where the first half of the
+        # direct exchange leaves it - the owner runs AdamW on its 1 / G slice and the second collective all-gathers the updated
+        # fp32 masters instead of the reduced gradients (same link bytes; the 28 B / parameter optimizer stream shrinks by G on
+        # every rank).  train_negplus.py:77-84,121-123 has one optimizer on one device; replicas stay bit-identical because
+        # everybody takes the owner's bits.  m / v are kept full size but only the owned chunks are live.  The token embedding
+        # (exchanged as touched rows) and buckets the direct exchange cannot split are still updated on every rank.
+        if optim not in ("replicated", "sharded"):
+            raise ValueError(optim)
+        if optim == "sharded" and check_finite:
+            raise ValueError("optim='sharded' has no skipped-step path (check_finite); bf16 training needs no loss scaling")
+        self.optim = optim if (self.world > 1 or _dp._FORCE) else "replicated"
+        if self.optim == "sharded":
+            self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype, algo="direct",
+                                             shard_update=self._update_range, flat_params=self.tower.params)
+        else:
+            self.reducer = GradBucketReducer(self.tower.grads, group, comm_dtype=grad_comm_dtype, algo=grad_comm_algo)
         # token-embedding gradients: exchanged as touched rows when the caller also hands the ids on the host (step(ids_host=))
         self.sparse_embed = SparseRowReducer(group) if (self.world > 1 or _dp._FORCE) else None
         self._bank = None
         self._m_begin, self._M_total = 0, 0
         self._refer = None
+
+    def _update_range(self, lo, hi, grad=None):
+        """AdamW on the flat range [lo, hi) with `grad` (default: the flat gradient's own slice) at the current step count."""
+        t = self.tower
+        g = t.grads[lo:hi] if grad is None else grad
+        ops.adamw_step(t.params[lo:hi], g, self.m[lo:hi], self.v[lo:hi], self.step_count, self.lr, self.betas, self.eps, self.wd,
+                       1.0, None)
 
     def set_banks(self, refer_bank, target_bank, bank_dtype="bf16"):
         """refer_bank fp32 [N, D] raw features; target_bank fp32 [M, D] L2-normalised rows.
@@ -140,6 +163,20 @@ class Stage2Trainer:
             if start == 0 and split:
                 self.reducer.flush()                      # ... and so do the embeddings, now
 
+        if self.optim == "sharded":
+            self.step_count += 1                          # the owners' updates run inside the bucket exchanges below
+            t.backward_phased(dtext, on_span, groups, embed_early=split)
+            inflight = self.reducer.finish_unsharded()    # fallback all-reduces are in; the sharded exchanges keep running
+            if sparse:
+                self.sparse_embed.finish(tok_grad)
+            # what no owner updated (the token embedding's touched-row exchange, fallback buckets): on every rank, under the
+            # last exchanges
+            for lo, hi in self.reducer.complement_spans(t.params.numel()):
+                self._update_range(lo, hi)
+            for w in inflight:
+                w.wait()
+            t.refresh()
+            return ctx["loss"]
         t.backward_phased(dtext, on_span, groups, embed_early=split)
         pending = self.reducer.finish(keep_span=keep)
         if sparse:

@@ -241,3 +241,98 @@ def test_sparse_embedding_row_exchange(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _zero1_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd.distributed import GradBucketReducer
+
+        class TorchKernels:
+            @staticmethod
+            def to_bf16(src, dst):
+                dst.copy_(src.to(torch.bfloat16))
+
+            @staticmethod
+            def sum_ranks(chunks, G, out_):
+                out_.copy_(chunks.view(G, -1).float().sum(0).to(torch.bfloat16))
+
+            @staticmethod
+            def to_f32(src, dst):
+                dst.copy_(src.float())
+
+            @staticmethod
+            def sum_ranks_f32(chunks, G, out_):
+                acc = torch.zeros_like(out_)
+                for r in range(G):
+                    acc += chunks.view(G, -1)[r]
+                out_.copy_(acc)
+        n = 24 * world * 5 + 7                     # the last bucket (7 + a few elements) cannot be split into aligned chunks
+        g = torch.Generator().manual_seed(3)
+        grads_all = torch.randn(world, n, generator=g)
+        p0 = torch.randn(n, generator=g)
+        res = {}
+        for dtype in ("fp32", "bf16"):
+            params, flat = p0.clone(), grads_all[rank].clone()
+            m = torch.zeros(n)
+            touched = []
+
+            def update(lo, hi, grad, params=params, m=m, touched=touched):
+                # a stateful elementwise rule (momentum + decay): only the owner's slice of the state is ever touched
+                m[lo:hi].mul_(0.9).add_(grad, alpha=0.1)
+                params[lo:hi].mul_(1 - 0.01).sub_(m[lo:hi], alpha=0.5)
+                touched.append((lo, hi))
+            red = GradBucketReducer(flat, None, bucket_elems=24 * world, comm_dtype=dtype, kernels=TorchKernels,
+                                    shard_update=update, flat_params=params)
+            cuts = [n, 24 * world * 5, 24 * world * 3, 24 * world, 0]                  # spans arrive from the end, as in backward
+            for k, (hi, lo) in enumerate(zip(cuts[:-1], cuts[1:])):
+                red.on_span_ready(lo, hi)
+                if k == 0:
+                    red.flush()                                                        # the ragged tail is a bucket of its own
+            inflight = red.finish_unsharded()
+            rest = red.complement_spans(n)
+            for lo, hi in rest:                                                        # fallback bucket: all-reduced, updated everywhere
+                update(lo, hi, flat[lo:hi])
+            for w in inflight:
+                w.wait()
+            # single-process reference: rank-order sums (fp32), or bf16(sum of bf16-rounded contributions) for the bf16 exchange
+            gsum = torch.zeros(n)
+            if dtype == "bf16":
+                gsum = grads_all.to(torch.bfloat16).float().sum(0).to(torch.bfloat16).float()
+            else:
+                for r in range(world):
+                    gsum += grads_all[r]
+            want = p0 * (1 - 0.01) - 0.5 * (0.1 * gsum)
+            owned = sum(hi - lo for lo, hi in touched)
+            sharded_elems = 24 * world * 5
+            ok_bits = torch.equal(params[:sharded_elems], want[:sharded_elems])
+            ok_tail = rest == [(sharded_elems, n)] and torch.allclose(params[sharded_elems:], (p0 * 0.99 - 0.05 * grads_all.sum(0))[sharded_elems:],
+                                                                      atol=1e-6)
+            res[dtype] = (ok_bits, ok_tail, owned == sharded_elems // world + (n - sharded_elems), params.clone())
+        out.put((rank, res["fp32"][:3], res["bf16"][:3], res["fp32"][3], res["bf16"][3]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_update(world):
+    """ZeRO-1 shape of the bucket exchange (GradBucketReducer(shard_update=...), Stage2Trainer(optim="sharded")): all-to-all ->
+    rank-order sum -> the OWNER updates its 1 / G chunk -> all-gather of the updated masters.  Every rank ends with the same bits,
+    equal to a single process applying the rule to the rank-order gradient sum; only 1 / G of the parameters (plus the fallback
+    bucket) are updated per rank.  clip4cir/train_negplus.py:77-84,121-123 is the single-device loop this distributes."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero1_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, f32, b16, _, _ in res:
+        assert all(f32), ("fp32", rank, f32)
+        assert all(b16), ("bf16", rank, b16)
+    for r in res[1:]:                                   # replicas bit-identical, both exchange flavours
+        assert torch.equal(r[3], res[0][3]) and torch.equal(r[4], res[0][4])

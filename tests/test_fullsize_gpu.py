@@ -99,6 +99,41 @@ def test_vitl14_every_gradient_matches_oracle(groups):
     assert len(worst) == len(sd) == 2 + 12 * layers + 3
 
 
+def test_config2_full_batch_features_and_loss_match_oracle():
+    """BASELINE config 2 at its FULL batch against the fp32 CPU oracle (round-5 VERDICT item 7: this comparison lived only in
+    bench.py's recall leg): the bf16 training tower's features of all 256 config-2 captions (ViT-L/14 text tower, 77 tokens) and
+    the loss of the fused bank step over the 40 000 x 768 bank, against oracle.clip_text.encode_text + oracle.bank_loss on the
+    same ids, banks and labels.  Gates: 1 - cos <= 1e-3 on every caption (north_star), |loss - oracle| <= 1e-2.  The oracle
+    forward takes ~15-60 s of CPU (no backward here - test_vitl14_every_gradient_matches_oracle gates the gradients at B = 8)."""
+    _need_gpu()
+    from oracle import bank_loss, clip_text
+    from spn4cir_amd import ops, synthetic
+    from spn4cir_amd.text_tower import TextTower
+    W, layers, heads, D = synthetic.CLIP_TEXT_CONFIGS["ViT-L/14"]
+    B, M, tau = 256, 40000, 0.02
+    sd = synthetic.text_state_dict(W, layers, D, seed=0)
+    ids = synthetic.token_ids(B, seed=1)
+    target, refer = synthetic.banks(M, D, seed=2)
+    ridx, labels = synthetic.triplet_indices(B, M, seed=4)
+    t = TextTower(W, layers, heads, D, device="cuda")
+    t.load_clip_state_dict(sd)
+    feats = t.forward(ids.cuda()).clone()
+    q, qb, inv = ops.combine_l2norm_fwd(refer.cuda(), ridx.cuda(), feats)
+    stats = ops.bank_stats_fwd(qb, ops.prepare_bank(target.cuda()), labels.cuda(), 1.0 / tau)
+    _, _, mean = ops.bank_loss_finalize(stats, M)
+    with torch.no_grad():
+        ref = torch.cat([clip_text.encode_text(sd, ids[s:s + 64].long()) for s in range(0, B, 64)])
+        ref_loss = bank_loss.bank_large_step(refer, ridx, ref, target, labels, tau)
+    cos = torch.nn.functional.cosine_similarity(feats.cpu().double(), ref.double(), dim=-1)
+    print(f"config 2, B = 256: max 1 - cos {float((1 - cos).max()):.2e}, loss {mean.item():.5f} vs oracle {ref_loss.item():.5f}")
+    assert float((1 - cos).max()) <= 1e-3
+    assert abs(mean.item() - ref_loss.item()) <= 1e-2
+    # packed rows (the product default for host ids) give the same features bit for bit: the gate covers both routes
+    cu_host, total = t.cu_seqlens(ids)
+    feats_p = t.forward(ids.cuda(), cu_host.cuda(), total)
+    assert torch.equal(feats_p, feats)
+
+
 def test_packed_matches_dense_at_full_size():
     """BASELINE config 2 (B = 256, ViT-L/14, 77-token rows of which ~27 % are live): the packed mode computes the same
     features (bit for bit per row: same kernels, same k order) and the same gradients up to the bf16 rounding of

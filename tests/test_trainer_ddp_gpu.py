@@ -42,8 +42,9 @@ def _worker(rank, world, port, mode, out):
         dev = torch.device("cuda", 0)
         model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
         comm = os.environ.get("SPN_TEST_DDP_COMM", "fp32")
-        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, grad_comm_dtype="bf16" if comm == "bf16" else "fp32",
-                           grad_comm_algo="direct" if comm == "direct" else None)
+        tr = Stage2Trainer(model, lr=LR, group=None, bank_mode=mode, grad_comm_dtype="bf16" if comm.endswith("bf16") else "fp32",
+                           grad_comm_algo="direct" if comm == "direct" else None,
+                           optim="sharded" if comm.startswith("zero1") else "replicated")
         tr.set_banks(refer, target)
         bl = B // world
         sl = slice(rank * bl, (rank + 1) * bl)
@@ -63,7 +64,11 @@ def _worker(rank, world, port, mode, out):
                                                      # gradient buckets as bf16: all-to-all + fp32 sum in rank order + all-gather
                                                      ("replicated", 2, 0, "bf16"), ("replicated", 6, 1, "bf16"),
                                                      # fp32 buckets through the same direct exchange instead of the ring all-reduce
-                                                     ("sharded", 6, 0, "direct")])
+                                                     ("sharded", 6, 0, "direct"),
+                                                     # sharded optimizer step (ZeRO-1 shape): the owner of a reduced chunk updates it,
+                                                     # the updated masters are all-gathered (Stage2Trainer(optim="sharded"))
+                                                     ("replicated", 6, 0, "zero1"), ("sharded", 2, 1, "zero1"),
+                                                     ("replicated", 6, 1, "zero1_bf16")])
 def test_two_ranks_match_single_process(mode, layers, sparse, comm, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -101,6 +106,75 @@ def test_two_ranks_match_single_process(mode, layers, sparse, comm, monkeypatch)
         assert diff.max() < (2e-3 if layers == 2 else 4.2e-3), (mode, rank, diff.max().item())
         assert (diff > 2e-3).float().mean() < 1e-4
     assert (res[0][2] - res[1][2]).abs().max() == 0.0       # replicas stay bit-identical
+
+
+def _zero1_bits_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spn4cir_amd import ops
+        from spn4cir_amd.distributed import GradBucketReducer
+        dev = torch.device("cuda", 0)
+        n = 3 * 1024 * 1024 + 8 * world                    # three buckets of 1 Mi elements + a short tail bucket
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = torch.randn(n, generator=g).to(dev)
+        p0 = torch.randn(n, generator=torch.Generator().manual_seed(7)).to(dev)
+        res = {}
+        for dtype in ("fp32", "bf16"):
+            # (a) replicated: direct exchange of the gradients, AdamW over everything on every rank
+            flat, pa = grads.clone(), p0.clone()
+            ma, va = torch.zeros_like(pa), torch.zeros_like(pa)
+            red = GradBucketReducer(flat, None, bucket_elems=1 << 20, comm_dtype=dtype, algo="direct")
+            for lo in range(n - 8 * world, -1, -(1 << 20)):
+                red.on_span_ready(lo, min(n, lo + (1 << 20)) if lo < n - 8 * world else n)
+            red.finish()
+            ops.adamw_step(pa, flat, ma, va, 1, 1e-3)
+            # (b) sharded: the owner updates its chunk of every bucket, the masters are all-gathered
+            flat2, pb = grads.clone(), p0.clone()
+            mb, vb = torch.zeros_like(pb), torch.zeros_like(pb)
+            owned = []
+
+            def update(lo, hi, grad, pb=pb, mb=mb, vb=vb, owned=owned):
+                ops.adamw_step(pb[lo:hi], grad, mb[lo:hi], vb[lo:hi], 1, 1e-3)
+                owned.append(hi - lo)
+            red2 = GradBucketReducer(flat2, None, bucket_elems=1 << 20, comm_dtype=dtype, shard_update=update, flat_params=pb)
+            for lo in range(n - 8 * world, -1, -(1 << 20)):
+                red2.on_span_ready(lo, min(n, lo + (1 << 20)) if lo < n - 8 * world else n)
+            inflight = red2.finish_unsharded()
+            for lo, hi in red2.complement_spans(n):
+                ops.adamw_step(pb[lo:hi], flat2[lo:hi], mb[lo:hi], vb[lo:hi], 1, 1e-3)
+            for w in inflight:
+                w.wait()
+            torch.cuda.synchronize()
+            res[dtype] = (int((pa != pb).sum().item()), sum(owned), pb.cpu().numpy())
+        out.put((rank, res["fp32"][:2], res["bf16"][:2], res["fp32"][2], res["bf16"][2]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_update_bits_on_the_hip_kernels():
+    """optim="sharded" on the library's kernels (two ranks sharing the GPU over gloo): all-to-all -> spn_sum_ranks_* -> spn_adamw_step
+    on the OWNED chunk -> all-gather of the masters gives, bit for bit, the parameters of the replicated update (direct exchange of
+    the gradients + AdamW over everything), on both ranks, for fp32 and bf16 payloads - and each rank updated 1 / G of the buckets
+    (train_negplus.py:77-84,121-123 is the single-device loop this distributes)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_zero1_bits_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 3 * 1024 * 1024 + 8 * world
+    for rank, f32, b16, _, _ in res:
+        assert f32 == (0, n // world), ("fp32", rank, f32)
+        assert b16 == (0, n // world), ("bf16", rank, b16)
+    assert (res[0][3] != res[1][3]).sum() == 0 and (res[0][4] != res[1][4]).sum() == 0       # replicas bit-identical
 
 
 _NCCL_WORLD1 = r"""
@@ -142,6 +216,15 @@ def run_direct():
     ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
     return ls, model.tower.params.clone()
 l, p = run_direct()                                   # one rank: the "sum" is the gradient itself - same step as the ring path
+assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5 and (p - ref_p).abs().max().item() < 1e-6
+def run_zero1():
+    model = CIRPlus(sd, tau=TAU, device=dev, plus=True)
+    tr = Stage2Trainer(model, lr=LR, group=None, bank_mode="replicated", pack=False, optim="sharded")
+    assert tr.optim == "sharded"
+    tr.set_banks(refer, target)
+    ls = [tr.step(ids.to(dev), ridx.to(dev), labels.to(dev)).item() for _ in range(2)]
+    return ls, model.tower.params.clone()
+l, p = run_zero1()                                    # the sharded optimizer step's collectives on RCCL: one rank owns everything
 assert max(abs(a - b) for a, b in zip(l, ref_l)) < 1e-5 and (p - ref_p).abs().max().item() < 1e-6
 l, p = run_bf16()
 assert max(abs(a - b) for a, b in zip(l, ref_l)) < 2e-3, (l, ref_l)
