@@ -27,18 +27,23 @@ from .vision_tower import VisionTower
 
 
 class _FusionBankStep(torch.autograd.Function):
+    """blip4cir/models.py:95-121 as one autograd node.  The learnable temperature (models.py:29) is READ ON THE DEVICE, as in
+    fusion.BlipStage2Trainer: logits = (q / tau) . bank with the bank kernels at inv_tau = 1 and every factor of tau applied by
+    device-side scalars.  (Round 5 read `float(tau)` here: a host synchronisation in front of every forward, behind the
+    optimizer's update of tau - the device drained and then idled while the host tokenised and enqueued the step.)"""
+
     @staticmethod
     def forward(ctx, anchor, tau_param, model, ids, mask, token_bank, token_idx, labels):
         enc = model.fusion
-        tau = float(tau_param.detach())
+        tau_dev = tau_param.detach().reshape(1)
         proj = enc.forward(ids, mask, token_bank=token_bank, token_idx=token_idx)
-        q, qb, inv = ops.combine_l2norm_fwd(None, None, proj)
+        q, _, inv = ops.combine_l2norm_fwd(None, None, proj)
         bank = model._target_bank_dev
-        saved = ops.bank_logits_buffer(qb.shape[0], bank.shape[0], qb.device)
-        stats = ops.bank_stats_fwd(qb, bank, labels, 1.0 / tau, save=saved)
+        qs = ops.scale_cast_bf16(q, tau_dev, reciprocal=True, ldo=bank.shape[1])        # bf16(q / tau)
+        saved = ops.bank_logits_buffer(qs.shape[0], bank.shape[0], qs.device)
+        stats = ops.bank_stats_fwd(qs, bank, labels, 1.0, save=saved)
         lse, row, mean = ops.bank_loss_finalize(stats, bank.shape[0])
-        ctx.model, ctx.st = model, dict(q=q, qb=qb, inv=inv, lse=lse, labels=labels, tau=tau, B=ids.shape[0], saved=saved,
-                                        tau_dev=tau_param.detach().reshape(1))
+        ctx.model, ctx.st = model, dict(q=q, qs=qs, inv=inv, lse=lse, labels=labels, B=ids.shape[0], saved=saved, tau_dev=tau_dev)
         return mean.reshape(())
 
     @staticmethod
@@ -48,15 +53,15 @@ class _FusionBankStep(torch.autograd.Function):
         bank = m._target_bank_dev
         # the incoming d(loss) scales the (linear) backward on the device: no host synchronisation on it
         scale = grad_out.detach().to(torch.float32).reshape(1)
-        dq = ops.bank_grad_q(st["qb"], bank, st["labels"], 1.0 / st["tau"], st["lse"], 1.0 / st["B"],
-                             M_total=bank.shape[0], saved=st["saved"])
-        # models.py:29: tau is an nn.Parameter.  dq = d loss / d q here, so d loss / d tau = -(1 / tau) sum q . dq = tau x the
-        # kernel's -(sum) / tau^2, times autograd's incoming scalar - one launch, nothing computed by torch
-        dtau = torch.empty(1, dtype=torch.float32, device=dq.device)
-        ops.tau_grad(st["q"], dq, st["tau_dev"], dtau, alpha=st["tau"], scale_dev=scale)
+        dqk = ops.bank_grad_q(st["qs"], bank, st["labels"], 1.0, st["lse"], 1.0 / st["B"], M_total=bank.shape[0],
+                              saved=st["saved"])                                          # d loss / d (q / tau)
+        # models.py:29: tau is an nn.Parameter.  d loss / d tau = -(sum q . dqk) / tau^2 times autograd's incoming scalar, and
+        # 1 / tau for the chain into q - one launch, tau read on the device
+        dtau = torch.empty(1, dtype=torch.float32, device=dqk.device)
+        inv_tau = ops.tau_grad(st["q"], dqk, st["tau_dev"], dtau, scale_dev=scale)
         snap = gradsink.snapshot(m._params, enc.grads, enc.named_views)
-        dqc = dq if dq.shape[1] == enc.Dp else dq[:, :enc.Dp].contiguous()
-        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dqc, scale=scale))
+        dqc = dqk if dqk.shape[1] == enc.Dp else dqk[:, :enc.Dp].contiguous()
+        flat = enc.backward(ops.combine_l2norm_bwd(st["q"], st["inv"], dqc, scale=inv_tau * scale))
         gradsink.publish(m._params, flat, enc.named_views, snap)
         return None, dtau.reshape(()), None, None, None, None, None, None
 

@@ -256,7 +256,7 @@ class BlipStage2Trainer:
     AdamW(lr, betas (0.9, 0.999), eps 1e-7) and default weight decay."""
 
     def __init__(self, encoder, tau=0.03, lr=5e-6, betas=(0.9, 0.999), eps=1e-7, weight_decay=0.01, group=None,
-                 bank_mode="auto", label_smoothing=0.0, learn_tau=True, bucket_elems=8 << 20):
+                 bank_mode="auto", label_smoothing=0.0, learn_tau=True, bucket_elems=8 << 20, optim="replicated"):
         from . import distributed as dp
         self.enc, self.group = encoder, group
         self._bank_mode_arg = bank_mode      # "auto": replicated below 10^6 bank rows (set_bank), as bench.py --bank-mode auto
@@ -264,10 +264,19 @@ class BlipStage2Trainer:
         self.world, self.rank = dp._world(group)
         first = "replicated" if bank_mode == "auto" else bank_mode
         self.loss_dp = dp.BankLossDP(ops, group, first if (self.world > 1 or dp._FORCE) else "replicated")
-        self.reducer = dp.GradBucketReducer(encoder.grads, group, bucket_elems)
         self._shard_range = dp.shard_range
         self.m = torch.zeros_like(encoder.params)
         self.v = torch.zeros_like(encoder.params)
+        # optim="sharded": the sharded optimizer step of trainer.Stage2Trainer (ZeRO-1 shape) - a bucket's reduced gradient chunk is
+        # updated by its owner, the masters are all-gathered; the temperature (one scalar) stays replicated
+        if optim not in ("replicated", "sharded"):
+            raise ValueError(optim)
+        self.optim = optim if (self.world > 1 or dp._FORCE) else "replicated"
+        if self.optim == "sharded":
+            self.reducer = dp.GradBucketReducer(encoder.grads, group, bucket_elems, shard_update=self._update_range,
+                                                flat_params=encoder.params)
+        else:
+            self.reducer = dp.GradBucketReducer(encoder.grads, group, bucket_elems)
         dev = encoder.device
         self.tau = torch.tensor([float(tau)], dtype=torch.float32, device=dev)      # learnable temperature
         self.learn_tau = learn_tau
@@ -276,6 +285,11 @@ class BlipStage2Trainer:
         self._tau_g = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step_count = 0
         self._bank, self._m_begin, self._M_total = None, 0, 0
+
+    def _update_range(self, lo, hi, grad=None):
+        e = self.enc
+        ops.adamw_step(e.params[lo:hi], e.grads[lo:hi] if grad is None else grad, self.m[lo:hi], self.v[lo:hi], self.step_count,
+                       self.lr, self.betas, self.eps, self.wd)
 
     def set_bank(self, target_bank, bank_dtype="bf16"):
         """target_bank fp32 [M, Dp], L2-normalised rows; sharded mode keeps only this rank's rows on the device."""
@@ -320,10 +334,18 @@ class BlipStage2Trainer:
         inv_tau = ops.tau_grad(q, dqk, self.tau, self._tau_g if self.learn_tau else None)     # d loss / d tau and 1 / tau, one launch
         dproj = ops.combine_l2norm_bwd(q, inv, dqk if dqk.shape[1] == enc.Dp else dqk[:, :enc.Dp].contiguous(), scale=inv_tau)
         groups = wgrad_groups(enc.layers, self.world)
-        enc.backward_phased(dproj, self.reducer.on_span_ready, groups if self.world > 1 else None)
-        self.reducer.finish()
         self.step_count += 1
-        ops.adamw_step(enc.params, enc.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)
+        if self.optim == "sharded":
+            enc.backward_phased(dproj, self.reducer.on_span_ready, groups if self.world > 1 else None)
+            inflight = self.reducer.finish_unsharded()
+            for lo, hi in self.reducer.complement_spans(enc.params.numel()):      # buckets the direct exchange could not split
+                self._update_range(lo, hi)
+            for w in inflight:
+                w.wait()
+        else:
+            enc.backward_phased(dproj, self.reducer.on_span_ready, groups if self.world > 1 else None)
+            self.reducer.finish()
+            ops.adamw_step(enc.params, enc.grads, self.m, self.v, self.step_count, self.lr, self.betas, self.eps, self.wd)
         enc.mark_stale()
         if self.learn_tau:
             if self.world > 1:

@@ -20,9 +20,24 @@ def _aliases(grad, flat):
             and grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr())
 
 
+def _views(named_views, flat):
+    """named_views(flat), memoised on the tower for its OWN persistent gradient buffer: building the ~150-330 views of a tower is
+    ~1-1.5 ms of host time per call, paid twice per step (snapshot + publish) in front of / behind the backward launches of a
+    loop that synchronises on the loss every step (the reference's does, train_negplus.py:114).  Other buffers (a snapshot's
+    clone) are not cached: the cache would keep their memory alive."""
+    owner = getattr(named_views, "__self__", None)
+    if owner is None or getattr(owner, "grads", None) is not flat:
+        return named_views(flat)
+    key = (flat.data_ptr(), flat.numel())
+    cached = owner.__dict__.get("_gradsink_views")
+    if cached is None or cached[0] != key:
+        cached = owner.__dict__["_gradsink_views"] = (key, named_views(flat))
+    return cached[1]
+
+
 def snapshot(params, flat, named_views, prefix=""):
     """Copy of `flat` if any parameter's .grad currently lives in it (its old gradient is about to be overwritten)."""
-    for key in named_views(flat):
+    for key in _views(named_views, flat):
         if _aliases(params[prefix + key].grad, flat):
             return flat.clone()
     return None
@@ -30,7 +45,7 @@ def snapshot(params, flat, named_views, prefix=""):
 
 def publish(params, flat, named_views, snap, prefix=""):
     """After the tower's backward filled `flat`: p.grad = new (alias, when there was none) or old + new."""
-    views = named_views(flat)
+    views = _views(named_views, flat)
     aliased = [k for k in views if _aliases(params[prefix + k].grad, flat)]
     if aliased:
         if snap is None:

@@ -122,7 +122,9 @@ def _blip_worker(rank, world, port, mode, golden_dir, out):
     try:
         from spn4cir_amd.fusion import BlipStage2Trainer
         z, enc = _blip_setup(golden_dir)
-        tr = BlipStage2Trainer(enc, tau=float(z["tau"]), lr=1e-3, bank_mode=mode)
+        zero1 = mode.endswith("+zero1")                  # sharded optimizer step (the owner of a reduced chunk updates it)
+        tr = BlipStage2Trainer(enc, tau=float(z["tau"]), lr=1e-3, bank_mode=mode.split("+")[0], optim="sharded" if zero1 else "replicated")
+        assert tr.optim == ("sharded" if zero1 else "replicated")
         tr.set_bank(torch.from_numpy(z["bank"]))
         B = z["ids"].shape[0]
         bl = B // world
@@ -136,7 +138,7 @@ def _blip_worker(rank, world, port, mode, golden_dir, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sharded", "replicated"])
+@pytest.mark.parametrize("mode", ["sharded", "replicated", "replicated+zero1"])
 def test_blip_trainer_two_ranks_match_single_process(golden_dir, mode):
     """BASELINE config 4's data-parallel step (two ranks sharing the test GPU over gloo): loss trajectory, updated
     encoder parameters and the learnable temperature equal the single-process step on the whole batch."""
