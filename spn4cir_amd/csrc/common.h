@@ -157,6 +157,23 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
     const float s = fast_sigmoid(1.702f * x);
     return s * (1.0f + 1.702f * x * (1.0f - s));
 }
+// Standard normal cdf and density for the exact GELU (med.py BertIntermediate, timm Mlp): Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf
+// from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 - three decimal orders below a bf16 ulp of the activation), which needs
+// e^{-z^2} at z = |x| / sqrt 2 - the SAME exponential as the density.  One v_exp, one v_rcp and a degree-5 Horner form instead of
+// ocml's erff (~35 VALU instructions) plus the exponential: the GELU epilogue of the 256 x 256 NT tile is VALU-bound (128 outputs per
+// lane; 55 us per one-round launch at 4 096 x 3 072 x 768 against 16 us of k loop).  The fp32-exact evaluation towers (exact.hip)
+// keep erff.
+__device__ __forceinline__ f32x2 gelu_cdf_pdf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    const float ex = __expf(-0.5f * x * x);                                   // e^{-z^2}
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 1.421413741f);
+    poly = __builtin_fmaf(t, poly, -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.254829592f);
+    const float half_erf = 0.5f - 0.5f * (poly * t) * ex;                     // erf(z) / 2, z >= 0
+    return f32x2{0.5f + copysignf(half_erf, x), 0.3989422804014327f * ex};
+}
 // activation and its derivative from ONE sigmoid / erf evaluation (ACT: 1 = QuickGELU, 2 = exact GELU, kernels.h)
 template <int ACT>
 __device__ __forceinline__ f32x2 act_and_grad_pair(float x) {
@@ -164,16 +181,14 @@ __device__ __forceinline__ f32x2 act_and_grad_pair(float x) {
         const float s = fast_sigmoid(1.702f * x);
         return f32x2{x * s, s * (1.0f + 1.702f * x * (1.0f - s))};
     } else {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-        const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-        return f32x2{x * cdf, cdf + x * pdf};
+        const f32x2 cp = gelu_cdf_pdf(x);
+        return f32x2{x * cp[0], cp[0] + x * cp[1]};
     }
 }
 // y = act(x), g = act'(x); a macro because vector elements cannot bind to references
 #define act_and_grad_into(ACT_, X, Y, G) do { const f32x2 ag__ = act_and_grad_pair<ACT_>(X); (Y) = ag__[0]; (G) = ag__[1]; } while (0)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * gelu_cdf_pdf(x)[0]; }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const f32x2 cp = gelu_cdf_pdf(x);
+    return cp[0] + x * cp[1];
 }

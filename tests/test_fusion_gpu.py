@@ -180,7 +180,13 @@ def test_blip_trainer_two_ranks_match_single_process(golden_dir, mode):
                 assert diff[off:off + n].max().item() < 4e-3, (k, diff[off:off + n].max().item())
                 diff[off:off + n] = 0
         d = diff.max().item()
-        assert d < 5e-4, d          # two AdamW steps at lr 1e-3: split-K / reduction-order noise only
+        worst = int(diff.argmax())
+        where = [(k, worst - off) for k, off, shape in enc.spans() if off <= worst < off + int(np.prod(shape))]
+        # two AdamW steps at lr 1e-3: split-K / reduction-order noise only.  AdamW moves an element by ~lr per step whatever the
+        # gradient's size, so an element whose gradient is rounding noise may differ by up to 2 lr per step; a handful of
+        # elements (cross-attention key weights of this tiny fixture) sit between 0.25 lr and 0.5 lr per step
+        assert d < 1e-3, (d, where)
+        assert (diff > 5e-4).float().mean().item() < 1e-5, (d, where)
 
 
 def test_blip_cirplus_protocol(golden_dir):
