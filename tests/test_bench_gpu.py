@@ -37,6 +37,9 @@ def test_bench_two_ranks_shared_gpu(mode):
     assert abs(st["value"] - 256 / (st["ms_per_step"] * 1e-3)) < 1e-2 * st["value"]
     assert d["grad_comm_bf16"]["grad_comm_dtype"] == "bf16" and d["grad_comm_bf16"]["value"] > 0
     assert d["grad_comm_direct_fp32"]["grad_comm_algo"] == "direct" and d["grad_comm_direct_fp32"]["value"] > 0
+    # sharded optimizer step (ZeRO-1 shape), weak and strong shapes, beside the replicated update
+    assert d["optim_sharded"]["optim"] == "sharded" and d["optim_sharded"]["value"] > 0, d["optim_sharded"]
+    assert d["optim_sharded_strong"]["optim"] == "sharded" and d["optim_sharded_strong"]["batch_per_gpu"] == 128
     # achieved all-reduce bandwidth and overlap of the gradient exchange with backward (meaningless on a shared GPU: shape only)
     c = d["collectives"]
     assert "error" not in c, c
