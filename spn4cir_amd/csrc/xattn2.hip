@@ -26,6 +26,9 @@ namespace spn {
 static constexpr int X2_THREADS = 512, X2_WAVES = 8, X2_BK = 32;
 
 // tools/x2probe: phase stamps (shader clock) of every workgroup, kept in LDS and dumped at the end - probe builds only
+#ifndef X2_ELIM
+#define X2_ELIM 0        // probe builds only (tools/x2probe): 1 = no MFMA in the k loop, 2 = fragments read once, 4 = no DMA in the k loop (wrong results)
+#endif
 #ifdef X2_PROBE
 __device__ uint64_t* x2_probe_buf;
 #define X2_PROBE_SLOTS 192
@@ -156,13 +159,14 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_rows_kernel(const bf16_t
         constexpr int HF = decltype(hf_)::value;
         X2_STAMP(8 + 3 * s);
         // ---- phase 1
-        read_frags(K1{}, bcur);
+        if (!(X2_ELIM & 2) || s == 0) read_frags(K1{}, bcur);
         __builtin_amdgcn_sched_barrier(0);
-        const bool st1 = s + 2 < NS;
+        const bool st1 = s + 2 < NS && !(X2_ELIM & 4);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[HF][i][j] = mfma16(fb[0][j], fa[0][i], acc[HF][i][j]);
+            for (int j = 0; j < NJ; ++j)
+                if (!(X2_ELIM & 1)) acc[HF][i][j] = mfma16(fb[0][j], fa[0][i], acc[HF][i][j]);
             if (REQ_P2 + i < REQ_HI) {                                   // second half of stage s + 2 -> the buffer stage s - 1 left
                 __builtin_amdgcn_sched_barrier(0);
                 if (st1) stage_one(REQ_P2 + i, s + 2, bprev);
@@ -182,14 +186,14 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_rows_kernel(const bf16_t
         __builtin_amdgcn_s_barrier();                                    // stage s + 1 visible to all; nobody reads buffer bcur any more
         X2_STAMP(10 + 3 * s);
         // ---- phase 2
-        read_frags(K0{}, bnext);                                         // (the last step reads a stale buffer and drops it)
+        if (!(X2_ELIM & 2)) read_frags(K0{}, bnext);                     // (the last step reads a stale buffer and drops it)
         __builtin_amdgcn_sched_barrier(0);
-        const bool st2 = s + 3 < NS;
+        const bool st2 = s + 3 < NS && !(X2_ELIM & 4);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                acc[HF][i][j] = mfma16(fb[1][j], fa[1][i], acc[HF][i][j]);
+                if (!(X2_ELIM & 1)) acc[HF][i][j] = mfma16(fb[1][j], fa[1][i], acc[HF][i][j]);
                 if ((i * NJ + j) % 2 == 1 && (i * NJ + j) / 2 < REQ_P2) {    // first half of stage s + 3 -> the buffer of stage s
                     __builtin_amdgcn_sched_barrier(0);
                     if (st2) stage_one((i * NJ + j) / 2, s + 3, bcur);
