@@ -105,7 +105,9 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_rows_kernel(const bf16_t
     auto stage_one = [&](int i, int s, int buf) {
         const int g = wid + X2_WAVES * i;
         if (i < REQ_LO || more) {
-            const int hf = s >= nkh ? 1 : 0, kt = s - hf * nkh;
+            // the second half walks k BACKWARDS: its first A slabs are the ones the first half read last, so the re-read of the
+            // workgroup's 147 KB of A rows finds more of them still in the XCD's L2 (the X stream pushes them out in order)
+            const int hf = s >= nkh ? 1 : 0, kt = hf ? 2 * nkh - 1 - s : s;
             // the k offset stays inside a row -> scalar offset; the half's row offset decides which X rows exist (rows >= S read as
             // zero) -> vector offset, where the descriptor's range check certainly sees it
             const uint32_t vo = voff[i] + (g < GA ? 0u : (uint32_t)hf * (uint32_t)HC * (uint32_t)E * 2u);

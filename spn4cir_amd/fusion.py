@@ -53,6 +53,24 @@ class FusionEncoder:
             return None
         return lens
 
+    def _stage_cu(self, cu):
+        """cu int32 [B + 1] on the host -> the same values in a pinned staging buffer that is safe to upload asynchronously."""
+        if not torch.cuda.is_available():
+            return cu
+        ring = self.__dict__.setdefault("_cu_ring", [])
+        n = cu.numel()
+        if not ring or ring[0][0].numel() != n:
+            ring.clear()
+            ring.extend([torch.empty(n, dtype=torch.int32).pin_memory(), None] for _ in range(8))
+            self._cu_next = 0
+        slot = ring[self._cu_next]
+        self._cu_next = (self._cu_next + 1) % len(ring)
+        if slot[1] is not None:
+            slot[1].synchronize()                      # the upload that last used this buffer has run (eight steps ago)
+        slot[0].copy_(cu)
+        self._cu_pending = slot
+        return slot[0]
+
     def spans(self):
         """[(BertModel key (+ text_proj.*), offset, shape)]; q/k/v rows of the packed weights are separate views."""
         lay, W, I, E = self._lay, self.W, self.I, self.E
@@ -142,10 +160,12 @@ class FusionEncoder:
             cu = torch.zeros(B + 1, dtype=torch.int32)
             cu[1:] = lens.cumsum(0)
             cfg = self._cfg(B, L, S, int(cu[-1]))
-            # the mask slot carries cu_seqlens (spn4cir_hip.h).  A fresh pinned tensor per step on purpose: torch's caching host
-            # allocator holds the block until the asynchronous upload below has run, so a host that enqueues several steps ahead
-            # never overwrites prefix sums a queued copy has yet to read (a reused buffer would need an event per step)
-            mask = cu.pin_memory() if torch.cuda.is_available() else cu
+            # the mask slot carries cu_seqlens (spn4cir_hip.h).  They go up through a small ring of pinned staging buffers, each
+            # guarded by an event recorded behind its upload: a host that enqueues several steps ahead never overwrites prefix sums
+            # a queued copy has yet to read, and no step pays for a pinned allocation (round 5 took a fresh `pin_memory()` tensor
+            # per step: usually recycled by torch's caching host allocator, but a slow path of several milliseconds when it was not
+            # - config 4's packed step measured 8.4 ms or 13 ms from run to run)
+            mask = self._stage_cu(cu)
         else:
             cfg = cfg0
         if self.is_stale():
@@ -163,6 +183,10 @@ class FusionEncoder:
             raise RuntimeError("fusion arena smaller than this batch needs")          # cannot happen; never write past the arena
         ids = ids.to(self.device, torch.int32).contiguous()
         mask = None if mask is None else mask.to(self.device, torch.int32, non_blocking=True).contiguous()
+        pend = self.__dict__.pop("_cu_pending", None)
+        if pend is not None:                               # the asynchronous upload of the staged prefix sums is enqueued: fence it
+            pend[1] = torch.cuda.Event()
+            pend[1].record()
         out = torch.empty(B, self.Dp, dtype=torch.float32, device=self.device)
         if token_bank is not None:
             check(lib().spn_fusion_fwd_bank(C.byref(cfg), _p(self.params), _p(self.wbf16), _p(ids), _p(mask), _p(token_bank),
