@@ -87,3 +87,22 @@ def test_fusion_prefix_lengths_host_logic():
     out = tok(["a red dress", "a red dress with long sleeves is shorter", "dress"], padding="longest", return_tensors="pt")
     lens = f(out["attention_mask"])
     assert lens is not None and lens.tolist() == out["attention_mask"].sum(1).tolist() and int(lens.max()) == out["input_ids"].shape[1]
+
+
+def test_fusion_arena_sized_for_the_dense_rows_fits_every_packed_batch():
+    """include/spn4cir_hip.h, spn_fusion_cfg.T: 'a buffer sized with T = 0 fits every batch of the shape'.  Round 5 shipped that
+    rule with sizes that broke it for T == B * L (all captions of equal length, or B = 1: the packed form's index arrays come on
+    top of the same rows) - device memory corruption in the BLIP step.  The size functions are host code: checked here, on the CPU,
+    over the shapes the product uses (and the packed scratch of the embedding backward in the workspace)."""
+    from spn4cir_amd import _lib
+    lib = _lib.lib()
+    for B, L, S, E in [(1, 8, 70, 128), (4, 9, 70, 128), (32, 20, 577, 768), (128, 32, 577, 768), (128, 32, 577, 1024), (3, 128, 640, 256)]:
+        dense = _lib.FusionCfg(B, L, S, 768, 12, 12, 3072, E, 256, 30524, 512, 0)
+        a0, w0 = lib.spn_fusion_act_bytes(C.byref(dense)), lib.spn_fusion_ws_bytes(C.byref(dense))
+        assert a0 > 0 and w0 > 0
+        for T in sorted({B, B * L // 2 + 1, B * L - 1, B * L}):
+            if T < B or T > B * L:
+                continue
+            packed = _lib.FusionCfg(B, L, S, 768, 12, 12, 3072, E, 256, 30524, 512, T)
+            assert lib.spn_fusion_act_bytes(C.byref(packed)) <= a0, (B, L, S, E, T)
+            assert lib.spn_fusion_ws_bytes(C.byref(packed)) <= w0, (B, L, S, E, T)
