@@ -308,9 +308,15 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_rows_kernel(const bf16_t
     constexpr int UPR = SPW / 8;
     const int rows_valid = min(BMR, R - m0);
     bf16_t* dst = out + (r0 + m0) * SPW;
+#ifndef X2_STORE_WT
+#define X2_STORE_WT 1        // write-through (sc1) output stores: the 63-75 MB output stream does not push the X / A lines the other
+#endif                       // workgroups of the sample are about to re-read out of the XCD's L2
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(dst, (uint32_t)rows_valid * (uint32_t)SPW * 2u);
     for (int u = tid; u < rows_valid * UPR; u += X2_THREADS) {
         const int r = u / UPR, c = u % UPR;
-        *(u32x4*)(dst + (size_t)r * SPW + c * 8) = *(const u32x4*)(img + r * PITCH + c * 16);
+        const u32x4 v = *(const u32x4*)(img + r * PITCH + c * 16);
+        if (X2_STORE_WT) store_wt16(rsO, ((size_t)r * SPW + c * 8) * 2, v);
+        else *(u32x4*)(dst + (size_t)r * SPW + c * 8) = v;
     }
     X2_STAMP(4);
     X2_DUMP();
@@ -505,9 +511,12 @@ __global__ __launch_bounds__(X2_THREADS, 1) void xattn2_apply_kernel(const bf16_
         const int mh = m0 + half * 96;
         const int rows_valid = min(96, R - mh);
         bf16_t* dst = out + (r0 + mh) * E + n0;
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(dst, rows_valid > 0 ? ((uint32_t)(rows_valid - 1) * (uint32_t)E + (uint32_t)BNA) * 2u : 0u);
         for (int u = tid; u < rows_valid * UPR; u += X2_THREADS) {
             const int r = u / UPR, c = u % UPR;
-            *(u32x4*)(dst + (size_t)r * E + c * 8) = *(const u32x4*)(img + r * PITCH + c * 16);
+            const u32x4 v = *(const u32x4*)(img + r * PITCH + c * 16);
+            if (X2_STORE_WT) store_wt16(rsO, ((size_t)r * E + c * 8) * 2, v);
+            else *(u32x4*)(dst + (size_t)r * E + c * 8) = v;
         }
     }
 }
