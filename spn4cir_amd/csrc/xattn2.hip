@@ -3,17 +3,18 @@
 //     dS = P o (dO' X^T - delta)                 xattn2_rows_kernel<.., 1>
 //     O' = P X,  dQ' = dS X                      xattn2_apply_kernel
 // Why a rebuild (round 6): the first generation runs 128 x 128 x 64 tiles on 4-wave workgroups with 32 x 64 (scores) / 64 x 64 wave
-// tiles.  Per k step such a wave moves 12-16 KB of fragments out of LDS for 256-512 MFMA cycles: with two workgroups on a CU the LDS
-// port (128 B / clk) is busy 2.2 x longer than the matrix pipe, and a k step is so short that the barrier, the DMA issue and the
-// fragment latency do not amortise (rocprof SQ pass, profiles/r05_blip_packed_sq_pmc.txt: matrix pipe busy 0.14 / 0.23 / 0.35).
-// Here ONE 8-wave workgroup per CU owns a tile whose wave tiles are 96 x 80 (rows kernel: 8 waves side by side over the 640 key
-// columns, every wave reads the same 96 query rows) or 96 x 96 (apply: 2 x 4 waves on 192 x 384): 30-36 MFMA per wave and k step of
-// 32, LDS bytes per MFMA cycle 0.55 x / 0.45 x of before, three LDS stages filled by LDS-DMA with counted waits, and - rows kernel - the
-// next k step's fragments prefetched into a second register set behind the current step's MFMAs.  96 rows = 8 tokens x 12 heads:
-// 4 tiles per dense sample at L = 32 -> 512 workgroups = two exact rounds of 256 CUs.
+// tiles: a k step is so short that the barrier, the request issue and the fragment latency do not amortise, and a workgroup streams
+// the sample's X once per 64 rows (rocprof SQ pass, profiles/r05_blip_packed_sq_pmc.txt: matrix pipe busy 0.14 / 0.23 / 0.35 at
+// 4.6-6.7 resident waves).  Here ONE 8-wave workgroup per CU owns a tile of 96 rows x all 640 key columns (rows kernel; 2 x 4 waves of
+// 48 x 80 on each of two column halves, both halves' accumulators in registers) or 192 x 384 (apply; 2 x 4 waves of 96 x 96): 30-36
+// MFMA per wave between barriers, LDS-DMA stages behind counted waits with the requests handed out one per MFMA group, and the next
+// phase's fragments prefetched into a second register set behind the current phase's MFMAs.  96 rows = 8 tokens x 12 heads: 4 tiles
+// per dense sample at L = 32 -> 512 workgroups = two exact rounds of 256 CUs.  What the kernels are bound by afterwards (bytes and the
+// CU's operand path, not the matrix pipe): LABNOTES.md 9.1; tools/x2probe (in-kernel phase stamps, -DX2_ELIM elimination builds).
 //
-// Operand images in LDS (k step of 32 bf16 = 64-byte rows): row r at r * 64, logical 16-byte k chunk c at position c ^ ((r >> 2) & 3)
-// (nt2_swz<32> of gemm2.hip).  Reduction-major X (apply): panels of [32 k][128 n], the tn image of gemm_v1_tiles.h.
+// Operand images in LDS: rows kernel, k step of 64 bf16 = 128-byte rows: row r at r * 128, logical 16-byte k chunk c at position
+// c ^ ((r >> 1) & 7) (nt_swz of gemm_v1_tiles.h); apply, k step of 32 (64-byte rows): chunk c at c ^ ((r >> 2) & 3) (nt2_swz<32> of
+// gemm2.hip); reduction-major X (apply): panels of [32 k][128 n], the tn image of gemm_v1_tiles.h.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
